@@ -1,0 +1,141 @@
+/*
+ * r2f.h -- C ABI of libr2f_hip.so: the MI355X (gfx950) film-emulation render path.
+ *
+ * This is the drop-in boundary under raw2film's processor objects.  The reference has no
+ * FFI for this path (it is Python + WGSL); each entry point below names the reference
+ * interface it stands in for (paths relative to /root/reference/src/raw2film/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative R2F_E* code on failure;
+ *     r2f_last_error(ctx) gives the message (thread-compatible: one ctx, one thread at a time,
+ *     like the reference's processor objects -- gui.py:2119-2129).
+ *   - `const float* host_*` arguments are HOST pointers (LUTs / stencils, copied to the device);
+ *     image buffers are DEVICE pointers owned by the caller (torch tensors on the Python side).
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - images are fp32.  Frame = H_global x W pixels; a call may address a row shard of it.
+ *
+ * No torch / C++ types cross this boundary.
+ */
+#ifndef R2F_H
+#define R2F_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct r2f_ctx r2f_ctx;
+
+enum {
+    R2F_OK = 0,
+    R2F_EINVAL = -1,   /* bad argument / missing LUT or stencil for an enabled stage */
+    R2F_EHIP = -2,     /* a HIP runtime call failed */
+    R2F_ETOOLARGE = -3 /* stencil does not fit the LDS tile configurations */
+};
+
+/* in_layout of r2f_render / r2f_stage_front */
+enum {
+    R2F_LAYOUT_HWC3 = 0, /* (H, W, 3) interleaved -- cpu_processor.py:136 `tex_input`            */
+    R2F_LAYOUT_HWC4 = 1, /* (H, W, 4), alpha ignored -- gpu_processor.py:765 `image_array`        */
+    R2F_LAYOUT_CHW = 2   /* 3 planes of (H, W) -- the device-native layout                         */
+};
+
+/* `which` of r2f_set_kernel */
+enum { R2F_KERNEL_HALATION = 0, R2F_KERNEL_MTF = 1, R2F_KERNEL_GRAIN = 2 };
+
+/* r2f_params.flags: stage gates, same conditions as cpu_processor.py:368,382,387 */
+enum {
+    R2F_F_MATRIX = 1u << 0,   /* S0: apply the 3x3 set by r2f_set_matrix3x3 (off = input already XYZ) */
+    R2F_F_HALATION = 1u << 1, /* S2 */
+    R2F_F_MTF = 1u << 2,      /* S5 */
+    R2F_F_GRAIN = 1u << 3,    /* S6 (+ the clip of cpu_processor.py:397) */
+    R2F_F_GRAIN_MONO = 1u << 4 /* grain == 1: noise_bw.wgsl */
+};
+
+/* `upto` of r2f_stage_front */
+enum { R2F_UPTO_EXPOSURE = 0, R2F_UPTO_DENSITY = 1, R2F_UPTO_OUTPUT = 2 };
+
+typedef struct r2f_params {
+    uint32_t flags;
+    uint32_t seed;      /* grain seed; upstream: random per render (gpu_processor.py:586-592) */
+    float log_eps;      /* lut_1d.wgsl:24 -> 1e-6 */
+    float lut3d_scale;  /* cpu_processor.py:405 -> 0.25 */
+    int32_t lut3d_mode; /* 0 tetrahedral (utils.py:247, the parity target), 1 trilinear (lut_3d.wgsl) */
+    int32_t reserved;
+} r2f_params;
+
+/* Three fp32 planes holding global rows [gy0, gy0+rows) of a frame, W floats per row. */
+typedef struct r2f_planes {
+    float* data;          /* device pointer to plane 0, row gy0 */
+    int64_t plane_stride; /* floats between consecutive channel planes (>= rows*W) */
+    int32_t gy0;
+    int32_t rows;
+} r2f_planes;
+
+/* --- lifetime: GpuProcessor.__init__ / device + pipeline creation, gpu_processor.py:73-257 --- */
+int r2f_create(int device, r2f_ctx** out);
+void r2f_destroy(r2f_ctx* ctx);
+const char* r2f_last_error(const r2f_ctx* ctx);
+/* "gfx950" build id + ABI version, for the loader's sanity check */
+const char* r2f_version(void);
+
+/* --- resource upload: the _ensure_* methods, gpu_processor.py:307-611 --- */
+/* S0 matrix, row-major 3x3 (data.py:128-135 for linear Rec.709 input). */
+int r2f_set_matrix3x3(r2f_ctx* ctx, const float* host_m9);
+/* S1 (n, n, 3) input LUT = negative_film.get_input_lut(...)   -- _ensure_lut_2d :349-376 */
+int r2f_set_lut2d(r2f_ctx* ctx, const float* host_lut, int n);
+/* S4 (4, m) density curve: row 0 xp, rows 1..3 fp              -- _ensure_lut_1d :307-347 */
+int r2f_set_curve1d(r2f_ctx* ctx, const float* host_lut4xm, int m);
+/* S8 (n, n, n, 3) output LUT = create_lut(..., linear_scaling=4) -- _ensure_lut_3d :378-409 */
+int r2f_set_lut3d(r2f_ctx* ctx, const float* host_lut, int n);
+/* S6c (4, m) grain LUT indexed by density                      -- _ensure_grain_lut :565-611 */
+int r2f_set_grain_lut(r2f_ctx* ctx, const float* host_lut4xm, int m);
+/* S2/S5/S6b stencil, (kh, kw, kc) row-major, kc in {1, 3}; correlation, anchor (kh/2, kw/2)
+ *   -- _ensure_halation_kernel :498-545, _ensure_mtf_kernel :411-451, _ensure_grain_kernel :453-496 */
+int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int kw, int kc);
+
+/* --- whole-frame render: CpuProcessor.process hot loop cpu_processor.py:363-407,
+ *     GpuProcessor._execute_gpu_pipeline gpu_processor.py:1756-1877 ---
+ * in: device image (in_layout), H x W.  out_f32_hwc / out_u8_hwc: device (H, W, 3), either may be NULL.
+ * workspace: device scratch of at least r2f_workspace_bytes(...) bytes (caller-owned). */
+size_t r2f_workspace_bytes(const r2f_params* p, int H, int W);
+int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32_hwc,
+               uint8_t* out_u8_hwc, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* --- stage entry points (row-shard aware): one per compute pass of
+ *     gpu_processor.py:1763-1862; used by the multi-GPU row tiler and by the parity tests.
+ * A call computes global rows [y0, y1) of an H_global x W frame.  Source rows outside
+ * [0, H_global) are reflected (BORDER_REFLECT_101, as cv.filter2D does on the CPU path);
+ * every reflected source row must lie inside the source buffer's [gy0, gy0+rows). --- */
+
+/* S0+S1 (+S3+S4 (+S8)) pointwise.  `in` holds global rows [in_gy0, in_gy0+in_rows).
+ * upto=EXPOSURE/DENSITY writes planes `dst`; upto=OUTPUT writes out_* (rows indexed from out_gy0). */
+int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
+                    int upto, const r2f_planes* dst, float* out_f32_hwc, uint8_t* out_u8_hwc, int out_gy0, int y0,
+                    int y1, int W, int H_global, void* stream);
+/* S2 halation stencil on exposure + S3 log + S4 curve -> density planes. */
+int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,
+                       int y0, int y1, int W, int H_global, void* stream);
+/* S5 MTF stencil on density -> density planes. */
+int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
+                  int y0, int y1, int W, int H_global, void* stream);
+/* [S6 grain + clip] + S8 3-D LUT (+ S9 uint8 truncation) -> interleaved output. */
+int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* out_f32_hwc,
+                   uint8_t* out_u8_hwc, int out_gy0, int y0, int y1, int W, int H_global, void* stream);
+/* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
+ * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
+int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,
+                    int W, void* stream);
+/* Test entry: plain per-channel stencil (no epilogue) with the kernel set for `which`. */
+int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W,
+                      int H_global, void* stream);
+
+/* Tuning knob for A/B runs: stencil tile variant (0 = auto). */
+int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R2F_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libr2f_hip.so (C ABI declared in include/r2f.h).
+
+The product path has NO CPU fallback: if the library is missing or a symbol is absent the
+import of the binding raises, and every render call goes through these entry points.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
+
+# enums of include/r2f.h
+LAYOUT_HWC3, LAYOUT_HWC4, LAYOUT_CHW = 0, 1, 2
+KERNEL_HALATION, KERNEL_MTF, KERNEL_GRAIN = 0, 1, 2
+F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO = 1, 2, 4, 8, 16
+UPTO_EXPOSURE, UPTO_DENSITY, UPTO_OUTPUT = 0, 1, 2
+OK, EINVAL, EHIP, ETOOLARGE = 0, -1, -2, -3
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("flags", C.c_uint32),
+        ("seed", C.c_uint32),
+        ("log_eps", C.c_float),
+        ("lut3d_scale", C.c_float),
+        ("lut3d_mode", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Planes(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("plane_stride", C.c_int64),
+        ("gy0", C.c_int32),
+        ("rows", C.c_int32),
+    ]
+
+
+_P = C.POINTER
+_fp = C.c_void_p  # float* (host numpy or device) passed as an address
+_SIGNATURES = {
+    "r2f_version": (C.c_char_p, []),
+    "r2f_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
+    "r2f_destroy": (None, [C.c_void_p]),
+    "r2f_last_error": (C.c_char_p, [C.c_void_p]),
+    "r2f_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "r2f_set_matrix3x3": (C.c_int, [C.c_void_p, _fp]),
+    "r2f_set_lut2d": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "r2f_set_curve1d": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "r2f_set_lut3d": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "r2f_set_grain_lut": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "r2f_set_kernel": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
+    "r2f_workspace_bytes": (C.c_size_t, [_P(Params), C.c_int, C.c_int]),
+    "r2f_render": (
+        C.c_int,
+        [C.c_void_p, _P(Params), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "r2f_stage_front": (
+        C.c_int,
+        [C.c_void_p, _P(Params), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _P(Planes), C.c_void_p, C.c_void_p,
+         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_halation": (
+        C.c_int,
+        [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_mtf": (
+        C.c_int,
+        [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_tail": (
+        C.c_int,
+        [C.c_void_p, _P(Params), _P(Planes), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_noise": (
+        C.c_int,
+        [C.c_void_p, _P(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_stencil": (
+        C.c_int,
+        [C.c_void_p, C.c_int, _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every symbol of include/r2f.h; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m raw2film_amd.build` (hipcc, gfx950). "
+            "raw2film_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

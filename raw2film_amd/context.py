@@ -1,0 +1,236 @@
+"""HipContext: a thin object over the C ABI (include/r2f.h), torch tensors as device buffers.
+
+One context per GPU, entered by one thread at a time (the reference's processors have the
+same rule, gui.py:2119-2129).  All launches go to torch's current stream on that device.
+torch is used for memory and streams only; every computation is a HIP kernel of libr2f_hip.so.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+LOG_EPS = 1e-6  # lut_1d.wgsl:24
+LUT3D_SCALE = 0.25  # cpu_processor.py:405
+
+
+class R2FError(RuntimeError):
+    pass
+
+
+def _host_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class HipContext:
+    def __init__(self, device: int = 0):
+        import torch
+
+        self._torch = torch
+        self._lib = _lib.load()  # raises ImportError if the HIP library is missing -- no fallback
+        if not torch.cuda.is_available():
+            raise R2FError("raw2film_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device("cuda", device)
+        handle = C.c_void_p()
+        rc = self._lib.r2f_create(int(device), C.byref(handle))
+        if rc != 0 or not handle.value:
+            raise R2FError(f"r2f_create(device={device}) failed with code {rc}")
+        self._h = handle
+        self._workspace = None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.r2f_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.r2f_last_error(self._h).decode(errors="replace")
+            if rc == _lib.EINVAL:
+                raise ValueError(msg)
+            raise R2FError(f"r2f error {rc}: {msg}")
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def make_params(self, *, matrix=False, halation=False, mtf=False, grain=False, grain_mono=False, seed=0,
+                    lut3d_mode=0, log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE) -> _lib.Params:
+        flags = (
+            (_lib.F_MATRIX if matrix else 0)
+            | (_lib.F_HALATION if halation else 0)
+            | (_lib.F_MTF if mtf else 0)
+            | (_lib.F_GRAIN if grain else 0)
+            | (_lib.F_GRAIN_MONO if grain_mono else 0)
+        )
+        return _lib.Params(flags, int(seed) & 0xFFFFFFFF, float(log_eps), float(lut3d_scale), int(lut3d_mode), 0)
+
+    def planes(self, t, gy0: int = 0) -> _lib.Planes:
+        """Describe a contiguous float32 (3, rows, W) device tensor holding global rows gy0.."""
+        torch = self._torch
+        if t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("planes: need a contiguous float32 CUDA tensor of shape (3, rows, W)")
+        return _lib.Planes(t.data_ptr(), int(t.shape[1]) * int(t.shape[2]), int(gy0), int(t.shape[1]))
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.r2f_set_option(self._h, name.encode(), int(value)))
+
+    # ------------------------------------------------------------------ uploads
+    def set_matrix3x3(self, m):
+        if m is None:
+            self._check(self._lib.r2f_set_matrix3x3(self._h, None))
+            return
+        m = _host_f32(m)
+        if m.shape != (3, 3):
+            raise ValueError("matrix must be 3x3")
+        self._check(self._lib.r2f_set_matrix3x3(self._h, m.ctypes.data))
+
+    def set_lut2d(self, lut):
+        lut = _host_f32(lut)
+        if lut.ndim != 3 or lut.shape[0] != lut.shape[1] or lut.shape[2] != 3:
+            raise ValueError(f"input LUT must be (n, n, 3), got {lut.shape}")
+        self._check(self._lib.r2f_set_lut2d(self._h, lut.ctypes.data, lut.shape[0]))
+
+    def set_curve1d(self, lut):
+        lut = _host_f32(lut)
+        if lut.ndim != 2 or lut.shape[0] != 4:
+            raise ValueError(f"density curve must be (4, m), got {lut.shape}")
+        self._check(self._lib.r2f_set_curve1d(self._h, lut.ctypes.data, lut.shape[1]))
+
+    def set_lut3d(self, lut):
+        lut = _host_f32(lut)
+        if lut.ndim != 4 or lut.shape[3] != 3 or not (lut.shape[0] == lut.shape[1] == lut.shape[2]):
+            raise ValueError(f"output LUT must be (n, n, n, 3), got {lut.shape}")
+        self._check(self._lib.r2f_set_lut3d(self._h, lut.ctypes.data, lut.shape[0]))
+
+    def set_grain_lut(self, lut):
+        lut = _host_f32(lut)
+        if lut.ndim != 2 or lut.shape[0] != 4:
+            raise ValueError(f"grain LUT must be (4, m), got {lut.shape}")
+        self._check(self._lib.r2f_set_grain_lut(self._h, lut.ctypes.data, lut.shape[1]))
+
+    def set_kernel(self, which: int, k):
+        k = _host_f32(k)
+        if k.ndim == 2:
+            k = k[..., None]
+        if k.ndim != 3 or k.shape[2] not in (1, 3):
+            raise ValueError(f"stencil must be (kh, kw) or (kh, kw, 1|3), got {k.shape}")
+        k = np.ascontiguousarray(k)
+        self._check(self._lib.r2f_set_kernel(self._h, int(which), k.ctypes.data, k.shape[0], k.shape[1], k.shape[2]))
+
+    # ------------------------------------------------------------------ whole frame
+    @staticmethod
+    def layout_of(t) -> tuple[int, int, int]:
+        """(layout, H, W) of an image tensor: (H, W, 3) / (H, W, 4) interleaved or (3, H, W) planar."""
+        if t.dim() != 3:
+            raise ValueError("image must be 3-D")
+        if t.shape[2] == 3:
+            return _lib.LAYOUT_HWC3, int(t.shape[0]), int(t.shape[1])
+        if t.shape[2] == 4:
+            return _lib.LAYOUT_HWC4, int(t.shape[0]), int(t.shape[1])
+        if t.shape[0] == 3:
+            return _lib.LAYOUT_CHW, int(t.shape[1]), int(t.shape[2])
+        raise ValueError(f"cannot interpret image shape {tuple(t.shape)}")
+
+    def _check_image(self, t):
+        torch = self._torch
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("image must be a contiguous float32 CUDA tensor")
+
+    def workspace_bytes(self, params, H, W) -> int:
+        return int(self._lib.r2f_workspace_bytes(C.byref(params), H, W))
+
+    def _get_workspace(self, nbytes: int):
+        torch = self._torch
+        if nbytes == 0:
+            return None
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None
+            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def render(self, image, params, out_f32=None, out_u8=None, want_f32=True, want_u8=False):
+        """Full pipeline on one frame: S0..S8 (+S9).  Returns (out_f32, out_u8) device tensors (H, W, 3)."""
+        torch = self._torch
+        self._check_image(image)
+        layout, H, W = self.layout_of(image)
+        if out_f32 is None and want_f32:
+            out_f32 = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+        if out_u8 is None and want_u8:
+            out_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        nbytes = self.workspace_bytes(params, H, W)
+        ws = self._get_workspace(nbytes)
+        rc = self._lib.r2f_render(
+            self._h, C.byref(params), image.data_ptr(), layout,
+            out_f32.data_ptr() if out_f32 is not None else None,
+            out_u8.data_ptr() if out_u8 is not None else None,
+            H, W, ws.data_ptr() if ws is not None else None, nbytes, self._stream(),
+        )
+        self._check(rc)
+        return out_f32, out_u8
+
+    # ------------------------------------------------------------------ stages (row-shard aware)
+    def stage_front(self, image, params, upto, *, in_gy0=0, dst=None, dst_gy0=0, out_f32=None, out_u8=None,
+                    out_gy0=0, y0=None, y1=None, H_global=None):
+        self._check_image(image)
+        layout, rows, W = self.layout_of(image)
+        y0 = in_gy0 if y0 is None else y0
+        y1 = in_gy0 + rows if y1 is None else y1
+        H_global = in_gy0 + rows if H_global is None else H_global
+        pl = self.planes(dst, dst_gy0) if dst is not None else None
+        rc = self._lib.r2f_stage_front(
+            self._h, C.byref(params), image.data_ptr(), layout, in_gy0, rows, int(upto),
+            C.byref(pl) if pl is not None else None,
+            out_f32.data_ptr() if out_f32 is not None else None,
+            out_u8.data_ptr() if out_u8 is not None else None,
+            out_gy0, y0, y1, W, H_global, self._stream(),
+        )
+        self._check(rc)
+
+    def _stencil_call(self, fn, first, src, src_gy0, dst, dst_gy0, y0, y1, H_global):
+        ps, pd = self.planes(src, src_gy0), self.planes(dst, dst_gy0)
+        W = int(src.shape[2])
+        if int(dst.shape[2]) != W:
+            raise ValueError("source and destination widths differ")
+        self._check(fn(self._h, first, C.byref(ps), C.byref(pd), y0, y1, W, H_global, self._stream()))
+
+    def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
+        self._stencil_call(self._lib.r2f_stage_halation, C.byref(params), exposure, src_gy0, density, dst_gy0, y0, y1, H_global)
+
+    def stage_mtf(self, density_in, density_out, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
+        self._stencil_call(self._lib.r2f_stage_mtf, C.byref(params), density_in, src_gy0, density_out, dst_gy0, y0, y1, H_global)
+
+    def stage_stencil(self, which, src, dst, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
+        self._stencil_call(self._lib.r2f_stage_stencil, int(which), src, src_gy0, dst, dst_gy0, y0, y1, H_global)
+
+    def stage_tail(self, density, params, *, src_gy0=0, out_f32=None, out_u8=None, out_gy0=0, y0, y1, H_global):
+        pd = self.planes(density, src_gy0)
+        W = int(density.shape[2])
+        rc = self._lib.r2f_stage_tail(
+            self._h, C.byref(params), C.byref(pd),
+            out_f32.data_ptr() if out_f32 is not None else None,
+            out_u8.data_ptr() if out_u8 is not None else None,
+            out_gy0, y0, y1, W, H_global, self._stream(),
+        )
+        self._check(rc)
+
+    def stage_noise(self, params, y0, y1, W, want_hash=True, want_noise=True):
+        torch = self._torch
+        rows = y1 - y0
+        h = torch.empty((3, rows, W), dtype=torch.int32, device=self.device) if want_hash else None
+        n = torch.empty((3, rows, W), dtype=torch.float32, device=self.device) if want_noise else None
+        rc = self._lib.r2f_stage_noise(
+            self._h, C.byref(params), h.data_ptr() if h is not None else None,
+            n.data_ptr() if n is not None else None, y0, y1, W, self._stream(),
+        )
+        self._check(rc)
+        return h, n

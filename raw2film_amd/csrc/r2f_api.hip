@@ -1,0 +1,590 @@
+// r2f_api.hip -- C ABI (include/r2f.h) over the gfx950 kernels: context, table upload,
+// stencil re-ordering, stage dispatch and the whole-frame render graph.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/r2f.h"
+#include "r2f_launch.h"
+
+using namespace r2f;
+
+namespace {
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+// Host copy of one stencil as handed to r2f_set_kernel, plus its device form per Q.
+struct StencilSet {
+    bool present = false;
+    int kh = 0, kw = 0, kc = 0;
+    std::vector<float> host;  // (kh, kw, kc)
+    int built_q = 0;          // 0 = device form stale
+    bool common_box = false;
+    DevStencil dev[3];
+    DeviceBuf wbuf[3], mbuf[3];
+    int maxk = 0;
+};
+
+}  // namespace
+
+struct r2f_ctx {
+    int device = 0;
+    std::string err;
+    bool has_matrix = false;
+    Mat3 mat;
+    DeviceBuf lut2d_buf, lut3d_buf, curve_buf, grain_lut_buf;
+    DevLut2D lut2d{nullptr, 0};
+    DevLut3D lut3d{nullptr, 0};
+    DevCurve curve{nullptr, 0, 0.f, 0.f};
+    DevCurve grain_lut{nullptr, 0, 0.f, 0.f};
+    StencilSet stencil[3];
+    int opt_variant = -1;  // -1 auto
+    int opt_xcd_remap = 1;
+};
+
+namespace {
+
+int fail(r2f_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define R2F_HIP(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ctx, R2F_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int upload(r2f_ctx* ctx, DeviceBuf& buf, const void* host, size_t bytes) {
+    if (buf.bytes < bytes) {
+        buf.release();
+        R2F_HIP(ctx, hipMalloc(&buf.p, bytes));
+        buf.bytes = bytes;
+    }
+    R2F_HIP(ctx, hipMemcpy(buf.p, host, bytes, hipMemcpyHostToDevice));
+    return R2F_OK;
+}
+
+// (4, m) table -> xp[m] | per channel fp[m], slope[m]; slopes in double like np.interp.
+int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, int m) {
+    if (!lut || m < 1) return fail(ctx, R2F_EINVAL, "curve: need a (4, m) table with m >= 1");
+    std::vector<float> packed((size_t)7 * m);
+    for (int i = 0; i < m; ++i) packed[i] = lut[i];
+    for (int c = 0; c < 3; ++c) {
+        const float* fp = lut + (size_t)(1 + c) * m;
+        float* dfp = packed.data() + (size_t)m * (1 + 2 * c);
+        float* dsl = dfp + m;
+        for (int i = 0; i < m; ++i) {
+            dfp[i] = fp[i];
+            if (i + 1 < m) {
+                const double dx = (double)lut[i + 1] - (double)lut[i];
+                dsl[i] = dx != 0.0 ? (float)(((double)fp[i + 1] - (double)fp[i]) / dx) : 0.f;
+            } else {
+                dsl[i] = 0.f;
+            }
+        }
+    }
+    for (int i = 0; i + 1 < m; ++i)
+        if (!(lut[i + 1] >= lut[i])) return fail(ctx, R2F_EINVAL, "curve: xp must be non-decreasing");
+    int rc = upload(ctx, buf, packed.data(), packed.size() * sizeof(float));
+    if (rc) return rc;
+    cv.data = static_cast<const float*>(buf.p);
+    cv.m = m;
+    cv.x0 = lut[0];
+    const float range = lut[m - 1] - lut[0];
+    cv.inv_step = (m > 1 && range > 0.f) ? (float)(m - 1) / range : 0.f;
+    return R2F_OK;
+}
+
+// Re-order one channel of a stencil for stencil_accumulate<Q> (layout documented in r2f_device.h).
+// The taps are cropped to the bounding box [i_lo..i_hi] x [j_lo..j_hi] given by the caller.
+void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int j_hi, int Q, std::vector<float>& w,
+                  std::vector<int4>& meta) {
+    const int kh = i_hi - i_lo + 1, kw = j_hi - j_lo + 1;
+    const int nch = (kw + 3) / 4;
+    const int M = kh + Q - 1;
+    w.clear();
+    meta.assign(M, make_int4(0, 0, 0, 0));
+    auto tap = [&](int i, int j) -> float {
+        if (i < 0 || i >= kh || j < 0 || j >= kw) return 0.f;
+        return k[(size_t)(i + i_lo) * kw_full + (j + j_lo)];
+    };
+    for (int m = 0; m < M; ++m) {
+        int c_lo = nch, c_hi = -1;
+        for (int c = 0; c < nch; ++c) {
+            bool nz = false;
+            for (int q = 0; q < Q && !nz; ++q)
+                for (int t = 0; t < 4; ++t)
+                    if (tap(m - q, 4 * c + t) != 0.f) {
+                        nz = true;
+                        break;
+                    }
+            if (nz) {
+                if (c < c_lo) c_lo = c;
+                c_hi = c;
+            }
+        }
+        if (c_hi < 0) continue;  // no work on this row step
+        meta[m] = make_int4(c_lo, c_hi - c_lo + 1, (int)w.size(), 0);
+        for (int c = c_lo; c <= c_hi; ++c)
+            for (int q = 0; q < Q; ++q)
+                for (int t = 0; t < 4; ++t) w.push_back(tap(m - q, 4 * c + t));
+    }
+    if (w.empty()) w.push_back(0.f);
+}
+
+int ensure_stencil(r2f_ctx* ctx, int which, int Q, bool common_box) {
+    StencilSet& s = ctx->stencil[which];
+    if (!s.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
+    if (s.built_q == Q && s.common_box == common_box) return R2F_OK;
+    int box[3][4];
+    for (int c = 0; c < 3; ++c) {
+        const int kc = s.kc == 1 ? 0 : c;
+        int i_lo = s.kh, i_hi = -1, j_lo = s.kw, j_hi = -1;
+        for (int i = 0; i < s.kh; ++i)
+            for (int j = 0; j < s.kw; ++j)
+                if (s.host[((size_t)i * s.kw + j) * s.kc + kc] != 0.f) {
+                    i_lo = std::min(i_lo, i);
+                    i_hi = std::max(i_hi, i);
+                    j_lo = std::min(j_lo, j);
+                    j_hi = std::max(j_hi, j);
+                }
+        if (i_hi < 0) i_lo = i_hi = s.kh / 2, j_lo = j_hi = s.kw / 2;  // all-zero stencil: keep one (zero) tap
+        box[c][0] = i_lo, box[c][1] = i_hi, box[c][2] = j_lo, box[c][3] = j_hi;
+    }
+    if (common_box) {
+        for (int c = 1; c < 3; ++c) {
+            box[0][0] = std::min(box[0][0], box[c][0]);
+            box[0][1] = std::max(box[0][1], box[c][1]);
+            box[0][2] = std::min(box[0][2], box[c][2]);
+            box[0][3] = std::max(box[0][3], box[c][3]);
+        }
+        for (int c = 1; c < 3; ++c) memcpy(box[c], box[0], sizeof box[0]);
+    }
+    std::vector<float> plane((size_t)s.kh * s.kw), w;
+    std::vector<int4> meta;
+    s.maxk = 0;
+    for (int c = 0; c < 3; ++c) {
+        const int kc = s.kc == 1 ? 0 : c;
+        for (size_t i = 0; i < plane.size(); ++i) plane[i] = s.host[i * s.kc + kc];
+        build_stream(plane.data(), s.kw, box[c][0], box[c][1], box[c][2], box[c][3], Q, w, meta);
+        int rc = upload(ctx, s.wbuf[c], w.data(), w.size() * sizeof(float));
+        if (rc) return rc;
+        rc = upload(ctx, s.mbuf[c], meta.data(), meta.size() * sizeof(int4));
+        if (rc) return rc;
+        DevStencil& d = s.dev[c];
+        d.wstream = static_cast<const float*>(s.wbuf[c].p);
+        d.rowmeta = static_cast<const int4*>(s.mbuf[c].p);
+        d.kh = box[c][1] - box[c][0] + 1;
+        d.kw = box[c][3] - box[c][2] + 1;
+        d.kw_pad = (d.kw + 3) / 4 * 4;
+        d.M = d.kh + Q - 1;
+        d.ay = s.kh / 2 - box[c][0];  // anchor (kh/2, kw/2): convolution.wgsl:31, cv.filter2D default
+        d.ax = s.kw / 2 - box[c][2];
+        s.maxk = std::max(s.maxk, std::max(d.kh, d.kw));
+    }
+    s.built_q = Q;
+    s.common_box = common_box;
+    return R2F_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool planes_vec_ok(const r2f_planes* pl, int W) {
+    return W % 4 == 0 && aligned16(pl->data) && pl->plane_stride % 4 == 0;
+}
+
+DevPlanes to_dev(const r2f_planes* pl) {
+    DevPlanes d;
+    d.data = pl->data;
+    d.plane_stride = pl->plane_stride;
+    d.gy0 = pl->gy0;
+    d.rows = pl->rows;
+    return d;
+}
+
+int check_rows(r2f_ctx* ctx, const char* what, const r2f_planes* pl, int lo, int hi) {
+    if (!pl || !pl->data) return fail(ctx, R2F_EINVAL, "%s: null planes", what);
+    if (lo < pl->gy0 || hi > pl->gy0 + pl->rows)
+        return fail(ctx, R2F_EINVAL, "%s: rows [%d, %d) not inside the buffer's [%d, %d)", what, lo, hi, pl->gy0,
+                    pl->gy0 + pl->rows);
+    return R2F_OK;
+}
+
+// Source rows a stencil with `above`/`below` taps needs for outputs [y0, y1), after reflect-101.
+int check_stencil_source(r2f_ctx* ctx, const char* what, const r2f_planes* src, int y0, int y1, int above, int below,
+                         int H) {
+    int lo = y0 - above, hi = y1 - 1 + below;  // inclusive
+    int need_lo = std::max(lo, 0), need_hi = std::min(hi, H - 1);
+    if (H > 1) {
+        if (lo < 0) need_hi = std::max(need_hi, std::min(-lo, H - 1));
+        if (hi > H - 1) need_lo = std::min(need_lo, std::max(2 * (H - 1) - hi, 0));
+    }
+    return check_rows(ctx, what, src, need_lo, need_hi + 1);
+}
+
+int pick_variant(r2f_ctx* ctx, const DevStencil* st, int nchan, int Q_of_built, int* variant) {
+    (void)Q_of_built;
+    for (int v = 0; v < kNumStencilVariants; ++v) {
+        if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
+        if (stencil_lds_bytes(kStencilVariants[v], st, nchan) <= kMaxLds) {
+            *variant = v;
+            return R2F_OK;
+        }
+    }
+    return fail(ctx, R2F_ETOOLARGE, "stencil does not fit any LDS tile variant (<= %zu bytes)", kMaxLds);
+}
+
+int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
+                int epilogue, float log_eps, hipStream_t s) {
+    if (y1 <= y0) return R2F_OK;
+    if (W <= 0 || H <= 0 || y0 < 0 || y1 > H) return fail(ctx, R2F_EINVAL, "stencil: bad geometry");
+    StencilSet& set = ctx->stencil[which];
+    if (!set.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
+    // choose the tile variant from the stencil size; the stream layout depends on its Q
+    int variant = -1;
+    for (int v = 0; v < kNumStencilVariants; ++v) {
+        if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
+        int rc = ensure_stencil(ctx, which, kStencilVariants[v].Q, false);
+        if (rc) return rc;
+        if (stencil_lds_bytes(kStencilVariants[v], set.dev, 3) <= kMaxLds) {
+            variant = v;
+            break;
+        }
+    }
+    if (variant < 0) return fail(ctx, R2F_ETOOLARGE, "stencil %d: %dx%d taps do not fit an LDS tile", which, set.kh, set.kw);
+    int rc = check_rows(ctx, "stencil dst", dst, y0, y1);
+    if (rc) return rc;
+    for (int c = 0; c < 3; ++c) {
+        const DevStencil& d = set.dev[c];
+        rc = check_stencil_source(ctx, "stencil src", src, y0, y1, d.ay, d.kh - 1 - d.ay, H);
+        if (rc) return rc;
+    }
+    if (epilogue == 1 && !ctx->curve.data) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
+    StencilArgs a;
+    for (int c = 0; c < 3; ++c) a.st[c] = set.dev[c];
+    a.src = to_dev(src);
+    a.dst = to_dev(dst);
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.H_global = H;
+    a.epilogue = epilogue;
+    a.curve = ctx->curve;
+    a.log_eps = log_eps;
+    a.nchan = 3;
+    a.vec = planes_vec_ok(dst, W) ? 1 : 0;
+    a.xcd_remap = ctx->opt_xcd_remap;
+    R2F_HIP(ctx, launch_stencil(a, variant, s));
+    return R2F_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* r2f_version(void) { return "r2f-hip 0.1 gfx950 abi1"; }
+
+int r2f_create(int device, r2f_ctx** out) {
+    if (!out) return R2F_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return R2F_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return R2F_EHIP;
+    if (init_kernel_attributes() != hipSuccess) return R2F_EHIP;
+    r2f_ctx* ctx = new r2f_ctx();
+    ctx->device = device;
+    *out = ctx;
+    return R2F_OK;
+}
+
+void r2f_destroy(r2f_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    ctx->lut2d_buf.release();
+    ctx->lut3d_buf.release();
+    ctx->curve_buf.release();
+    ctx->grain_lut_buf.release();
+    for (auto& s : ctx->stencil)
+        for (int c = 0; c < 3; ++c) {
+            s.wbuf[c].release();
+            s.mbuf[c].release();
+        }
+    delete ctx;
+}
+
+const char* r2f_last_error(const r2f_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return R2F_EINVAL;
+    if (!strcmp(name, "stencil_variant")) {
+        if (value < -1 || value >= kNumStencilVariants) return fail(ctx, R2F_EINVAL, "stencil_variant out of range");
+        ctx->opt_variant = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "xcd_remap")) {
+        ctx->opt_xcd_remap = value ? 1 : 0;
+        return R2F_OK;
+    }
+    return fail(ctx, R2F_EINVAL, "unknown option %s", name);
+}
+
+int r2f_set_matrix3x3(r2f_ctx* ctx, const float* m) {
+    if (!ctx) return R2F_EINVAL;
+    ctx->has_matrix = m != nullptr;
+    if (m) memcpy(ctx->mat.m, m, sizeof ctx->mat.m);
+    return R2F_OK;
+}
+
+int r2f_set_lut2d(r2f_ctx* ctx, const float* lut, int n) {
+    if (!ctx) return R2F_EINVAL;
+    if (!lut || n < 2) return fail(ctx, R2F_EINVAL, "lut2d: need (n, n, 3) with n >= 2");
+    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float4> tex((size_t)n * n);
+    for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(lut[3 * i], lut[3 * i + 1], lut[3 * i + 2], 0.f);
+    int rc = upload(ctx, ctx->lut2d_buf, tex.data(), tex.size() * sizeof(float4));
+    if (rc) return rc;
+    ctx->lut2d.tex = static_cast<const float4*>(ctx->lut2d_buf.p);
+    ctx->lut2d.n = n;
+    return R2F_OK;
+}
+
+int r2f_set_lut3d(r2f_ctx* ctx, const float* lut, int n) {
+    if (!ctx) return R2F_EINVAL;
+    if (!lut || n < 2 || n > 256) return fail(ctx, R2F_EINVAL, "lut3d: need (n, n, n, 3) with 2 <= n <= 256");
+    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float4> tex((size_t)n * n * n);
+    for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(lut[3 * i], lut[3 * i + 1], lut[3 * i + 2], 0.f);
+    int rc = upload(ctx, ctx->lut3d_buf, tex.data(), tex.size() * sizeof(float4));
+    if (rc) return rc;
+    ctx->lut3d.tex = static_cast<const float4*>(ctx->lut3d_buf.p);
+    ctx->lut3d.n = n;
+    return R2F_OK;
+}
+
+int r2f_set_curve1d(r2f_ctx* ctx, const float* lut4xm, int m) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    return upload_curve(ctx, ctx->curve_buf, ctx->curve, lut4xm, m);
+}
+
+int r2f_set_grain_lut(r2f_ctx* ctx, const float* lut4xm, int m) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    return upload_curve(ctx, ctx->grain_lut_buf, ctx->grain_lut, lut4xm, m);
+}
+
+int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int kc) {
+    if (!ctx) return R2F_EINVAL;
+    if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "set_kernel: which must be 0..2");
+    if (!k || kh < 1 || kw < 1 || (kc != 1 && kc != 3)) return fail(ctx, R2F_EINVAL, "set_kernel: need (kh, kw, 1|3)");
+    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    StencilSet& s = ctx->stencil[which];
+    s.present = true;
+    s.kh = kh;
+    s.kw = kw;
+    s.kc = kc;
+    s.host.assign(k, k + (size_t)kh * kw * kc);
+    s.built_q = 0;
+    return R2F_OK;
+}
+
+// ------------------------------------------------------------------------------- stages
+int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
+                    const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
+                    int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    if (y1 <= y0) return R2F_OK;
+    if (!in || W <= 0 || y0 < in_gy0 || y1 > in_gy0 + in_rows || in_layout < 0 || in_layout > 2)
+        return fail(ctx, R2F_EINVAL, "front: bad input geometry");
+    if (!ctx->lut2d.tex) return fail(ctx, R2F_EINVAL, "input LUT not set (r2f_set_lut2d)");
+    if ((p->flags & R2F_F_MATRIX) && !ctx->has_matrix) return fail(ctx, R2F_EINVAL, "matrix not set (r2f_set_matrix3x3)");
+    FrontArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = in;
+    a.in_layout = in_layout;
+    a.in_gy0 = in_gy0;
+    a.in_rows = in_rows;
+    a.upto = upto;
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.H_global = H_global;
+    a.use_matrix = (p->flags & R2F_F_MATRIX) ? 1 : 0;
+    a.mat = ctx->mat;
+    a.lut2d = ctx->lut2d;
+    a.curve = ctx->curve;
+    a.lut3d = ctx->lut3d;
+    a.log_eps = p->log_eps;
+    a.lut3d_scale = p->lut3d_scale;
+    a.lut3d_mode = p->lut3d_mode;
+    bool vec = W % 4 == 0 && aligned16(in);
+    if (upto >= R2F_UPTO_DENSITY && !ctx->curve.data) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
+    if (upto == R2F_UPTO_OUTPUT) {
+        if (!ctx->lut3d.tex) return fail(ctx, R2F_EINVAL, "output LUT not set (r2f_set_lut3d)");
+        if (!out_f32 && !out_u8) return fail(ctx, R2F_EINVAL, "front: no output buffer");
+        if (y0 < out_gy0) return fail(ctx, R2F_EINVAL, "front: y0 above the output buffer");
+        a.out_f32 = out_f32;
+        a.out_u8 = out_u8;
+        a.out_gy0 = out_gy0;
+        vec = vec && (!out_f32 || aligned16(out_f32)) && (!out_u8 || (reinterpret_cast<uintptr_t>(out_u8) & 3u) == 0);
+    } else if (upto == R2F_UPTO_EXPOSURE || upto == R2F_UPTO_DENSITY) {
+        int rc = check_rows(ctx, "front dst", dst, y0, y1);
+        if (rc) return rc;
+        a.dst = to_dev(dst);
+        vec = vec && planes_vec_ok(dst, W);
+    } else {
+        return fail(ctx, R2F_EINVAL, "front: bad upto");
+    }
+    a.vec = vec ? 1 : 0;
+    R2F_HIP(ctx, launch_front(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density, int y0,
+                       int y1, int W, int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    return run_stencil(ctx, R2F_KERNEL_HALATION, exposure, density, y0, y1, W, H_global, 1, p->log_eps,
+                       static_cast<hipStream_t>(stream));
+}
+
+int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1,
+                  int W, int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    return run_stencil(ctx, R2F_KERNEL_MTF, din, dout, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
+}
+
+int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W,
+                      int H_global, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "stencil: which must be 0..2");
+    return run_stencil(ctx, which, src, dst, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
+}
+
+int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* out_f32, uint8_t* out_u8,
+                   int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    if (y1 <= y0) return R2F_OK;
+    if (W <= 0 || y0 < 0 || y1 > H_global || y0 < out_gy0) return fail(ctx, R2F_EINVAL, "tail: bad geometry");
+    if (!out_f32 && !out_u8) return fail(ctx, R2F_EINVAL, "tail: no output buffer");
+    if (!ctx->lut3d.tex) return fail(ctx, R2F_EINVAL, "output LUT not set (r2f_set_lut3d)");
+    int rc = check_rows(ctx, "tail src", density, y0, y1);
+    if (rc) return rc;
+    TailArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = to_dev(density);
+    a.out_f32 = out_f32;
+    a.out_u8 = out_u8;
+    a.out_gy0 = out_gy0;
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.H_global = H_global;
+    a.grain = (p->flags & R2F_F_GRAIN) ? 1 : 0;
+    a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
+    a.seed = p->seed;
+    a.lut3d = ctx->lut3d;
+    a.lut3d_scale = p->lut3d_scale;
+    a.lut3d_mode = p->lut3d_mode;
+    a.vec = (planes_vec_ok(density, W) && (!out_f32 || aligned16(out_f32)) &&
+             (!out_u8 || (reinterpret_cast<uintptr_t>(out_u8) & 3u) == 0))
+                ? 1
+                : 0;
+    if (a.grain) {
+        if (!ctx->grain_lut.data) return fail(ctx, R2F_EINVAL, "grain LUT not set (r2f_set_grain_lut)");
+        if (!ctx->stencil[R2F_KERNEL_GRAIN].present) {
+            // gpu_processor.py:931-932: no grain kernel -> 1x1 ones
+            const float one = 1.f;
+            rc = r2f_set_kernel(ctx, R2F_KERNEL_GRAIN, &one, 1, 1, 1);
+            if (rc) return rc;
+        }
+        rc = ensure_stencil(ctx, R2F_KERNEL_GRAIN, kTailQ, true);
+        if (rc) return rc;
+        for (int c = 0; c < 3; ++c) a.gk[c] = ctx->stencil[R2F_KERNEL_GRAIN].dev[c];
+        if (tail_lds_bytes(a.gk, a.mono) > kMaxLds)
+            return fail(ctx, R2F_ETOOLARGE, "grain stencil %dx%d does not fit the LDS noise tile", a.gk[0].kh, a.gk[0].kw);
+        a.grain_lut = ctx->grain_lut;
+    }
+    R2F_HIP(ctx, launch_tail(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1, int W,
+                    void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    NoiseArgs a;
+    a.hash = hash_planes;
+    a.noise = noise_planes;
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.seed = p->seed;
+    a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
+    R2F_HIP(ctx, launch_noise(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+// ------------------------------------------------------------------------------- whole frame
+static size_t plane_set_floats(int H, int W) { return ((size_t)H * W + 3) / 4 * 4 * 3; }
+
+size_t r2f_workspace_bytes(const r2f_params* p, int H, int W) {
+    if (!p || H <= 0 || W <= 0) return 0;
+    const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF, grain = p->flags & R2F_F_GRAIN;
+    int sets = 0;
+    if (hal || mtf || grain) sets = 1;
+    if (hal || mtf) sets = 2;
+    return sets * plane_set_floats(H, W) * sizeof(float);
+}
+
+int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32, uint8_t* out_u8, int H,
+               int W, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    if (H <= 0 || W <= 0) return fail(ctx, R2F_EINVAL, "render: empty frame");
+    const size_t need = r2f_workspace_bytes(p, H, W);
+    if (need > workspace_bytes || (need && !workspace)) return fail(ctx, R2F_EINVAL, "render: workspace too small (%zu needed)", need);
+    if (need && !aligned16(workspace)) return fail(ctx, R2F_EINVAL, "render: workspace must be 16-byte aligned");
+    const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF;
+    const bool any = hal || mtf || (p->flags & R2F_F_GRAIN);
+    if (!any)  // config "LUTs only": one fused pointwise pass
+        return r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_OUTPUT, nullptr, out_f32, out_u8, 0, 0, H, W, H, stream);
+    const size_t set_floats = plane_set_floats(H, W);
+    r2f_planes A{static_cast<float*>(workspace), (int64_t)(set_floats / 3), 0, H};
+    r2f_planes B{static_cast<float*>(workspace) + set_floats, (int64_t)(set_floats / 3), 0, H};
+    int rc = r2f_stage_front(ctx, p, in, in_layout, 0, H, hal ? R2F_UPTO_EXPOSURE : R2F_UPTO_DENSITY, &A, nullptr, nullptr,
+                             0, 0, H, W, H, stream);
+    if (rc) return rc;
+    const r2f_planes* cur = &A;
+    const r2f_planes* other = &B;
+    if (hal) {
+        rc = r2f_stage_halation(ctx, p, cur, other, 0, H, W, H, stream);
+        if (rc) return rc;
+        std::swap(cur, other);
+    }
+    if (mtf) {
+        rc = r2f_stage_mtf(ctx, p, cur, other, 0, H, W, H, stream);
+        if (rc) return rc;
+        std::swap(cur, other);
+    }
+    return r2f_stage_tail(ctx, p, cur, out_f32, out_u8, 0, 0, H, W, H, stream);
+}
+
+}  // extern "C"

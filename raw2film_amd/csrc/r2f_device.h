@@ -1,0 +1,285 @@
+// r2f_device.h -- device-side tables and per-pixel stage functions (gfx950 only).
+//
+// Stage numbering and the reference lines each function follows are in DESIGN.md and
+// include/r2f.h.  Everything here is fp32 VALU + integer work; there is no dense
+// contraction on this path, so no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Wave-uniform read-only tables are addressed through the constant address space so that
+// hipcc emits scalar (s_load) instructions and the values sit in SGPRs.
+#define R2F_CONSTANT __attribute__((address_space(4)))
+
+namespace r2f {
+
+// ---------------------------------------------------------------------------- tables
+// 1-D curve (S4 density curve, S6c grain LUT).  data = xp[m] | fp0[m] slope0[m] | fp1 slope1 | fp2 slope2
+struct DevCurve {
+    const float* data;
+    int m;
+    float x0;        // xp[0]
+    float inv_step;  // (m-1)/(xp[m-1]-xp[0]): first guess of the cell, corrected against xp[]
+};
+
+struct DevLut2D {  // S1: n*n float4 texels (rgb + pad), texel (xi, yi) at xi*n + yi
+    const float4* tex;
+    int n;
+};
+
+struct DevLut3D {  // S8: n^3 float4 texels, (r, g, b) at (r*n + g)*n + b
+    const float4* tex;
+    int n;
+};
+
+// One channel of a stencil, cropped to the bounding box of its non-zero taps and
+// re-ordered into the order the inner loop consumes it (see stencil_accumulate).
+struct DevStencil {
+    const float* wstream;  // per (m, chunk): Q*4 floats  w[q][t] = K[m-q][4*chunk+t]
+    const int4* rowmeta;   // per m: {first chunk, chunk count, float offset into wstream, 0}
+    int M;                 // kh + Q - 1 input-row steps
+    int kh, kw;            // cropped taps
+    int kw_pad;            // kw rounded up to a multiple of 4
+    int ay, ax;            // anchor inside the cropped box
+};
+
+struct DevPlanes {
+    float* data;
+    long long plane_stride;
+    int gy0;
+    int rows;
+};
+
+// ---------------------------------------------------------------------------- helpers
+// BORDER_REFLECT_101 (what cv.filter2D uses on the reference's CPU path): ... c b | a b c d | c b ...
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (i >= 0 && i < n) return i;
+    if (n == 1) return 0;
+    if (i < 0 && i > -n) return -i;
+    if (i >= n && i < 2 * n - 1) return 2 * n - 2 - i;
+    int period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// np.interp semantics: linear, clamped to fp[0] / fp[m-1] outside [xp[0], xp[m-1]].
+__device__ __forceinline__ float curve_eval(const DevCurve& cv, int ch, float x) {
+    const float* xp = cv.data;
+    const float* fp = cv.data + (size_t)cv.m * (1 + 2 * ch);
+    const float* sl = fp + cv.m;
+    const int m = cv.m;
+    if (!(x > xp[0])) return fp[0];
+    if (x >= xp[m - 1]) return fp[m - 1];
+    int i = (int)((x - cv.x0) * cv.inv_step);
+    i = clampi(i, 0, m - 2);
+    while (i > 0 && x < xp[i]) --i;
+    while (i < m - 2 && x >= xp[i + 1]) ++i;
+    return fmaf(sl[i], x - xp[i], fp[i]);
+}
+
+// S0: out = M . in, ((m0*r + m1*g) + m2*b)
+struct Mat3 {
+    float m[9];
+};
+__device__ __forceinline__ void apply_matrix(const Mat3& M, float& r, float& g, float& b) {
+    float x = (M.m[0] * r + M.m[1] * g) + M.m[2] * b;
+    float y = (M.m[3] * r + M.m[4] * g) + M.m[5] * b;
+    float z = (M.m[6] * r + M.m[7] * g) + M.m[8] * b;
+    r = x;
+    g = y;
+    b = z;
+}
+
+// S1: chromaticity-triangle 2-D LUT, lut_2d.wgsl:18-108.
+__device__ __forceinline__ void apply_lut2d(const DevLut2D& L, float& X, float& Y, float& Z) {
+    const float S = (X + Y) + Z;
+    if (S < 1e-12f) {
+        X = Y = Z = 0.f;
+        return;
+    }
+    const int n = L.n;
+    const float inv_sum = (float)(n - 1) / S;
+    const float r = X * inv_sum;
+    const float g = Y * inv_sum;
+    const float fr = floorf(r), fg = floorf(g);
+    const int ri = clampi((int)fr, 0, n - 2);
+    const int gi = clampi((int)fg, 0, n - 2);
+    const float rf = r - fr, gf = g - fg;
+    const float fsum = rf + gf;
+    const bool lower = fsum <= 1.0f;
+    const float4 rv = L.tex[(ri + 1) * n + gi];
+    const float4 gv = L.tex[ri * n + gi + 1];
+    const float4 sv = L.tex[(lower ? ri : ri + 1) * n + (lower ? gi : gi + 1)];
+    const float wr = lower ? rf : 1.0f - gf;
+    const float wg = lower ? gf : 1.0f - rf;
+    const float ws = lower ? 1.0f - fsum : fsum - 1.0f;
+    X = ((rv.x * wr + gv.x * wg) + sv.x * ws) * S;
+    Y = ((rv.y * wr + gv.y * wg) + sv.y * ws) * S;
+    Z = ((rv.z * wr + gv.z * wg) + sv.z * ws) * S;
+}
+
+// S3 + S4: log10(max(x, eps)) then the density curve.
+__device__ __forceinline__ float log_curve(const DevCurve& cv, int ch, float x, float eps) {
+    return curve_eval(cv, ch, log10f(fmaxf(x, eps)));
+}
+
+// S8 tetrahedral: utils.py:247-380 (tie rules `>=` kept), fp32.
+__device__ __forceinline__ void lut3d_axis(float x, float s, int n, int& lo, int& hi, float& d) {
+    const float t = x * s;
+    int i0 = (int)t;  // truncation toward zero, like int(r) in the reference
+    if (i0 >= n - 1) {
+        i0 = n - 2;
+        d = 1.0f;
+    } else {
+        d = t - (float)i0;
+    }
+    int i1 = i0 + 1;
+    // negative indices wrap like Python/numba indexing; clamp what would be out of bounds there
+    if (i0 < 0) i0 = i0 + n < 0 ? 0 : i0 + n;
+    if (i1 < 0) i1 = i1 + n < 0 ? 0 : i1 + n;
+    lo = i0;
+    hi = i1;
+}
+
+__device__ __forceinline__ void apply_lut3d_tetra(const DevLut3D& L, float s, float& r, float& g, float& b) {
+    const int n = L.n;
+    int rl, rh, gl, gh, bl, bh;
+    float dr, dg, db;
+    lut3d_axis(r, s, n, rl, rh, dr);
+    lut3d_axis(g, s, n, gl, gh, dg);
+    lut3d_axis(b, s, n, bl, bh, db);
+    const int base = (rl * n + gl) * n + bl;
+    const int er = (rh - rl) * n * n, eg = (gh - gl) * n, eb = bh - bl;
+    int e1, e2;
+    float d1, d2, d3;
+    if (dr >= dg) {
+        if (dg >= db) { e1 = er; e2 = eg; d1 = dr; d2 = dg; d3 = db; }
+        else if (dr >= db) { e1 = er; e2 = eb; d1 = dr; d2 = db; d3 = dg; }
+        else { e1 = eb; e2 = er; d1 = db; d2 = dr; d3 = dg; }
+    } else {
+        if (db >= dg) { e1 = eb; e2 = eg; d1 = db; d2 = dg; d3 = dr; }
+        else if (db >= dr) { e1 = eg; e2 = eb; d1 = dg; d2 = db; d3 = dr; }
+        else { e1 = eg; e2 = er; d1 = dg; d2 = dr; d3 = db; }
+    }
+    const float4 c0 = L.tex[base];
+    const float4 ca = L.tex[base + e1];
+    const float4 cb = L.tex[base + e1 + e2];
+    const float4 c1 = L.tex[base + er + eg + eb];
+    r = ((c0.x + d1 * (ca.x - c0.x)) + d2 * (cb.x - ca.x)) + d3 * (c1.x - cb.x);
+    g = ((c0.y + d1 * (ca.y - c0.y)) + d2 * (cb.y - ca.y)) + d3 * (c1.y - cb.y);
+    b = ((c0.z + d1 * (ca.z - c0.z)) + d2 * (cb.z - ca.z)) + d3 * (c1.z - cb.z);
+}
+
+// S8 GPU-variant: trilinear between texel centres, lut_3d.wgsl:27-40 (fp32 LUT).
+__device__ __forceinline__ void apply_lut3d_trilinear(const DevLut3D& L, float scale, float& r, float& g, float& b) {
+    const int n = L.n;
+    float t[3] = {r, g, b};
+    int i0[3];
+    float f[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float v = fminf(fmaxf(t[a] * scale, 0.f), 1.f) * (float)(n - 1);
+        int i = (int)floorf(v);
+        if (i > n - 2) i = n - 2;
+        i0[a] = i;
+        f[a] = v - (float)i;
+    }
+    float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int a = c >> 2, bq = (c >> 1) & 1, cq = c & 1;
+        const float w = (a ? f[0] : 1.f - f[0]) * (bq ? f[1] : 1.f - f[1]) * (cq ? f[2] : 1.f - f[2]);
+        const float4 v = L.tex[((i0[0] + a) * n + i0[1] + bq) * n + i0[2] + cq];
+        o[0] += w * v.x;
+        o[1] += w * v.y;
+        o[2] += w * v.z;
+    }
+    r = o[0];
+    g = o[1];
+    b = o[2];
+}
+
+// S6a: PCG3D hash, noise.wgsl:14-20 (uint32 wrap-around arithmetic).
+__device__ __forceinline__ void pcg3d(uint32_t& x, uint32_t& y, uint32_t& z) {
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    x += y * z;
+    y += z * x;
+    z += x * y;
+    x ^= x >> 16;
+    y ^= y >> 16;
+    z ^= z >> 16;
+    x += y * z;
+    y += z * x;
+    z += x * y;
+}
+
+// S6a: Box-Muller on the hashed uniforms, noise.wgsl:30-50 / noise_bw.wgsl:30-44.
+__device__ __forceinline__ void gaussian_noise(uint32_t gx, uint32_t gy, uint32_t seed, bool mono, float& nr, float& ng,
+                                               float& nb) {
+    uint32_t vx = gx, vy = gy, vz = seed;
+    pcg3d(vx, vy, vz);
+    const float inv = 1.0f / 4294967296.0f;  // 1/f32(0xffffffff): f32(0xffffffff) rounds to 2^32
+    const float TWO_PI = 6.28318530718f;     // 2.0 * 3.14159265359 folded, then f32
+    const float ux = (float)vx * inv;
+    const float uy = (float)vy * inv;
+    const float u1 = fmaxf(ux, 1e-7f);
+    const float r1 = sqrtf(-2.0f * logf(u1));
+    const float th1 = TWO_PI * uy;
+    float s1, c1;
+    sincosf(th1, &s1, &c1);
+    nr = r1 * c1;
+    if (mono) {
+        ng = nr;
+        nb = nr;
+        return;
+    }
+    ng = r1 * s1;
+    const float u3 = fmaxf((float)vz * inv, 1e-7f);
+    const float s12 = u1 + uy;
+    const float th2 = TWO_PI * (s12 - floorf(s12));
+    nb = sqrtf(-2.0f * logf(u3)) * cosf(th2);
+}
+
+// ---------------------------------------------------------------------------- stencil core
+// Register-tiled direct correlation out of an LDS tile.  Each lane owns P=4 consecutive
+// pixels in x and Q consecutive rows.  `lds` points at the lane's first row / first column
+// of the tile plane.  For every input-row step m and every 4-tap chunk the lane reads ONE
+// new float4 from LDS (the other half of the 7-float window is last iteration's), the wave
+// reads Q*4 weights through the scalar cache into SGPRs, and issues Q*16 v_fma_f32.
+// Accumulation order per output pixel is row-major over the taps, independent of the tile
+// or shard the pixel falls in -> results are bit-identical for any tiling.
+template <int Q>
+__device__ __forceinline__ void stencil_accumulate(const float* lds, int RS, const DevStencil& st, float (&acc)[Q][4]) {
+    const int R2F_CONSTANT* rowmeta = (const int R2F_CONSTANT*)st.rowmeta;
+    const float R2F_CONSTANT* wstream = (const float R2F_CONSTANT*)st.wstream;
+    const int M = st.M;
+    for (int m = 0; m < M; ++m) {
+        const int c_lo = rowmeta[4 * m], nchunk = rowmeta[4 * m + 1], woff = rowmeta[4 * m + 2];
+        const float* lrow = lds + m * RS + 4 * c_lo;
+        const float R2F_CONSTANT* w = wstream + woff;
+        float4 a = *reinterpret_cast<const float4*>(lrow);
+#pragma unroll 2
+        for (int c = 0; c < nchunk; ++c) {
+            const float4 b = *reinterpret_cast<const float4*>(lrow + 4 * (c + 1));
+            const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float wv = w[(c * Q + q) * 4 + t];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[q][p] = fmaf(wv, win[p + t], acc[q][p]);
+                }
+            }
+            a = b;
+        }
+    }
+}
+
+}  // namespace r2f

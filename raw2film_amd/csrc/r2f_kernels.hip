@@ -1,0 +1,459 @@
+// r2f_kernels.hip -- gfx950 kernels of the film-emulation render path and their launchers.
+//
+// Kernel inventory (pass graph mirrors gpu_processor.py:1763-1862, fused where it is free):
+//   front_kernel    S0 3x3 + S1 2-D LUT [+ S3 log + S4 curve [+ S8 3-D LUT + S9 u8]]   HBM-bound
+//   stencil_kernel  S2 halation (+S3+S4 epilogue) / S5 MTF: LDS-tiled direct stencil    fp32-VALU-bound
+//   tail_kernel     S6 hash noise -> LDS, grain stencil, grain LUT, clip, S8, S9        VALU/LDS
+//   lut3d_kernel    S8 + S9 from density planes (grain off)                              HBM-bound
+//   noise_kernel    S6a test entry (hash + Gaussian field)
+#include "r2f_launch.h"
+
+#include "../../include/r2f.h"
+
+namespace r2f {
+
+const StencilVariant kStencilVariants[kNumStencilVariants] = {
+    {0, 32, 16, 4},  // 512 threads, tile 128 x 64, 4x4 outputs per lane
+    {1, 32, 32, 2},  // 1024 threads, tile 128 x 64, 4x2 outputs per lane
+    {2, 16, 8, 4},   // 128 threads, tile 64 x 32: fallback for very large stencils
+};
+
+// ------------------------------------------------------------------------------ output
+__device__ __forceinline__ uint32_t to_u8(float v) {
+    // cpu_processor.py:407: (image * 255).astype(uint8) -- truncation
+    float s = fminf(fmaxf(v * 255.0f, 0.0f), 255.0f);
+    return (uint32_t)s;
+}
+
+// Write `nv` (1..4) consecutive pixels of row `orow` starting at column x, interleaved HWC.
+__device__ __forceinline__ void emit_hwc(float* out_f32, uint8_t* out_u8, long long orow, int x, int W, int nv, bool vec,
+                                         const float (&r)[4], const float (&g)[4], const float (&b)[4]) {
+    const long long base = (orow * W + x) * 3;
+    if (out_f32) {
+        float* o = out_f32 + base;
+        if (vec && nv == 4) {
+            float4* o4 = reinterpret_cast<float4*>(o);
+            o4[0] = make_float4(r[0], g[0], b[0], r[1]);
+            o4[1] = make_float4(g[1], b[1], r[2], g[2]);
+            o4[2] = make_float4(b[2], r[3], g[3], b[3]);
+        } else {
+            for (int p = 0; p < nv; ++p) {
+                o[3 * p + 0] = r[p];
+                o[3 * p + 1] = g[p];
+                o[3 * p + 2] = b[p];
+            }
+        }
+    }
+    if (out_u8) {
+        uint8_t* o = out_u8 + base;
+        if (vec && nv == 4) {
+            uint32_t q[12];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                q[3 * p + 0] = to_u8(r[p]);
+                q[3 * p + 1] = to_u8(g[p]);
+                q[3 * p + 2] = to_u8(b[p]);
+            }
+            uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+            o32[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+            o32[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+            o32[2] = q[8] | (q[9] << 8) | (q[10] << 16) | (q[11] << 24);
+        } else {
+            for (int p = 0; p < nv; ++p) {
+                o[3 * p + 0] = (uint8_t)to_u8(r[p]);
+                o[3 * p + 1] = (uint8_t)to_u8(g[p]);
+                o[3 * p + 2] = (uint8_t)to_u8(b[p]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_planes4(const DevPlanes& pl, int gy, int x, int W, int nv, bool vec, float (&r)[4],
+                                             float (&g)[4], float (&b)[4]) {
+    const float* p0 = pl.data + (long long)(gy - pl.gy0) * W + x;
+    const float* p1 = p0 + pl.plane_stride;
+    const float* p2 = p1 + pl.plane_stride;
+    if (vec && nv == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p0);
+        const float4 c = *reinterpret_cast<const float4*>(p1);
+        const float4 d = *reinterpret_cast<const float4*>(p2);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        g[0] = c.x; g[1] = c.y; g[2] = c.z; g[3] = c.w;
+        b[0] = d.x; b[1] = d.y; b[2] = d.z; b[3] = d.w;
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = p < nv;
+            r[p] = ok ? p0[p] : 0.f;
+            g[p] = ok ? p1[p] : 0.f;
+            b[p] = ok ? p2[p] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_planes4(const DevPlanes& pl, int gy, int x, int W, int nv, bool vec,
+                                              const float (&r)[4], const float (&g)[4], const float (&b)[4]) {
+    float* p0 = pl.data + (long long)(gy - pl.gy0) * W + x;
+    float* p1 = p0 + pl.plane_stride;
+    float* p2 = p1 + pl.plane_stride;
+    if (vec && nv == 4) {
+        *reinterpret_cast<float4*>(p0) = make_float4(r[0], r[1], r[2], r[3]);
+        *reinterpret_cast<float4*>(p1) = make_float4(g[0], g[1], g[2], g[3]);
+        *reinterpret_cast<float4*>(p2) = make_float4(b[0], b[1], b[2], b[3]);
+    } else {
+        for (int p = 0; p < nv; ++p) {
+            p0[p] = r[p];
+            p1[p] = g[p];
+            p2[p] = b[p];
+        }
+    }
+}
+
+__device__ __forceinline__ void apply_lut3d(const DevLut3D& L, float scale, int mode, float& r, float& g, float& b) {
+    if (mode == 0)
+        apply_lut3d_tetra(L, scale * (float)(L.n - 1), r, g, b);
+    else
+        apply_lut3d_trilinear(L, scale, r, g, b);
+}
+
+// ------------------------------------------------------------------------------ front
+// One lane = 4 consecutive pixels of one row.  Block (64, 4).
+__global__ __launch_bounds__(256) void front_kernel(const FrontArgs a) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int gy = a.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.W || gy >= a.y1) return;
+    const int W = a.W;
+    const int nv = min(4, W - x);
+    const bool vec = a.vec != 0;
+    const long long irow = gy - a.in_gy0;
+    float r[4], g[4], b[4];
+    const float* in = static_cast<const float*>(a.in);
+    if (a.in_layout == R2F_LAYOUT_CHW) {
+        DevPlanes pl;
+        pl.data = const_cast<float*>(in);
+        pl.plane_stride = (long long)a.in_rows * W;
+        pl.gy0 = a.in_gy0;
+        pl.rows = a.in_rows;
+        load_planes4(pl, gy, x, W, nv, vec, r, g, b);
+    } else if (a.in_layout == R2F_LAYOUT_HWC3) {
+        const float* p = in + (irow * W + x) * 3;
+        if (vec && nv == 4) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            const float4 v0 = p4[0], v1 = p4[1], v2 = p4[2];
+            r[0] = v0.x; g[0] = v0.y; b[0] = v0.z;
+            r[1] = v0.w; g[1] = v1.x; b[1] = v1.y;
+            r[2] = v1.z; g[2] = v1.w; b[2] = v2.x;
+            r[3] = v2.y; g[3] = v2.z; b[3] = v2.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = q < nv;
+                r[q] = ok ? p[3 * q + 0] : 0.f;
+                g[q] = ok ? p[3 * q + 1] : 0.f;
+                b[q] = ok ? p[3 * q + 2] : 0.f;
+            }
+        }
+    } else {  // HWC4, alpha ignored (gpu_processor.py:765)
+        const float4* p4 = reinterpret_cast<const float4*>(in + (irow * W + x) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < nv) {
+                const float4 v = p4[q];
+                r[q] = v.x; g[q] = v.y; b[q] = v.z;
+            } else {
+                r[q] = g[q] = b[q] = 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (a.use_matrix) apply_matrix(a.mat, r[q], g[q], b[q]);
+        apply_lut2d(a.lut2d, r[q], g[q], b[q]);
+        if (a.upto >= R2F_UPTO_DENSITY) {
+            r[q] = log_curve(a.curve, 0, r[q], a.log_eps);
+            g[q] = log_curve(a.curve, 1, g[q], a.log_eps);
+            b[q] = log_curve(a.curve, 2, b[q], a.log_eps);
+        }
+        if (a.upto == R2F_UPTO_OUTPUT) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[q], g[q], b[q]);
+    }
+    if (a.upto == R2F_UPTO_OUTPUT)
+        emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, x, W, nv, vec, r, g, b);
+    else
+        store_planes4(a.dst, gy, x, W, nv, vec, r, g, b);
+}
+
+// ------------------------------------------------------------------------------ lut3d
+struct Lut3dArgs {
+    DevPlanes src;
+    float* out_f32;
+    uint8_t* out_u8;
+    int out_gy0, y0, y1, W;
+    DevLut3D lut3d;
+    float lut3d_scale;
+    int lut3d_mode;
+    int vec;
+};
+
+__global__ __launch_bounds__(256) void lut3d_kernel(const Lut3dArgs a) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int gy = a.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.W || gy >= a.y1) return;
+    const int nv = min(4, a.W - x);
+    float r[4], g[4], b[4];
+    load_planes4(a.src, gy, x, a.W, nv, a.vec != 0, r, g, b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[q], g[q], b[q]);
+    emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, x, a.W, nv, a.vec != 0, r, g, b);
+}
+
+// ------------------------------------------------------------------------------ stencil
+// XCD-aware block order: consecutive linear ids are dealt round-robin to the 8 XCDs, so give
+// each XCD a contiguous run of tiles (neighbouring tiles share halo columns/rows in that L2).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+// Fill rows x RS floats of an LDS tile from a source plane with BORDER_REFLECT_101 on the
+// global frame.  Tile element (r, c) <-> global (ty0 + r, tx0 + c).  Columns >= cols_valid are
+// zero (they only meet zero padding taps).  One wave per tile row, lanes along x (coalesced).
+template <int NT>
+__device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, int cols_valid, const float* src,
+                                                  int src_gy0, int src_rows, int W, int H_global, int ty0, int tx0) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < rows; r += NT / 64) {
+        int sy = reflect101(ty0 + r, H_global) - src_gy0;
+        sy = clampi(sy, 0, src_rows - 1);  // only rows feeding discarded outputs can fall outside
+        const float* srow = src + (long long)sy * W;
+        float* drow = lds + r * RS;
+        for (int c = lane; c < RS; c += 64) {
+            float v = 0.f;
+            if (c < cols_valid) v = srow[reflect101(tx0 + c, W)];
+            drow[c] = v;
+        }
+    }
+}
+
+template <int BX, int BY, int Q>
+__global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = BX * BY, TW = 4 * BX, TH = Q * BY;
+    int bx = blockIdx.x, by = blockIdx.y, ch = blockIdx.z;
+    if (a.xcd_remap) {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        int id = xcd_remap(bx + gridDim.x * (by + gridDim.y * ch), nwg);
+        bx = id % gridDim.x;
+        id /= gridDim.x;
+        by = id % gridDim.y;
+        ch = id / gridDim.y;
+    }
+    const DevStencil st = a.st[ch];
+    const int tile_x0 = bx * TW, tile_y0 = a.y0 + by * TH;
+    const int RS = TW + st.kw_pad;
+    const int rows = TH + st.kh - 1;
+    const float* src = a.src.data + (long long)ch * a.src.plane_stride;
+    fill_tile_reflect<NT>(smem, RS, rows, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global,
+                          tile_y0 - st.ay, tile_x0 - st.ax);
+    __syncthreads();
+
+    const int tx = threadIdx.x % BX, ty = threadIdx.x / BX;
+    float acc[Q][4];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[q][p] = 0.f;
+    stencil_accumulate<Q>(smem + ty * Q * RS + 4 * tx, RS, st, acc);
+
+    const int gx = tile_x0 + 4 * tx;
+    if (gx >= a.W) return;
+    const int nv = min(4, a.W - gx);
+    float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int gy = tile_y0 + ty * Q + q;
+        if (gy >= a.y1) break;
+        float v[4] = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+        if (a.epilogue == 1) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) v[p] = log_curve(a.curve, ch, v[p], a.log_eps);
+        }
+        float* d = dplane + (long long)(gy - a.dst.gy0) * a.W + gx;
+        if (a.vec && nv == 4) {
+            *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int p = 0; p < nv; ++p) d[p] = v[p];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ tail (grain)
+__global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = kTailBX * kTailBY, TW = 4 * kTailBX, TH = kTailQ * kTailBY, Q = kTailQ;
+    const int tile_x0 = blockIdx.x * TW, tile_y0 = a.y0 + blockIdx.y * TH;
+    const DevStencil g0 = a.gk[0];
+    const int RS = TW + g0.kw_pad;
+    const int rows = TH + g0.kh - 1;
+    const int plane_sz = rows * RS;
+    const int cols_valid = TW + g0.kw - 1;
+    const bool mono = a.mono != 0;
+    // S6a: hash noise for the tile + halo, straight into LDS.  Coordinates are clamped to the
+    // frame like the shader's texture reads (grain.wgsl:63-75); the hash sees GLOBAL coordinates.
+    for (int idx = threadIdx.x; idx < plane_sz; idx += NT) {
+        const int r = idx / RS, c = idx - r * RS;
+        float nr = 0.f, ng = 0.f, nb = 0.f;
+        if (c < cols_valid) {
+            const int sx = clampi(tile_x0 - g0.ax + c, 0, a.W - 1);
+            const int sy = clampi(tile_y0 - g0.ay + r, 0, a.H_global - 1);
+            gaussian_noise((uint32_t)sx, (uint32_t)sy, a.seed, mono, nr, ng, nb);
+        }
+        smem[idx] = nr;
+        if (!mono) {
+            smem[plane_sz + idx] = ng;
+            smem[2 * plane_sz + idx] = nb;
+        }
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x % kTailBX, ty = threadIdx.x / kTailBX;
+    float G[3][Q][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) G[c][q][p] = 0.f;
+        const float* plane = smem + (mono ? 0 : c * plane_sz);
+        stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, RS, a.gk[c], G[c]);
+    }
+
+    const int gx = tile_x0 + 4 * tx;
+    if (gx >= a.W) return;
+    const int nv = min(4, a.W - gx);
+    const bool vec = a.vec != 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int gy = tile_y0 + ty * Q + q;
+        if (gy >= a.y1) break;
+        float r[4], g[4], b[4];
+        load_planes4(a.src, gy, gx, a.W, nv, vec, r, g, b);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // S6c grain.wgsl:78-89 + clip cpu_processor.py:397
+            r[p] = fmaxf(r[p] + G[0][q][p] * curve_eval(a.grain_lut, 0, r[p]), 0.f);
+            g[p] = fmaxf(g[p] + G[1][q][p] * curve_eval(a.grain_lut, 1, g[p]), 0.f);
+            b[p] = fmaxf(b[p] + G[2][q][p] * curve_eval(a.grain_lut, 2, b[p]), 0.f);
+            apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
+        }
+        emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, gx, a.W, nv, vec, r, g, b);
+    }
+}
+
+// ------------------------------------------------------------------------------ noise (test)
+__global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int gy = a.y0 + blockIdx.y;
+    if (x >= a.W) return;
+    const long long rows = a.y1 - a.y0;
+    const long long plane = rows * a.W;
+    const long long o = (long long)(gy - a.y0) * a.W + x;
+    if (a.hash) {
+        uint32_t vx = (uint32_t)x, vy = (uint32_t)gy, vz = a.seed;
+        pcg3d(vx, vy, vz);
+        a.hash[o] = vx;
+        a.hash[plane + o] = vy;
+        a.hash[2 * plane + o] = vz;
+    }
+    if (a.noise) {
+        float nr, ng, nb;
+        gaussian_noise((uint32_t)x, (uint32_t)gy, a.seed, a.mono != 0, nr, ng, nb);
+        a.noise[o] = nr;
+        a.noise[plane + o] = ng;
+        a.noise[2 * plane + o] = nb;
+    }
+}
+
+// ------------------------------------------------------------------------------ launchers
+size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan) {
+    size_t best = 0;
+    for (int c = 0; c < nchan; ++c) {
+        size_t b = (size_t)(v.TW() + st[c].kw_pad) * (size_t)(v.TH() + st[c].kh - 1) * sizeof(float);
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+size_t tail_lds_bytes(const DevStencil* gk, int mono) {
+    const size_t plane = (size_t)(4 * kTailBX + gk[0].kw_pad) * (size_t)(kTailQ * kTailBY + gk[0].kh - 1);
+    return plane * (mono ? 1 : 3) * sizeof(float);
+}
+
+hipError_t init_kernel_attributes() {
+    hipError_t e;
+#define R2F_SET_LDS(k)                                                                                \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)kMaxLds);                                                            \
+    if (e != hipSuccess) return e;
+    R2F_SET_LDS((stencil_kernel<32, 16, 4>))
+    R2F_SET_LDS((stencil_kernel<32, 32, 2>))
+    R2F_SET_LDS((stencil_kernel<16, 8, 4>))
+    R2F_SET_LDS(tail_kernel)
+#undef R2F_SET_LDS
+    return hipSuccess;
+}
+
+hipError_t launch_front(const FrontArgs& a, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    const int quads = (a.W + 3) / 4;
+    dim3 block(64, 4), grid((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4);
+    hipLaunchKernelGGL(front_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    const StencilVariant& v = kStencilVariants[variant];
+    const size_t lds = stencil_lds_bytes(v, a.st, a.nchan);
+    dim3 block(v.BX * v.BY), grid((a.W + v.TW() - 1) / v.TW(), (a.y1 - a.y0 + v.TH() - 1) / v.TH(), a.nchan);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4>), grid, block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((stencil_kernel<32, 32, 2>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((stencil_kernel<16, 8, 4>), grid, block, lds, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    if (!a.grain) {
+        Lut3dArgs l;
+        l.src = a.src;
+        l.out_f32 = a.out_f32;
+        l.out_u8 = a.out_u8;
+        l.out_gy0 = a.out_gy0;
+        l.y0 = a.y0;
+        l.y1 = a.y1;
+        l.W = a.W;
+        l.lut3d = a.lut3d;
+        l.lut3d_scale = a.lut3d_scale;
+        l.lut3d_mode = a.lut3d_mode;
+        l.vec = a.vec;
+        const int quads = (a.W + 3) / 4;
+        dim3 block(64, 4), grid((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4);
+        hipLaunchKernelGGL(lut3d_kernel, grid, block, 0, s, l);
+        return hipGetLastError();
+    }
+    const int TW = 4 * kTailBX, TH = kTailQ * kTailBY;
+    dim3 block(kTailBX * kTailBY), grid((a.W + TW - 1) / TW, (a.y1 - a.y0 + TH - 1) / TH);
+    hipLaunchKernelGGL(tail_kernel, grid, block, tail_lds_bytes(a.gk, a.mono), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_noise(const NoiseArgs& a, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    dim3 block(256), grid((a.W + 255) / 256, a.y1 - a.y0);
+    hipLaunchKernelGGL(noise_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace r2f

@@ -1,0 +1,87 @@
+// r2f_launch.h -- host-callable launchers implemented in r2f_kernels.hip.
+#pragma once
+
+#include "r2f_device.h"
+
+namespace r2f {
+
+struct FrontArgs {
+    const void* in;
+    int in_layout;  // R2F_LAYOUT_*
+    int in_gy0, in_rows;
+    int upto;  // R2F_UPTO_*
+    DevPlanes dst;
+    float* out_f32;
+    uint8_t* out_u8;
+    int out_gy0;
+    int y0, y1, W, H_global;
+    int use_matrix;
+    Mat3 mat;
+    DevLut2D lut2d;
+    DevCurve curve;
+    DevLut3D lut3d;
+    float log_eps;
+    float lut3d_scale;
+    int lut3d_mode;
+    int vec;  // 1: W % 4 == 0 and all bases 16-byte aligned -> float4 paths
+};
+
+struct StencilArgs {
+    DevStencil st[3];
+    DevPlanes src, dst;
+    int y0, y1, W, H_global;
+    int epilogue;  // 0 = none, 1 = log + density curve (halation)
+    DevCurve curve;
+    float log_eps;
+    int nchan;
+    int vec;
+    int xcd_remap;
+};
+
+struct TailArgs {
+    DevPlanes src;
+    float* out_f32;
+    uint8_t* out_u8;
+    int out_gy0;
+    int y0, y1, W, H_global;
+    int grain;  // 0/1
+    int mono;
+    uint32_t seed;
+    DevStencil gk[3];  // grain stencil, common geometry for the 3 channels
+    DevCurve grain_lut;
+    DevLut3D lut3d;
+    float lut3d_scale;
+    int lut3d_mode;
+    int vec;
+};
+
+struct NoiseArgs {
+    uint32_t* hash;
+    float* noise;
+    int y0, y1, W;
+    uint32_t seed;
+    int mono;
+};
+
+// tile geometry of the stencil variants (threads = BX*BY, tile = 4*BX x Q*BY)
+struct StencilVariant {
+    int id;
+    int BX, BY, Q;
+    int TW() const { return 4 * BX; }
+    int TH() const { return Q * BY; }
+};
+constexpr int kNumStencilVariants = 3;
+extern const StencilVariant kStencilVariants[kNumStencilVariants];
+constexpr int kTailBX = 16, kTailBY = 16, kTailQ = 4;  // grain/tail tile 64 x 64, 256 threads
+constexpr size_t kMaxLds = 160 * 1024;
+
+size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan);
+size_t tail_lds_bytes(const DevStencil* gk, int mono);
+
+hipError_t init_kernel_attributes();
+hipError_t launch_front(const FrontArgs& a, hipStream_t s);
+hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s);
+hipError_t launch_tail(const TailArgs& a, hipStream_t s);
+hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
+
+}  // namespace r2f

@@ -1,0 +1,303 @@
+"""HipProcessor: the MI355X backend behind raw2film's processor surface.
+
+Mirrors `CpuProcessor.process` (cpu_processor.py:269-414) / `GpuProcessor.process`,
+`.extract_image_data_cpu`, `.process_preloaded` (gpu_processor.py:715-783, 1541-1693): same
+keyword names and defaults, unknown keywords swallowed, LUTs / stencils rebuilt and
+re-uploaded only when their parameter dict changes (cpu_processor.py:104-105,157-158,...).
+
+Scope: the post-decode per-pixel path.  RAW decoding, lens correction, crop/rotate/zoom,
+chroma NR, the `max_scale` resize, canvas and highlight burn belong to the rows SURVEY.md
+section 8f lists as "next"; asking for them raises NotImplementedError instead of silently
+rendering something else.  `src` is therefore a decoded frame: a float32 (H, W, 3|4) array /
+CUDA tensor in linear CIE XYZ (what `raw_to_linear` returns, raw_conversion.py:33-53), or the
+path of a `.npy` file holding one.
+"""
+
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from . import _lib, filmstock, stencils
+from .context import LOG_EPS, LUT3D_SCALE, HipContext
+
+REC709_TO_XYZ = np.array(  # data.py:128-135
+    [[0.4124564, 0.3575761, 0.1804375], [0.2126729, 0.7151522, 0.0721750], [0.0193339, 0.1191920, 0.9503041]],
+    dtype=np.float32,
+)
+
+
+class HipProcessor:
+    """Drop-in for the hot path of CpuProcessor / GpuProcessor (gui.py:1584-1585)."""
+
+    def __init__(self, cameras=None, lenses=None, device: int = 0):
+        import torch
+
+        self._torch = torch
+        self.cameras = cameras
+        self.lenses = lenses
+        self.ctx = HipContext(device)
+        self.device = self.ctx.device  # NB: a torch device, not a wgpu device (gui.py:1652 uses bitmap mode)
+        # comparison dicts, same role as cpu_processor.py:41-45 / gpu_processor.py
+        self.input_param_dict = None
+        self.curve_param_dict = None
+        self.output_param_dict = None
+        self.halation_param_dict = None
+        self.mtf_param_dict = None
+        self.grain_kernel_param_dict = None
+        self.grain_lut_param_dict = None
+        self.matrix_key = None
+        self.uploads = 0  # number of table uploads, for the caching tests
+
+    def close(self):
+        self.ctx.close()
+
+    # ------------------------------------------------------------------ cached loaders
+    def load_input_lut(self, negative_film, exp_kelvin, tint, exp_comp):
+        """cpu_processor.py:142-164"""
+        new = {"negative_film": negative_film.name, "exp_kelvin": exp_kelvin, "tint": tint, "exp_comp": exp_comp}
+        if new == self.input_param_dict:
+            return
+        self.ctx.set_lut2d(negative_film.get_input_lut(exp_kelvin, tint, exp_comp))
+        self.uploads += 1
+        self.input_param_dict = new
+
+    def load_density_curve(self, negative_film, push_pull, color_masking=None):
+        """cpu_processor.py:166-188"""
+        new = {"negative_film": negative_film.name, "push_pull": push_pull, "color_masking": color_masking}
+        if new == self.curve_param_dict:
+            return
+        self.ctx.set_curve1d(negative_film.get_density_curve(push_pull=push_pull, color_masking=color_masking))
+        self.uploads += 1
+        self.curve_param_dict = new
+
+    def load_output_lut(self, negative_film, print_film=None, red_light=0.0, green_light=0.0, blue_light=0.0,
+                        projector_kelvin=6500, shadow_comp=0.0, sat_adjust=1.0, gamma_func="sRGB",
+                        inversion_gamma=4.0, idealized_curve=False, inversion=False, white_balance=False,
+                        white_clip=False, icc_transform=None, color_masking=None):
+        """cpu_processor.py:190-267"""
+        new = {
+            "negative_film": negative_film.name,
+            "print_film": print_film.name if print_film is not None else None,
+            "red_light": red_light, "green_light": green_light, "blue_light": blue_light,
+            "projector_kelvin": projector_kelvin, "shadow_comp": shadow_comp, "sat_adjust": sat_adjust,
+            "gamma_func": gamma_func, "inversion_gamma": inversion_gamma, "idealized_curve": idealized_curve,
+            "inversion": inversion, "white_balance": white_balance, "white_clip": white_clip,
+            "icc_transform": icc_transform, "color_masking": color_masking,
+        }
+        if new == self.output_param_dict:
+            return
+        lut = filmstock.create_lut(
+            negative_film, print_film, mode="print", input_colorspace=None, adx_coding=False, cube=False,
+            red_light=red_light, green_light=green_light, blue_light=blue_light, projector_kelvin=projector_kelvin,
+            shadow_comp=shadow_comp, sat_adjust=sat_adjust, gamma_func=gamma_func, inversion_gamma=inversion_gamma,
+            idealized_curve=idealized_curve, inversion=inversion, white_balance=white_balance, white_clip=white_clip,
+            linear_scaling=4.0, color_masking=color_masking,
+        )
+        if icc_transform is not None:  # cpu_processor.py:255-263: 8-bit ICC pass over the LUT itself
+            from PIL import Image, ImageCms
+
+            shape = lut.shape
+            img = Image.fromarray((lut * 255).astype(np.uint8).reshape(shape[0], -1, shape[-1]))
+            ImageCms.applyTransform(img, icc_transform, inPlace=True)
+            lut = (np.array(img, np.uint8).reshape(shape) / 255.0).astype(np.float32)
+        self.ctx.set_lut3d(lut)
+        self.uploads += 1
+        self.output_param_dict = new
+
+    def load_halation_kernel(self, scale, halation_size=1.0, halation_red_factor=1.0, halation_green_factor=0.4,
+                             halation_blue_factor=0.0, halation_intensity=1.0, bw=False):
+        """gpu_processor.py:818-854"""
+        new = {"scale": scale, "halation_size": halation_size, "halation_red_factor": halation_red_factor,
+               "halation_green_factor": halation_green_factor, "halation_blue_factor": halation_blue_factor,
+               "halation_intensity": halation_intensity, "bw": bw}
+        if new == self.halation_param_dict:
+            return
+        k = stencils.halation_stencil(scale, halation_size, halation_red_factor, halation_green_factor,
+                                      halation_blue_factor, halation_intensity, bw=bw)
+        self.ctx.set_kernel(_lib.KERNEL_HALATION, k)
+        self.uploads += 1
+        self.halation_param_dict = new
+
+    def load_mtf_kernel(self, negative_film, scale, sharpening_strength, sharpening_sigma):
+        """gpu_processor.py:792-816"""
+        new = {"negative_film": negative_film.name, "scale": scale, "sharpening_strength": sharpening_strength,
+               "sharpening_sigma": sharpening_sigma}
+        if new == self.mtf_param_dict:
+            return
+        self.ctx.set_kernel(_lib.KERNEL_MTF, stencils.mtf_stencil(negative_film, scale, sharpening_strength, sharpening_sigma))
+        self.uploads += 1
+        self.mtf_param_dict = new
+
+    def load_grain(self, negative_film, scale, grain_size_mm=0.01, grain_sigma=0.4, bw_grain=False):
+        """gpu_processor.py:904-936 (the seed is an explicit argument of the render here)"""
+        new_lut = {"negative_film": negative_film.name, "scale": scale, "bw_grain": bw_grain}
+        if new_lut != self.grain_lut_param_dict:
+            self.ctx.set_grain_lut(negative_film.get_grain_curve(scale, adx=False, bw_grain=bw_grain))
+            self.uploads += 1
+            self.grain_lut_param_dict = new_lut
+        new = {"scale": scale, "grain_size_mm": grain_size_mm, "grain_sigma": grain_sigma, "bw_grain": bw_grain}
+        if new == self.grain_kernel_param_dict:
+            return
+        k = filmstock.grain_kernel(1 / scale, grain_size_mm=grain_size_mm, grain_sigma=grain_sigma)
+        if k is None:
+            k = np.ones((1, 1), dtype=np.float32)  # gpu_processor.py:931-932
+        self.ctx.set_kernel(_lib.KERNEL_GRAIN, k)
+        self.uploads += 1
+        self.grain_kernel_param_dict = new
+
+    # ------------------------------------------------------------------ phase 1 (host)
+    def extract_image_data_cpu(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24,
+                               rotation=0.0, zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True,
+                               cache=True, chroma_nr=0, max_scale=400.0, canvas_mode="No", canvas_scale=1.0,
+                               canvas_ratio=1.0, **kwargs):
+        """PHASE 1 of the two-phase batch API (gpu_processor.py:715-783): pure host work, touches
+        no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32."""
+        image = self._load_decoded(src)
+        if rotation or zoom != 1.0 or rotate_times or chroma_nr or canvas_mode != "No":
+            raise NotImplementedError(
+                "crop/rotate/zoom, chroma NR and canvas are outside the accelerated path (SURVEY.md section 8f)"
+            )
+        h, w = image.shape[:2]
+        if resolution is not None and tuple(resolution) != (h, w):
+            raise NotImplementedError("pre-path resolution scaling is outside the accelerated path (SURVEY.md section 8f)")
+        if max_scale is not None and max(h, w) / max(frame_width, frame_height) > max_scale:
+            raise NotImplementedError(
+                f"frame is finer than max_scale={max_scale} px/mm; the reference down-scales first "
+                "(cpu_processor.py:128-134), which is outside the accelerated path"
+            )
+        if image.shape[2] == 3:
+            image = np.concatenate([image, np.ones_like(image[..., :1])], axis=-1)  # gpu_processor.py:765
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        return {
+            "image_array": image,
+            "output_resolution": (w, h),
+            "canvas_resolution": None,
+            "pipeline_resolution": (w, h),
+        }
+
+    @staticmethod
+    def _load_decoded(src):
+        if isinstance(src, np.ndarray):
+            image = src
+        elif isinstance(src, str) and src.lower().endswith(".npy"):
+            image = np.load(src)
+        elif isinstance(src, str):
+            raise NotImplementedError(
+                f"{src!r}: RAW decoding (LibRaw/rawpy, raw_conversion.py:33-53) is outside the accelerated path; "
+                "pass the decoded linear-XYZ frame (array or .npy)"
+            )
+        else:
+            raise TypeError(f"unsupported src type {type(src)!r}")
+        if image.ndim != 3 or image.shape[2] not in (3, 4):
+            raise ValueError(f"decoded frame must be (H, W, 3|4), got {image.shape}")
+        image = np.asarray(image, dtype=np.float32)
+        return np.clip(image, 0, 65504)  # gpu_processor.py:275
+
+    # ------------------------------------------------------------------ the operator surface
+    def process(self, src, negative_film, grain_size, grain_sigma, dst_texture=None, histogram_texture=None,
+                lens_correction=True, print_film=None, exp_comp=0.0, red_light=0.0, green_light=0.0, blue_light=0.0,
+                projector_kelvin=6500, shadow_comp=0.0, sat_adjust=1.0, gamma_func="sRGB", exp_kelvin=6500, tint=0.0,
+                inversion_gamma=4.0, idealized_curve=False, inversion=False, push_pull=0.0, white_balance=False,
+                white_clip=False, icc_transform=None, resolution=None, frame_width=36, frame_height=24, rotation=0.0,
+                zoom=1.0, rotate_times=0, flip=False, cam=None, lens=None, canvas_mode="No", canvas_scale=1.0,
+                canvas_ratio=1.0, halation_intensity=1.0, halation=True, halation_size=1.0, halation_green_factor=0.4,
+                sharpness=True, sharpening_strength=0.0, sharpening_sigma=1.0, chroma_nr=0, grain=2,
+                highlight_burn=0.0, burn_scale=50.0, half_size=True, cache=True, color_masking=None, max_scale=400.0,
+                seed=None, **_):
+        """Load (decoded) frame and render it: np.uint8 (H, W, 3), like cpu_processor.py:414."""
+        if dst_texture is not None or histogram_texture is not None:
+            raise NotImplementedError("wgpu destination textures are not supported; use the bitmap branch (gui.py:2219-2228)")
+        payload = self.extract_image_data_cpu(
+            src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
+            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio,
+        )
+        return self.process_preloaded(
+            payload, negative_film, grain_size, grain_sigma, print_film=print_film, exp_comp=exp_comp,
+            red_light=red_light, green_light=green_light, blue_light=blue_light, projector_kelvin=projector_kelvin,
+            shadow_comp=shadow_comp, sat_adjust=sat_adjust, gamma_func=gamma_func, exp_kelvin=exp_kelvin, tint=tint,
+            inversion_gamma=inversion_gamma, idealized_curve=idealized_curve, inversion=inversion, push_pull=push_pull,
+            white_balance=white_balance, white_clip=white_clip, icc_transform=icc_transform, frame_width=frame_width,
+            frame_height=frame_height, halation_intensity=halation_intensity, halation=halation,
+            halation_size=halation_size, halation_green_factor=halation_green_factor, sharpness=sharpness,
+            sharpening_strength=sharpening_strength, sharpening_sigma=sharpening_sigma, grain=grain,
+            highlight_burn=highlight_burn, burn_scale=burn_scale, color_masking=color_masking, seed=seed,
+        )
+
+    def process_preloaded(self, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture=None,
+                          histogram_texture=None, **settings):
+        """PHASE 2 (gpu_processor.py:1643-1693): upload the payload and run the device pipeline."""
+        if dst_texture is not None or histogram_texture is not None:
+            raise NotImplementedError("wgpu destination textures are not supported")
+        torch = self._torch
+        image = cpu_payload["image_array"]
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
+        _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,
+                                           **settings)
+        return out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def process_array(self, image, negative_film, grain_size=6, grain_sigma=0.4, *, colorspace="XYZ", seed=None,
+                      return_float=False, output="host", **settings):
+        """Render a decoded frame given as an array / CUDA tensor (synthetic benchmark frames).
+
+        colorspace: "XYZ" (S0 skipped) or "linear-rec709" (S0 = data.py:128-135).
+        return_float: float32 display-referred (H, W, 3) instead of uint8.  output: "host" | "device".
+        """
+        torch = self._torch
+        if colorspace not in ("XYZ", "linear-rec709"):
+            raise ValueError("colorspace must be 'XYZ' or 'linear-rec709'")
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        image = image.to(self.device).contiguous()
+        f32, u8 = self._execute_pipeline(
+            image, negative_film, grain_size, grain_sigma, want_f32=return_float, want_u8=not return_float,
+            matrix=REC709_TO_XYZ if colorspace == "linear-rec709" else None, seed=seed, **settings,
+        )
+        out = f32 if return_float else u8
+        return out if output == "device" else out.cpu().numpy()
+
+    # ------------------------------------------------------------------ device pipeline
+    def prepare(self, negative_film, grain_size, grain_sigma, pipeline_resolution, *, print_film=None, exp_comp=0.0,
+                red_light=0.0, green_light=0.0, blue_light=0.0, projector_kelvin=6500, shadow_comp=0.0, sat_adjust=1.0,
+                gamma_func="sRGB", exp_kelvin=6500, tint=0.0, inversion_gamma=4.0, idealized_curve=False,
+                inversion=False, push_pull=0.0, white_balance=False, white_clip=False, icc_transform=None,
+                frame_width=36, frame_height=24, halation_intensity=1.0, halation=True, halation_size=1.0,
+                halation_green_factor=0.4, sharpness=True, sharpening_strength=0.0, sharpening_sigma=1.0, grain=2,
+                highlight_burn=0.0, burn_scale=50.0, color_masking=None, matrix=None, seed=None, lut3d_mode=0, **_):
+        """Upload whatever changed and return the r2f_params for this render: the table half of
+        `_execute_gpu_pipeline` (gpu_processor.py:1735-1756, 1772-1825)."""
+        if highlight_burn:
+            raise NotImplementedError("highlight burn is outside the accelerated path (SURVEY.md section 8f)")
+        self.load_input_lut(negative_film, exp_kelvin, tint, exp_comp)
+        self.load_density_curve(negative_film, push_pull, color_masking)
+        self.load_output_lut(negative_film, print_film, red_light, green_light, blue_light, projector_kelvin,
+                             shadow_comp, sat_adjust, gamma_func, inversion_gamma, idealized_curve, inversion,
+                             white_balance, white_clip, icc_transform, color_masking)
+        scale = max(pipeline_resolution) / max(frame_width, frame_height)  # px per mm, cpu_processor.py:366
+        do_hal = bool(halation)
+        do_mtf = bool(sharpness) and negative_film.mtf is not None
+        do_grain = bool(grain) and negative_film.rms_density is not None
+        if do_hal:
+            self.load_halation_kernel(scale, halation_size=halation_size, halation_green_factor=halation_green_factor,
+                                      halation_intensity=halation_intensity, bw=negative_film.density_measure == "bw")
+        if do_mtf:
+            self.load_mtf_kernel(negative_film, scale, sharpening_strength, sharpening_sigma)
+        if do_grain:
+            self.load_grain(negative_film, scale, grain_size / 1000, grain_sigma, grain == 1)
+        mkey = None if matrix is None else np.asarray(matrix, dtype=np.float32).tobytes()
+        if mkey != self.matrix_key:
+            self.ctx.set_matrix3x3(matrix)
+            self.matrix_key = mkey
+        if seed is None:
+            seed = random.randint(0, 100000000)  # gpu_processor.py:591: a new seed every render
+        return self.ctx.make_params(matrix=matrix is not None, halation=do_hal, mtf=do_mtf, grain=do_grain,
+                                    grain_mono=grain == 1, seed=seed, lut3d_mode=lut3d_mode,
+                                    log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE)
+
+    def _execute_pipeline(self, image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True, **settings):
+        _, H, W = self.ctx.layout_of(image)
+        params = self.prepare(negative_film, grain_size, grain_sigma, (W, H), **settings)
+        return self.ctx.render(image, params, want_f32=want_f32, want_u8=want_u8)

@@ -1,0 +1,308 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Tolerances (north_star: 1e-5 relative fp32 per channel; hash bit-identical):
+  * stage outputs:   |hip - oracle| <= 1e-5 * max(|oracle|, floor) with the floor stated per test
+    (densities and display values live in [0, 4] / [0, 1]; the floor keeps near-zero values from
+    turning an absolute 1e-7 rounding difference into a meaningless relative one);
+  * PCG3D hash:      bit-exact uint32;
+  * uint8 output:    <= 1 LSB on <= 1e-4 of the samples (truncation at fp32 rounding boundaries).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import kernels as ok
+from oracle import stages as st
+
+from helpers import SEED, assert_close, oracle_inputs, rel_err, stocks, synthetic_frame
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from raw2film_amd.context import HipContext
+
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def to_planes(a):
+    return dev(np.ascontiguousarray(np.transpose(a, (2, 0, 1))))
+
+
+def from_planes(t):
+    return np.transpose(t.cpu().numpy(), (1, 2, 0))
+
+
+def setup_ctx(ctx, p):
+    ctx.set_matrix3x3(p.matrix)
+    ctx.set_lut2d(p.lut_2d)
+    ctx.set_curve1d(p.lut_1d)
+    ctx.set_lut3d(p.lut_3d)
+    if p.halation_kernel is not None:
+        ctx.set_kernel(0, p.halation_kernel)
+    if p.mtf_kernel is not None:
+        ctx.set_kernel(1, p.mtf_kernel)
+    if p.grain_lut is not None:
+        ctx.set_grain_lut(p.grain_lut)
+        ctx.set_kernel(2, p.grain_kernel if p.grain_kernel is not None else np.ones((1, 1), np.float32))
+    return ctx.make_params(
+        matrix=p.matrix is not None, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None,
+        grain=p.grain_lut is not None, grain_mono=p.grain_mono, seed=p.seed,
+        lut3d_mode=0 if p.lut3d_mode == "tetrahedral" else 1)
+
+
+# ------------------------------------------------------------------------------- pointwise
+@pytest.mark.parametrize("layout", ["hwc3", "hwc4", "chw"])
+@pytest.mark.parametrize("shape", [(64, 96), (37, 53)])
+def test_front_stages_and_layouts(ctx, layout, shape):
+    H, W = shape
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0, halation=False, mtf=False, grain=0)
+    img = synthetic_frame(H, W, seed=3)
+    img[0, :4] = 0.0  # S < 1e-12 branch of the 2-D LUT
+    img[1, :4] = [1e-9, 0, 0]
+    ref_out = st.render(img, p, keep_stages=True)
+    params = setup_ctx(ctx, p)
+    if layout == "hwc3":
+        t = dev(img)
+    elif layout == "hwc4":
+        t = dev(np.concatenate([img, np.ones((H, W, 1), np.float32)], axis=-1))
+    else:
+        t = to_planes(img)
+    E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_front(t, params, 0, dst=E)
+    assert_close(from_planes(E), p.stages["exposure"], 1e-5, 1e-4, "exposure")
+    D = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_front(t, params, 1, dst=D)
+    assert_close(from_planes(D), p.stages["density"], 1e-5, 1e-1, "density")
+    out, u8 = ctx.render(t, params, want_f32=True, want_u8=True)
+    assert_close(out.cpu().numpy(), ref_out, 1e-5, 1e-1, "output")
+    ref_u8 = st.to_uint8(ref_out)
+    diff = np.abs(u8.cpu().numpy().astype(int) - ref_u8.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+
+
+def test_tetrahedral_against_reference_golden_vectors(ctx, golden_dir):
+    """S8 on the GPU vs the vectors produced by the reference's own apply_lut_tetrahedral."""
+    import os
+
+    tet = np.load(os.path.join(golden_dir, "tetrahedral.npz"))
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0, halation=False, mtf=False, grain=0)
+    for n in (2, 5, 17, 33):
+        img, lut = tet[f"img_{n}"], tet[f"lut_{n}"]
+        setup_ctx(ctx, p)
+        ctx.set_lut3d(lut)
+        params = ctx.make_params()
+        H, W = img.shape[:2]
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        ctx.stage_tail(to_planes(img), params, out_f32=out, y0=0, y1=H, H_global=H)
+        np.testing.assert_allclose(out.cpu().numpy(), tet[f"out_numba_semantic_{n}"], rtol=0, atol=4e-7)
+
+
+def test_trilinear_mode(ctx):
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0, halation=False, mtf=False, grain=0)
+    p.lut3d_mode = "trilinear"
+    img = synthetic_frame(48, 64, seed=5)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    out, _ = ctx.render(dev(img), params)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "trilinear output")
+
+
+# ------------------------------------------------------------------------------- stencils
+@pytest.mark.parametrize("shape,ksize", [((96, 160), 5), ((150, 200), 43), ((70, 133), 87), ((20, 24), 59), ((1, 40), 5), ((33, 1), 7)])
+def test_generic_stencil_reflect101(ctx, shape, ksize):
+    """Plain per-channel correlation with reflect-101 borders, incl. frames smaller than the stencil
+    (multiple reflections), single-row/column frames, and widths that are not multiples of 4."""
+    H, W = shape
+    rng = np.random.default_rng(ksize)
+    k = rng.uniform(0, 1, (ksize, ksize, 3)).astype(np.float32)
+    k /= k.sum(axis=(0, 1), keepdims=True)
+    img = rng.uniform(0.0, 2.0, (H, W, 3)).astype(np.float32)
+    ref = st.convolve_2d(img, k, method="direct")
+    ctx.set_kernel(1, k)
+    src, dst = to_planes(img), torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_stencil(1, src, dst, y0=0, y1=H, H_global=H)
+    assert_close(from_planes(dst), ref, 1e-5, 1e-3, f"stencil {ksize}")
+
+
+def test_stencil_non_square_and_even_sizes(ctx):
+    rng = np.random.default_rng(11)
+    img = rng.uniform(0.0, 1.0, (40, 72, 3)).astype(np.float32)
+    k = rng.uniform(-0.5, 1, (6, 9, 1)).astype(np.float32)  # even height, anchor (3, 4), negative taps
+    ctx.set_kernel(2, k)
+    src, dst = to_planes(img), torch.empty((3, 40, 72), dtype=torch.float32, device="cuda")
+    ctx.stage_stencil(2, src, dst, y0=0, y1=40, H_global=40)
+    pad = np.pad(img, ((3, 2), (4, 4), (0, 0)), mode="reflect").astype(np.float64)
+    ref = np.zeros((40, 72, 3))
+    for i in range(6):
+        for j in range(9):
+            ref += k[i, j, 0] * pad[i:i + 40, j:j + 72]
+    assert_close(from_planes(dst), ref, 1e-5, 1e-2, "non-square stencil")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_stencil_tile_variants_agree_bitwise(ctx, variant):
+    """Every tile variant accumulates taps in the same order -> identical bits."""
+    rng = np.random.default_rng(7)
+    img = rng.uniform(0.0, 2.0, (130, 270, 3)).astype(np.float32)
+    k = ok.compute_halation_kernel(100.0, halation_green_factor=0.3)
+    ctx.set_kernel(0, k)
+    src = to_planes(img)
+    outs = []
+    for v in (0, variant):
+        ctx.set_option("stencil_variant", v)
+        dst = torch.empty((3, 130, 270), dtype=torch.float32, device="cuda")
+        ctx.stage_stencil(0, src, dst, y0=0, y1=130, H_global=130)
+        outs.append(dst.cpu().numpy())
+    ctx.set_option("stencil_variant", -1)
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("scale", [14.22, 166.67, 341.33])
+def test_halation_stage(ctx, scale):
+    neg, prt, _ = stocks()
+    H, W = 96, 144
+    p = oracle_inputs(neg, prt, scale, mtf=False, grain=0)
+    img = synthetic_frame(H, W, seed=9)
+    st.render(img, p, keep_stages=True)
+    params = setup_ctx(ctx, p)
+    E = to_planes(p.stages["exposure"])
+    D = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H)
+    assert_close(from_planes(D), p.stages["density"], 1e-5, 1e-1, "halation+curve")
+
+
+def test_halation_bw_stock(ctx):
+    _, prt, bw = stocks()
+    H, W = 64, 96
+    p = oracle_inputs(bw, prt, 120.0, mtf=False, grain=0)
+    img = synthetic_frame(H, W, seed=10)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    out, _ = ctx.render(dev(img), params)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "bw halation output")
+
+
+@pytest.mark.parametrize("strength", [0.0, 0.7])
+def test_mtf_stage(ctx, strength):
+    neg, prt, _ = stocks()
+    H, W = 80, 120
+    scale = 229.33
+    p = oracle_inputs(neg, prt, scale, halation=False, grain=0, sharpening_strength=strength)
+    img = synthetic_frame(H, W, seed=12)
+    st.render(img, p, keep_stages=True)
+    params = setup_ctx(ctx, p)
+    D = to_planes(p.stages["density"])
+    D2 = torch.empty_like(D)
+    ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H)
+    assert_close(from_planes(D2), p.stages["mtf"], 1e-5, 1e-1, "mtf")
+
+
+# ------------------------------------------------------------------------------- grain
+def test_pcg3d_hash_bit_exact(ctx):
+    params = ctx.make_params(seed=SEED)
+    H, W = 67, 301
+    h, _ = ctx.stage_noise(params, 5, 5 + H, W, want_noise=False)
+    ys, xs = np.arange(5, 5 + H)[:, None], np.arange(W)[None, :]
+    vx, vy, vz = st.pcg3d(xs, ys, SEED)
+    got = h.cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got[0], vx)
+    np.testing.assert_array_equal(got[1], vy)
+    np.testing.assert_array_equal(got[2], vz)
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_gaussian_field(ctx, mono):
+    params = ctx.make_params(seed=12345, grain_mono=mono)
+    H, W = 128, 256
+    _, n = ctx.stage_noise(params, 0, H, W, want_hash=False)
+    ref = st.gaussian_noise(np.arange(W)[None, :], np.arange(H)[:, None], 12345, mono)
+    got = from_planes(n)
+    assert np.max(np.abs(got - ref)) <= 1e-5  # |n| < 6; fp32 log/sin/cos differ by ~1e-6 between libms
+    assert abs(got.mean()) < 0.02 and abs(got.std() - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("grain", [2, 1])
+@pytest.mark.parametrize("grain_size", [6.0, 1.0, 14.0])
+def test_tail_grain(ctx, grain, grain_size):
+    neg, prt, _ = stocks()
+    H, W = 100, 140
+    p = oracle_inputs(neg, prt, 341.33, halation=False, mtf=False, grain=grain, grain_size=grain_size)
+    img = synthetic_frame(H, W, seed=13)
+    ref = st.render(img, p, keep_stages=True)
+    params = setup_ctx(ctx, p)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    ctx.stage_tail(to_planes(p.stages["density"]), params, out_f32=out, y0=0, y1=H, H_global=H)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "grain tail")
+
+
+# ------------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("shape,scale", [((160, 240), 166.67), ((131, 203), 341.33), ((256, 384), 229.33)])
+def test_full_pipeline(ctx, shape, scale):
+    neg, prt, _ = stocks()
+    H, W = shape
+    p = oracle_inputs(neg, prt, scale)
+    img = synthetic_frame(H, W, seed=21)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    out, u8 = ctx.render(dev(img), params, want_f32=True, want_u8=True)
+    e = assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "full pipeline")
+    print(f"full pipeline {shape} scale {scale}: max err {e:.2e}")
+    diff = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+
+
+def test_row_shards_match_whole_frame_bitwise(ctx):
+    """Stage calls on row shards (with halos) reproduce the whole-frame render bit for bit --
+    the property the multi-GPU row tiler relies on."""
+    neg, prt, _ = stocks()
+    H, W = 150, 200
+    scale = 200.0
+    p = oracle_inputs(neg, prt, scale)
+    img = synthetic_frame(H, W, seed=22)
+    params = setup_ctx(ctx, p)
+    t = dev(img)
+    whole, _ = ctx.render(t, params)
+    rh = p.halation_kernel.shape[0] // 2
+    rm = p.mtf_kernel.shape[0] // 2
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    bounds = [0, 40, 97, 150]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        # rows this shard needs at each level
+        d_lo, d_hi = max(a - rm, 0), min(b + rm, H)
+        e_lo, e_hi = max(d_lo - rh, 0), min(d_hi + rh, H)
+        E = torch.empty((3, e_hi - e_lo, W), dtype=torch.float32, device="cuda")
+        ctx.stage_front(t[e_lo:e_hi].contiguous(), params, 0, in_gy0=e_lo, dst=E, dst_gy0=e_lo, H_global=H)
+        D = torch.empty((3, d_hi - d_lo, W), dtype=torch.float32, device="cuda")
+        ctx.stage_halation(E, D, params, src_gy0=e_lo, dst_gy0=d_lo, y0=d_lo, y1=d_hi, H_global=H)
+        D2 = torch.empty((3, b - a, W), dtype=torch.float32, device="cuda")
+        ctx.stage_mtf(D, D2, params, src_gy0=d_lo, dst_gy0=a, y0=a, y1=b, H_global=H)
+        ctx.stage_tail(D2, params, src_gy0=a, out_f32=out, out_gy0=0, y0=a, y1=b, H_global=H)
+    np.testing.assert_array_equal(out.cpu().numpy(), whole.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------- errors
+def test_errors_are_reported(ctx):
+    from raw2film_amd.context import HipContext
+
+    c = HipContext(0)
+    img = dev(synthetic_frame(8, 8))
+    with pytest.raises(ValueError, match="input LUT not set"):
+        c.render(img, c.make_params())
+    with pytest.raises(ValueError):
+        c.set_lut2d(np.zeros((4, 5, 3), np.float32))
+    with pytest.raises(ValueError):
+        c.set_curve1d(np.zeros((3, 8), np.float32))
+    c.close()
