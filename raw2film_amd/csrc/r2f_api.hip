@@ -32,10 +32,10 @@ struct StencilSet {
     int kh = 0, kw = 0, kc = 0;
     std::vector<float> host;  // (kh, kw, kc)
     int built_q = 0;          // 0 = device form stale
+    int built_tw = 0;
     bool common_box = false;
     DevStencil dev[3];
     DeviceBuf wbuf[3], mbuf[3];
-    int maxk = 0;
 };
 
 }  // namespace
@@ -53,6 +53,7 @@ struct r2f_ctx {
     StencilSet stencil[3];
     int opt_variant = -1;  // -1 auto
     int opt_xcd_remap = 1;
+    int opt_ablate = 0;
 };
 
 namespace {
@@ -114,15 +115,18 @@ int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, i
     return R2F_OK;
 }
 
-// Re-order one channel of a stencil for stencil_accumulate<Q> (layout documented in r2f_device.h).
-// The taps are cropped to the bounding box [i_lo..i_hi] x [j_lo..j_hi] given by the caller.
-void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int j_hi, int Q, std::vector<float>& w,
-                  std::vector<int4>& meta) {
+// Flatten one channel of a stencil into the entry list of stencil_accumulate<Q> (layout in
+// r2f_device.h).  Taps are cropped to the bounding box [i_lo..i_hi] x [j_lo..j_hi]; per input-row
+// step m only the 4-tap chunks between the first and last chunk holding a non-zero tap of any of
+// the Q kernel rows m-q are emitted (the halation disc skips its empty corners this way).
+void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int j_hi, int Q, int RS,
+                  std::vector<float>& w, std::vector<int>& offs, std::vector<int>& rowcnt) {
     const int kh = i_hi - i_lo + 1, kw = j_hi - j_lo + 1;
     const int nch = (kw + 3) / 4;
     const int M = kh + Q - 1;
     w.clear();
-    meta.assign(M, make_int4(0, 0, 0, 0));
+    offs.clear();
+    rowcnt.clear();
     auto tap = [&](int i, int j) -> float {
         if (i < 0 || i >= kh || j < 0 || j >= kw) return 0.f;
         return k[(size_t)(i + i_lo) * kw_full + (j + j_lo)];
@@ -143,18 +147,24 @@ void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int
             }
         }
         if (c_hi < 0) continue;  // no work on this row step
-        meta[m] = make_int4(c_lo, c_hi - c_lo + 1, (int)w.size(), 0);
-        for (int c = c_lo; c <= c_hi; ++c)
-            for (int q = 0; q < Q; ++q)
-                for (int t = 0; t < 4; ++t) w.push_back(tap(m - q, 4 * c + t));
+        rowcnt.push_back(c_hi - c_lo + 1);
+        for (int c = c_lo; c <= c_hi; ++c) {
+            offs.push_back(m * RS + 4 * c);
+            for (int t = 0; t < 4; ++t)
+                for (int q = 0; q < Q; ++q) w.push_back(tap(m - q, 4 * c + t));
+        }
     }
-    if (w.empty()) w.push_back(0.f);
+    for (int d = 0; d < 2; ++d) {  // two dummy entries: targets of the last prefetches
+        offs.push_back(0);
+        for (int i = 0; i < 4 * Q; ++i) w.push_back(0.f);
+    }
+    if (rowcnt.empty()) rowcnt.push_back(0);
 }
 
-int ensure_stencil(r2f_ctx* ctx, int which, int Q, bool common_box) {
+int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, bool common_box) {
     StencilSet& s = ctx->stencil[which];
     if (!s.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
-    if (s.built_q == Q && s.common_box == common_box) return R2F_OK;
+    if (s.built_q == Q && s.built_tw == TW && s.common_box == common_box) return R2F_OK;
     int box[3][4];
     for (int c = 0; c < 3; ++c) {
         const int kc = s.kc == 1 ? 0 : c;
@@ -180,28 +190,33 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, bool common_box) {
         for (int c = 1; c < 3; ++c) memcpy(box[c], box[0], sizeof box[0]);
     }
     std::vector<float> plane((size_t)s.kh * s.kw), w;
-    std::vector<int4> meta;
-    s.maxk = 0;
+    std::vector<int> offs, rowcnt;
     for (int c = 0; c < 3; ++c) {
         const int kc = s.kc == 1 ? 0 : c;
         for (size_t i = 0; i < plane.size(); ++i) plane[i] = s.host[i * s.kc + kc];
-        build_stream(plane.data(), s.kw, box[c][0], box[c][1], box[c][2], box[c][3], Q, w, meta);
-        int rc = upload(ctx, s.wbuf[c], w.data(), w.size() * sizeof(float));
-        if (rc) return rc;
-        rc = upload(ctx, s.mbuf[c], meta.data(), meta.size() * sizeof(int4));
-        if (rc) return rc;
         DevStencil& d = s.dev[c];
-        d.wstream = static_cast<const float*>(s.wbuf[c].p);
-        d.rowmeta = static_cast<const int4*>(s.mbuf[c].p);
         d.kh = box[c][1] - box[c][0] + 1;
         d.kw = box[c][3] - box[c][2] + 1;
         d.kw_pad = (d.kw + 3) / 4 * 4;
-        d.M = d.kh + Q - 1;
+        d.RS = TW + d.kw_pad;
         d.ay = s.kh / 2 - box[c][0];  // anchor (kh/2, kw/2): convolution.wgsl:31, cv.filter2D default
         d.ax = s.kw / 2 - box[c][2];
-        s.maxk = std::max(s.maxk, std::max(d.kh, d.kw));
+        d.wmul = 1;
+        build_stream(plane.data(), s.kw, box[c][0], box[c][1], box[c][2], box[c][3], Q, d.RS, w, offs, rowcnt);
+        d.n_rows = offs.size() > 2 ? (int)rowcnt.size() : 0;
+        int rc = upload(ctx, s.wbuf[c], w.data(), w.size() * sizeof(float));
+        if (rc) return rc;
+        // offsets and row counts share one allocation: [offs | rowcnt]
+        const size_t n_off = offs.size();
+        offs.insert(offs.end(), rowcnt.begin(), rowcnt.end());
+        rc = upload(ctx, s.mbuf[c], offs.data(), offs.size() * sizeof(int));
+        if (rc) return rc;
+        d.wstream = static_cast<const float*>(s.wbuf[c].p);
+        d.offs = static_cast<const int*>(s.mbuf[c].p);
+        d.rowcnt = d.offs + n_off;
     }
     s.built_q = Q;
+    s.built_tw = TW;
     s.common_box = common_box;
     return R2F_OK;
 }
@@ -241,18 +256,6 @@ int check_stencil_source(r2f_ctx* ctx, const char* what, const r2f_planes* src, 
     return check_rows(ctx, what, src, need_lo, need_hi + 1);
 }
 
-int pick_variant(r2f_ctx* ctx, const DevStencil* st, int nchan, int Q_of_built, int* variant) {
-    (void)Q_of_built;
-    for (int v = 0; v < kNumStencilVariants; ++v) {
-        if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
-        if (stencil_lds_bytes(kStencilVariants[v], st, nchan) <= kMaxLds) {
-            *variant = v;
-            return R2F_OK;
-        }
-    }
-    return fail(ctx, R2F_ETOOLARGE, "stencil does not fit any LDS tile variant (<= %zu bytes)", kMaxLds);
-}
-
 int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
                 int epilogue, float log_eps, hipStream_t s) {
     if (y1 <= y0) return R2F_OK;
@@ -263,7 +266,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     int variant = -1;
     for (int v = 0; v < kNumStencilVariants; ++v) {
         if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
-        int rc = ensure_stencil(ctx, which, kStencilVariants[v].Q, false);
+        int rc = ensure_stencil(ctx, which, kStencilVariants[v].Q, kStencilVariants[v].TW(), false);
         if (rc) return rc;
         if (stencil_lds_bytes(kStencilVariants[v], set.dev, 3) <= kMaxLds) {
             variant = v;
@@ -280,7 +283,10 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     }
     if (epilogue == 1 && !ctx->curve.data) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
     StencilArgs a;
-    for (int c = 0; c < 3; ++c) a.st[c] = set.dev[c];
+    for (int c = 0; c < 3; ++c) {
+        a.st[c] = set.dev[c];
+        if (ctx->opt_ablate == 3) a.st[c].wmul = 0;
+    }
     a.src = to_dev(src);
     a.dst = to_dev(dst);
     a.y0 = y0;
@@ -293,6 +299,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     a.nchan = 3;
     a.vec = planes_vec_ok(dst, W) ? 1 : 0;
     a.xcd_remap = ctx->opt_xcd_remap;
+    a.ablate = ctx->opt_ablate;
     R2F_HIP(ctx, launch_stencil(a, variant, s));
     return R2F_OK;
 }
@@ -339,6 +346,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_variant")) {
         if (value < -1 || value >= kNumStencilVariants) return fail(ctx, R2F_EINVAL, "stencil_variant out of range");
         ctx->opt_variant = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_ablate")) {
+        ctx->opt_ablate = value;
         return R2F_OK;
     }
     if (!strcmp(name, "xcd_remap")) {
@@ -517,7 +528,7 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
             rc = r2f_set_kernel(ctx, R2F_KERNEL_GRAIN, &one, 1, 1, 1);
             if (rc) return rc;
         }
-        rc = ensure_stencil(ctx, R2F_KERNEL_GRAIN, kTailQ, true);
+        rc = ensure_stencil(ctx, R2F_KERNEL_GRAIN, kTailQ, 4 * kTailBX, true);
         if (rc) return rc;
         for (int c = 0; c < 3; ++c) a.gk[c] = ctx->stencil[R2F_KERNEL_GRAIN].dev[c];
         if (tail_lds_bytes(a.gk, a.mono) > kMaxLds)

@@ -33,15 +33,20 @@ struct DevLut3D {  // S8: n^3 float4 texels, (r, g, b) at (r*n + g)*n + b
     int n;
 };
 
-// One channel of a stencil, cropped to the bounding box of its non-zero taps and
-// re-ordered into the order the inner loop consumes it (see stencil_accumulate).
+// One channel of a stencil, cropped to the bounding box of its non-zero taps and flattened
+// into the list of "entries" the inner loop consumes (see stencil_accumulate).  One entry =
+// one input-row step m x one 4-tap chunk c; the entries of a row step are consecutive.  The
+// list ends with two dummy entries so the loop can always prefetch ahead.
 struct DevStencil {
-    const float* wstream;  // per (m, chunk): Q*4 floats  w[q][t] = K[m-q][4*chunk+t]
-    const int4* rowmeta;   // per m: {first chunk, chunk count, float offset into wstream, 0}
-    int M;                 // kh + Q - 1 input-row steps
+    const float* wstream;  // per entry: 4*Q floats  w[t][q] = K[m-q][4c+t]  (0 outside the taps)
+    const int* offs;       // per entry: LDS float offset m*RS + 4c
+    const int* rowcnt;     // per non-empty row step: number of entries (>= 1)
+    int n_rows;
     int kh, kw;            // cropped taps
     int kw_pad;            // kw rounded up to a multiple of 4
     int ay, ax;            // anchor inside the cropped box
+    int RS;                // LDS row stride (floats) the offsets were built for
+    int wmul;              // 1; 0 = profiling aid (every entry reads entry 0's weights -> scalar-cache hits)
 };
 
 struct DevPlanes {
@@ -247,38 +252,127 @@ __device__ __forceinline__ void gaussian_noise(uint32_t gx, uint32_t gy, uint32_
 }
 
 // ---------------------------------------------------------------------------- stencil core
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float8v __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+template <int N>
+struct WVec;
+template <>
+struct WVec<8> {
+    typedef float8v type;
+};
+template <>
+struct WVec<16> {
+    typedef float16v type;
+};
+
 // Register-tiled direct correlation out of an LDS tile.  Each lane owns P=4 consecutive
-// pixels in x and Q consecutive rows.  `lds` points at the lane's first row / first column
-// of the tile plane.  For every input-row step m and every 4-tap chunk the lane reads ONE
-// new float4 from LDS (the other half of the 7-float window is last iteration's), the wave
-// reads Q*4 weights through the scalar cache into SGPRs, and issues Q*16 v_fma_f32.
-// Accumulation order per output pixel is row-major over the taps, independent of the tile
-// or shard the pixel falls in -> results are bit-identical for any tiling.
-template <int Q>
-__device__ __forceinline__ void stencil_accumulate(const float* lds, int RS, const DevStencil& st, float (&acc)[Q][4]) {
-    const int R2F_CONSTANT* rowmeta = (const int R2F_CONSTANT*)st.rowmeta;
-    const float R2F_CONSTANT* wstream = (const float R2F_CONSTANT*)st.wstream;
-    const int M = st.M;
-    for (int m = 0; m < M; ++m) {
-        const int c_lo = rowmeta[4 * m], nchunk = rowmeta[4 * m + 1], woff = rowmeta[4 * m + 2];
-        const float* lrow = lds + m * RS + 4 * c_lo;
-        const float R2F_CONSTANT* w = wstream + woff;
-        float4 a = *reinterpret_cast<const float4*>(lrow);
-#pragma unroll 2
-        for (int c = 0; c < nchunk; ++c) {
-            const float4 b = *reinterpret_cast<const float4*>(lrow + 4 * (c + 1));
-            const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+// pixels in x and Q consecutive rows; accumulators are packed in pairs of ROWS so that one
+// v_pk_fma_f32 does acc[rows 2j,2j+1][p] += (w[t][2j], w[t][2j+1]) * pixel, with the weight
+// pair in SGPRs (scalar-cache load, wave-uniform) and the pixel broadcast from one VGPR.
+// Per entry the lane reads 8 consecutive floats from LDS (two ds_read_b128), the wave reads
+// 4*Q weights with one s_load, and issues 8*Q v_pk_fma_f32.  Entry e+1's weights and pixels
+// (and entry e+2's LDS offset) are requested before entry e's FMAs issue; the inner loop body
+// is branch-free so that order survives to the ISA.
+//
+// Numerics: taps are consumed in row-major order per output pixel (independent of the tile
+// or shard the pixel falls in -> bit-identical results for any tiling).  Each kernel row is
+// summed into a row partial (its first entry starts the partial with a multiply), and the
+// row partials are then added up: two-level summation, so the rounding error grows like
+// sqrt(kw) + sqrt(kh) instead of sqrt(kh*kw) ulps.
+template <int Q, bool FIRST>
+__device__ __forceinline__ void entry_fma(const typename WVec<4 * Q>::type& w, const float4v& a, const float4v& b,
+                                          float2v (&part)[Q / 2][4]) {
+    const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float wv = w[(c * Q + q) * 4 + t];
+        for (int j = 0; j < Q / 2; ++j) {
+            const float2v wv = {w[t * Q + 2 * j], w[t * Q + 2 * j + 1]};
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[q][p] = fmaf(wv, win[p + t], acc[q][p]);
-                }
+            for (int p = 0; p < 4; ++p) {
+                const float2v px = {win[p + t], win[p + t]};
+                if (FIRST && t == 0)
+                    part[j][p] = wv * px;
+                else
+                    part[j][p] = __builtin_elementwise_fma(wv, px, part[j][p]);
             }
-            a = b;
         }
+    }
+}
+
+// Scalar-memory loads return out of order, so the only wait hipcc can emit for them is
+// lgkmcnt(0) -- which also waits for anything issued since.  Touching the current entry's
+// operands here makes that wait land BEFORE the next entry's loads are issued (they then fly
+// during this entry's FMAs); sched_barrier keeps the scheduler from moving loads across it.
+template <int Q>
+__device__ __forceinline__ void wait_operands(const typename WVec<4 * Q>::type& w, const float4v& a, const float4v& b) {
+    asm volatile("" ::"s"(w[0]), "s"(w[4 * Q - 1]), "v"(a.x), "v"(b.w));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One pipeline step: wait for the current entry's operands, request the next entry's
+// (into the other register set), then issue the current entry's FMAs.
+template <int Q, bool FIRST>
+__device__ __forceinline__ void entry_step(const float* lds, const int R2F_CONSTANT* offs,
+                                           const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e, int& off1,
+                                           const typename WVec<4 * Q>::type& cw, const float4v& ca, const float4v& cb,
+                                           typename WVec<4 * Q>::type& nw, float4v& na, float4v& nb,
+                                           float2v (&part)[Q / 2][4]) {
+    wait_operands<Q>(cw, ca, cb);
+    const int off2 = offs[e + 2];
+    nw = wstream[(e + 1) * wmul];
+    na = *reinterpret_cast<const float4v*>(lds + off1);
+    nb = *reinterpret_cast<const float4v*>(lds + off1 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    entry_fma<Q, FIRST>(cw, ca, cb, part);
+    off1 = off2;
+    ++e;
+}
+
+template <int Q>
+__device__ __forceinline__ void stencil_accumulate(const float* lds, const DevStencil& st, float2v (&acc)[Q / 2][4]) {
+    static_assert(Q == 2 || Q == 4, "Q must be 2 or 4");
+    typedef typename WVec<4 * Q>::type wvec;
+    const int R2F_CONSTANT* offs = (const int R2F_CONSTANT*)st.offs;
+    const int R2F_CONSTANT* rowcnt = (const int R2F_CONSTANT*)st.rowcnt;
+    const wvec R2F_CONSTANT* wstream = (const wvec R2F_CONSTANT*)st.wstream;
+    const int n_rows = st.n_rows;
+    const int wmul = st.wmul;
+    float2v part[Q / 2][4];
+
+    int e = 0;           // flat entry index
+    int off1 = offs[1];  // LDS offset of entry e+1
+    // two operand sets: A holds the current entry at the top of every row step
+    wvec wA = wstream[0], wB;
+    float4v aA, bA, aB, bB;
+    {
+        const int off0 = offs[0];
+        aA = *reinterpret_cast<const float4v*>(lds + off0);
+        bA = *reinterpret_cast<const float4v*>(lds + off0 + 4);
+    }
+    for (int r = 0; r < n_rows; ++r) {
+        const int cnt = rowcnt[r];
+        // first entry of the row step starts the row partial (multiply instead of fma)
+        entry_step<Q, true>(lds, offs, wstream, wmul, e, off1, wA, aA, bA, wB, aB, bB, part);
+        int i = 1;
+        for (; i + 1 < cnt; i += 2) {
+            entry_step<Q, false>(lds, offs, wstream, wmul, e, off1, wB, aB, bB, wA, aA, bA, part);
+            entry_step<Q, false>(lds, offs, wstream, wmul, e, off1, wA, aA, bA, wB, aB, bB, part);
+        }
+        if (i < cnt) {
+            entry_step<Q, false>(lds, offs, wstream, wmul, e, off1, wB, aB, bB, wA, aA, bA, part);
+        } else {  // an odd number of steps was taken: the current entry sits in set B
+            wA = wB;
+            aA = aB;
+            bA = bB;
+        }
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[j][p] += part[j][p];
     }
 }
 

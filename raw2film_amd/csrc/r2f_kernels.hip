@@ -249,20 +249,21 @@ __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
     }
     const DevStencil st = a.st[ch];
     const int tile_x0 = bx * TW, tile_y0 = a.y0 + by * TH;
-    const int RS = TW + st.kw_pad;
+    const int RS = st.RS;
     const int rows = TH + st.kh - 1;
     const float* src = a.src.data + (long long)ch * a.src.plane_stride;
-    fill_tile_reflect<NT>(smem, RS, rows, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global,
-                          tile_y0 - st.ay, tile_x0 - st.ax);
+    if (a.ablate != 1)
+        fill_tile_reflect<NT>(smem, RS, rows, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global,
+                              tile_y0 - st.ay, tile_x0 - st.ax);
     __syncthreads();
 
     const int tx = threadIdx.x % BX, ty = threadIdx.x / BX;
-    float acc[Q][4];
+    float2v acc[Q / 2][4];
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+    for (int j = 0; j < Q / 2; ++j)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[q][p] = 0.f;
-    stencil_accumulate<Q>(smem + ty * Q * RS + 4 * tx, RS, st, acc);
+        for (int p = 0; p < 4; ++p) acc[j][p] = (float2v){0.f, 0.f};
+    if (a.ablate != 2) stencil_accumulate<Q>(smem + ty * Q * RS + 4 * tx, st, acc);
 
     const int gx = tile_x0 + 4 * tx;
     if (gx >= a.W) return;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
     for (int q = 0; q < Q; ++q) {
         const int gy = tile_y0 + ty * Q + q;
         if (gy >= a.y1) break;
-        float v[4] = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+        float v[4] = {acc[q / 2][0][q & 1], acc[q / 2][1][q & 1], acc[q / 2][2][q & 1], acc[q / 2][3][q & 1]};
         if (a.epilogue == 1) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) v[p] = log_curve(a.curve, ch, v[p], a.log_eps);
@@ -292,14 +293,14 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
     constexpr int NT = kTailBX * kTailBY, TW = 4 * kTailBX, TH = kTailQ * kTailBY, Q = kTailQ;
     const int tile_x0 = blockIdx.x * TW, tile_y0 = a.y0 + blockIdx.y * TH;
     const DevStencil g0 = a.gk[0];
-    const int RS = TW + g0.kw_pad;
+    const int RS = g0.RS;
     const int rows = TH + g0.kh - 1;
-    const int plane_sz = rows * RS;
+    const int plane_sz = rows * RS + 16;  // + slack: the prefetch of the dummy entry reads past the last row
     const int cols_valid = TW + g0.kw - 1;
     const bool mono = a.mono != 0;
     // S6a: hash noise for the tile + halo, straight into LDS.  Coordinates are clamped to the
     // frame like the shader's texture reads (grain.wgsl:63-75); the hash sees GLOBAL coordinates.
-    for (int idx = threadIdx.x; idx < plane_sz; idx += NT) {
+    for (int idx = threadIdx.x; idx < rows * RS; idx += NT) {
         const int r = idx / RS, c = idx - r * RS;
         float nr = 0.f, ng = 0.f, nb = 0.f;
         if (c < cols_valid) {
@@ -316,15 +317,15 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
     __syncthreads();
 
     const int tx = threadIdx.x % kTailBX, ty = threadIdx.x / kTailBX;
-    float G[3][Q][4];
+    float2v G[3][Q / 2][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
+        for (int j = 0; j < Q / 2; ++j)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) G[c][q][p] = 0.f;
+            for (int p = 0; p < 4; ++p) G[c][j][p] = (float2v){0.f, 0.f};
         const float* plane = smem + (mono ? 0 : c * plane_sz);
-        stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, RS, a.gk[c], G[c]);
+        stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], G[c]);
     }
 
     const int gx = tile_x0 + 4 * tx;
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             // S6c grain.wgsl:78-89 + clip cpu_processor.py:397
-            r[p] = fmaxf(r[p] + G[0][q][p] * curve_eval(a.grain_lut, 0, r[p]), 0.f);
-            g[p] = fmaxf(g[p] + G[1][q][p] * curve_eval(a.grain_lut, 1, g[p]), 0.f);
-            b[p] = fmaxf(b[p] + G[2][q][p] * curve_eval(a.grain_lut, 2, b[p]), 0.f);
+            r[p] = fmaxf(r[p] + G[0][q / 2][p][q & 1] * curve_eval(a.grain_lut, 0, r[p]), 0.f);
+            g[p] = fmaxf(g[p] + G[1][q / 2][p][q & 1] * curve_eval(a.grain_lut, 1, g[p]), 0.f);
+            b[p] = fmaxf(b[p] + G[2][q / 2][p][q & 1] * curve_eval(a.grain_lut, 2, b[p]), 0.f);
             apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
         }
         emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, gx, a.W, nv, vec, r, g, b);
@@ -377,14 +378,14 @@ __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan) {
     size_t best = 0;
     for (int c = 0; c < nchan; ++c) {
-        size_t b = (size_t)(v.TW() + st[c].kw_pad) * (size_t)(v.TH() + st[c].kh - 1) * sizeof(float);
+        size_t b = ((size_t)(v.TW() + st[c].kw_pad) * (size_t)(v.TH() + st[c].kh - 1) + 16) * sizeof(float);
         if (b > best) best = b;
     }
     return best;
 }
 
 size_t tail_lds_bytes(const DevStencil* gk, int mono) {
-    const size_t plane = (size_t)(4 * kTailBX + gk[0].kw_pad) * (size_t)(kTailQ * kTailBY + gk[0].kh - 1);
+    const size_t plane = (size_t)(4 * kTailBX + gk[0].kw_pad) * (size_t)(kTailQ * kTailBY + gk[0].kh - 1) + 16;
     return plane * (mono ? 1 : 3) * sizeof(float);
 }
 

@@ -36,6 +36,7 @@ struct StencilArgs {
     int nchan;
     int vec;
     int xcd_remap;
+    int ablate;  // profiling aid: 1 = skip the tile fill, 2 = skip the accumulation (results invalid)
 };
 
 struct TailArgs {

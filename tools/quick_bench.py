@@ -66,6 +66,14 @@ for v in [int(x) for x in args.variants.split(",")]:
         print(f"halation v{v} remap{remap} {t[0]:8.3f} ms")
     t = timeit(lambda: ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H))
     print(f"mtf      v{v}        {t[0]:8.3f} ms")
+ctx.set_option("xcd_remap", 0)
+for v in [int(x) for x in args.variants.split(",")]:
+    ctx.set_option("stencil_variant", v)
+    for ab in (1, 2, 3):
+        ctx.set_option("stencil_ablate", ab)
+        t = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
+        print(f"halation v{v} ablate={ab} ({['', 'no fill', 'no accumulate', 'weights always entry 0'][ab]}) {t[0]:8.3f} ms")
+ctx.set_option("stencil_ablate", 0)
 ctx.set_option("stencil_variant", -1)
 ctx.set_option("xcd_remap", 1)
 t = timeit(lambda: ctx.stage_tail(D2, params, out_f32=out, y0=0, y1=H, H_global=H))
