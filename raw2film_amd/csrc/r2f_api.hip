@@ -32,7 +32,8 @@ struct StencilSet {
     int kh = 0, kw = 0, kc = 0;
     std::vector<float> host;  // (kh, kw, kc)
     int built_q = 0;          // 0 = device form stale
-    int built_tw = 0;
+    int built_tw = 0, built_th = 0;
+    size_t built_budget = 0;
     bool common_box = false;
     DevStencil dev[3];
     DeviceBuf wbuf[3], mbuf[3];
@@ -54,6 +55,7 @@ struct r2f_ctx {
     int opt_variant = -1;  // -1 auto
     int opt_xcd_remap = 1;
     int opt_ablate = 0;
+    int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
 };
 
 namespace {
@@ -119,52 +121,77 @@ int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, i
 // r2f_device.h).  Taps are cropped to the bounding box [i_lo..i_hi] x [j_lo..j_hi]; per input-row
 // step m only the 4-tap chunks between the first and last chunk holding a non-zero tap of any of
 // the Q kernel rows m-q are emitted (the halation disc skips its empty corners this way).
-void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int j_hi, int Q, int RS,
-                  std::vector<float>& w, std::vector<int>& offs, std::vector<int>& rowcnt) {
+// Row steps are grouped into phases of at most `mp` steps; LDS offsets are relative to the phase.
+struct StreamHost {
+    std::vector<float> w;
+    std::vector<int> offs, rowcnt, phases;
+    int n_phases = 0, n_rowsteps = 0, max_lds_rows = 0;
+};
+
+void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int j_hi, int Q, int RS, int TH, int mp,
+                  StreamHost& out) {
     const int kh = i_hi - i_lo + 1, kw = j_hi - j_lo + 1;
     const int nch = (kw + 3) / 4;
     const int M = kh + Q - 1;
-    w.clear();
-    offs.clear();
-    rowcnt.clear();
+    out = StreamHost();
     auto tap = [&](int i, int j) -> float {
         if (i < 0 || i >= kh || j < 0 || j >= kw) return 0.f;
         return k[(size_t)(i + i_lo) * kw_full + (j + j_lo)];
     };
-    for (int m = 0; m < M; ++m) {
-        int c_lo = nch, c_hi = -1;
-        for (int c = 0; c < nch; ++c) {
-            bool nz = false;
-            for (int q = 0; q < Q && !nz; ++q)
+    if (mp < 1) mp = 1;
+    for (int m0 = 0; m0 < M; m0 += mp) {
+        const int m1 = std::min(M, m0 + mp);
+        const int lds_rows = TH - Q + (m1 - m0);
+        out.phases.push_back(m0);
+        out.phases.push_back(lds_rows);
+        out.phases.push_back((int)out.rowcnt.size());
+        out.phases.push_back((int)out.offs.size());
+        out.max_lds_rows = std::max(out.max_lds_rows, lds_rows);
+        ++out.n_phases;
+        for (int m = m0; m < m1; ++m) {
+            int c_lo = nch, c_hi = -1;
+            for (int c = 0; c < nch; ++c) {
+                bool nz = false;
+                for (int q = 0; q < Q && !nz; ++q)
+                    for (int t = 0; t < 4; ++t)
+                        if (tap(m - q, 4 * c + t) != 0.f) {
+                            nz = true;
+                            break;
+                        }
+                if (nz) {
+                    if (c < c_lo) c_lo = c;
+                    c_hi = c;
+                }
+            }
+            if (c_hi < 0) continue;  // no work on this row step
+            out.rowcnt.push_back(c_hi - c_lo + 1);
+            for (int c = c_lo; c <= c_hi; ++c) {
+                out.offs.push_back((m - m0) * RS + 4 * c);
                 for (int t = 0; t < 4; ++t)
-                    if (tap(m - q, 4 * c + t) != 0.f) {
-                        nz = true;
-                        break;
-                    }
-            if (nz) {
-                if (c < c_lo) c_lo = c;
-                c_hi = c;
+                    for (int q = 0; q < Q; ++q) out.w.push_back(tap(m - q, 4 * c + t));
             }
         }
-        if (c_hi < 0) continue;  // no work on this row step
-        rowcnt.push_back(c_hi - c_lo + 1);
-        for (int c = c_lo; c <= c_hi; ++c) {
-            offs.push_back(m * RS + 4 * c);
-            for (int t = 0; t < 4; ++t)
-                for (int q = 0; q < Q; ++q) w.push_back(tap(m - q, 4 * c + t));
-        }
     }
+    out.n_rowsteps = (int)out.rowcnt.size();
+    // terminator phase record: {., ., n_rowsteps, n_entries}
+    out.phases.push_back(0);
+    out.phases.push_back(0);
+    out.phases.push_back(out.n_rowsteps);
+    out.phases.push_back((int)out.offs.size());
     for (int d = 0; d < 2; ++d) {  // two dummy entries: targets of the last prefetches
-        offs.push_back(0);
-        for (int i = 0; i < 4 * Q; ++i) w.push_back(0.f);
+        out.offs.push_back(0);
+        for (int i = 0; i < 4 * Q; ++i) out.w.push_back(0.f);
     }
-    if (rowcnt.empty()) rowcnt.push_back(0);
+    if (out.rowcnt.empty()) out.rowcnt.push_back(0);
 }
 
-int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, bool common_box) {
+// Build (or reuse) the device form of stencil `which` for a tile TW x TH, Q rows per lane, and an LDS
+// budget in bytes (0 = whole stencil height in one phase).
+int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_budget, bool common_box) {
     StencilSet& s = ctx->stencil[which];
     if (!s.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
-    if (s.built_q == Q && s.built_tw == TW && s.common_box == common_box) return R2F_OK;
+    if (s.built_q == Q && s.built_tw == TW && s.built_th == TH && s.built_budget == lds_budget && s.common_box == common_box)
+        return R2F_OK;
     int box[3][4];
     for (int c = 0; c < 3; ++c) {
         const int kc = s.kc == 1 ? 0 : c;
@@ -189,8 +216,8 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, bool common_box) {
         }
         for (int c = 1; c < 3; ++c) memcpy(box[c], box[0], sizeof box[0]);
     }
-    std::vector<float> plane((size_t)s.kh * s.kw), w;
-    std::vector<int> offs, rowcnt;
+    std::vector<float> plane((size_t)s.kh * s.kw);
+    StreamHost sh;
     for (int c = 0; c < 3; ++c) {
         const int kc = s.kc == 1 ? 0 : c;
         for (size_t i = 0; i < plane.size(); ++i) plane[i] = s.host[i * s.kc + kc];
@@ -202,21 +229,39 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, bool common_box) {
         d.ay = s.kh / 2 - box[c][0];  // anchor (kh/2, kw/2): convolution.wgsl:31, cv.filter2D default
         d.ax = s.kw / 2 - box[c][2];
         d.wmul = 1;
-        build_stream(plane.data(), s.kw, box[c][0], box[c][1], box[c][2], box[c][3], Q, d.RS, w, offs, rowcnt);
-        d.n_rows = offs.size() > 2 ? (int)rowcnt.size() : 0;
-        int rc = upload(ctx, s.wbuf[c], w.data(), w.size() * sizeof(float));
+        const int M = d.kh + Q - 1;
+        int mp = M;
+        if (lds_budget) {
+            const long long rows_fit = (long long)(lds_budget / sizeof(float) - 16) / d.RS;
+            mp = (int)std::min<long long>(M, rows_fit - (TH - Q));
+            if (mp < 1) return fail(ctx, R2F_ETOOLARGE, "stencil %d: %d-tap rows do not fit the LDS budget", which, d.kw);
+            // equalise the phases instead of leaving a short last one
+            const int nph = (M + mp - 1) / mp;
+            mp = (M + nph - 1) / nph;
+        }
+        build_stream(plane.data(), s.kw, box[c][0], box[c][1], box[c][2], box[c][3], Q, d.RS, TH, mp, sh);
+        d.n_phases = sh.n_phases;
+        d.n_rowsteps = sh.n_rowsteps;
+        d.max_lds_rows = sh.max_lds_rows;
+        int rc = upload(ctx, s.wbuf[c], sh.w.data(), sh.w.size() * sizeof(float));
         if (rc) return rc;
-        // offsets and row counts share one allocation: [offs | rowcnt]
-        const size_t n_off = offs.size();
-        offs.insert(offs.end(), rowcnt.begin(), rowcnt.end());
-        rc = upload(ctx, s.mbuf[c], offs.data(), offs.size() * sizeof(int));
+        // offsets, row counts and phase records share one allocation: [offs | rowcnt | phases]
+        std::vector<int> meta(sh.offs);
+        const size_t n_off = meta.size();
+        meta.insert(meta.end(), sh.rowcnt.begin(), sh.rowcnt.end());
+        const size_t n_rc = sh.rowcnt.size();
+        meta.insert(meta.end(), sh.phases.begin(), sh.phases.end());
+        rc = upload(ctx, s.mbuf[c], meta.data(), meta.size() * sizeof(int));
         if (rc) return rc;
         d.wstream = static_cast<const float*>(s.wbuf[c].p);
         d.offs = static_cast<const int*>(s.mbuf[c].p);
         d.rowcnt = d.offs + n_off;
+        d.phases = d.rowcnt + n_rc;
     }
     s.built_q = Q;
     s.built_tw = TW;
+    s.built_th = TH;
+    s.built_budget = lds_budget;
     s.common_box = common_box;
     return R2F_OK;
 }
@@ -262,13 +307,18 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     if (W <= 0 || H <= 0 || y0 < 0 || y1 > H) return fail(ctx, R2F_EINVAL, "stencil: bad geometry");
     StencilSet& set = ctx->stencil[which];
     if (!set.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
-    // choose the tile variant from the stencil size; the stream layout depends on its Q
+    // choose the tile variant: the widest tile whose rows fit the LDS budget and the fill's 256-float row limit
     int variant = -1;
+    const size_t budget = (size_t)ctx->opt_lds_kb * 1024;
     for (int v = 0; v < kNumStencilVariants; ++v) {
         if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
-        int rc = ensure_stencil(ctx, which, kStencilVariants[v].Q, kStencilVariants[v].TW(), false);
+        const StencilVariant& sv = kStencilVariants[v];
+        int rc = ensure_stencil(ctx, which, sv.Q, sv.TW(), sv.TH(), budget, false);
+        if (rc == R2F_ETOOLARGE) continue;
         if (rc) return rc;
-        if (stencil_lds_bytes(kStencilVariants[v], set.dev, 3) <= kMaxLds) {
+        bool ok = stencil_lds_bytes(sv, set.dev, 3) <= kMaxLds;
+        for (int c = 0; c < 3; ++c) ok = ok && set.dev[c].RS <= 256;
+        if (ok) {
             variant = v;
             break;
         }
@@ -346,6 +396,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_variant")) {
         if (value < -1 || value >= kNumStencilVariants) return fail(ctx, R2F_EINVAL, "stencil_variant out of range");
         ctx->opt_variant = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_lds_kb")) {
+        if (value < 8 || value > 160) return fail(ctx, R2F_EINVAL, "stencil_lds_kb must be in [8, 160]");
+        ctx->opt_lds_kb = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_ablate")) {
@@ -528,7 +583,7 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
             rc = r2f_set_kernel(ctx, R2F_KERNEL_GRAIN, &one, 1, 1, 1);
             if (rc) return rc;
         }
-        rc = ensure_stencil(ctx, R2F_KERNEL_GRAIN, kTailQ, 4 * kTailBX, true);
+        rc = ensure_stencil(ctx, R2F_KERNEL_GRAIN, kTailQ, 4 * kTailBX, kTailQ * kTailBY, 0, true);
         if (rc) return rc;
         for (int c = 0; c < 3; ++c) a.gk[c] = ctx->stencil[R2F_KERNEL_GRAIN].dev[c];
         if (tail_lds_bytes(a.gk, a.mono) > kMaxLds)

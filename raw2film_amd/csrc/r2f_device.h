@@ -35,17 +35,24 @@ struct DevLut3D {  // S8: n^3 float4 texels, (r, g, b) at (r*n + g)*n + b
 
 // One channel of a stencil, cropped to the bounding box of its non-zero taps and flattened
 // into the list of "entries" the inner loop consumes (see stencil_accumulate).  One entry =
-// one input-row step m x one 4-tap chunk c; the entries of a row step are consecutive.  The
-// list ends with two dummy entries so the loop can always prefetch ahead.
+// one input-row step m x one 4-tap chunk c; the entries of a row step are consecutive.  Row
+// steps are grouped into PHASES: a phase keeps only the input rows its row steps touch in LDS,
+// so the LDS footprint (and with it the number of resident workgroups) is a tuning knob that
+// does not depend on the stencil height.  The list ends with two dummy entries so the loop can
+// always prefetch ahead.
 struct DevStencil {
     const float* wstream;  // per entry: 4*Q floats  w[t][q] = K[m-q][4c+t]  (0 outside the taps)
-    const int* offs;       // per entry: LDS float offset m*RS + 4c
+    const int* offs;       // per entry: LDS float offset (m - m0(phase))*RS + 4c
     const int* rowcnt;     // per non-empty row step: number of entries (>= 1)
-    int n_rows;
+    const int* phases;     // per phase 4 ints: {m0, lds_rows, first row step (index into rowcnt), first entry}
+                           // + one terminator {., ., n_rowsteps, n_entries}
+    int n_phases;
+    int n_rowsteps;        // total non-empty row steps
     int kh, kw;            // cropped taps
     int kw_pad;            // kw rounded up to a multiple of 4
     int ay, ax;            // anchor inside the cropped box
     int RS;                // LDS row stride (floats) the offsets were built for
+    int max_lds_rows;      // largest lds_rows over the phases
     int wmul;              // 1; 0 = profiling aid (every entry reads entry 0's weights -> scalar-cache hits)
 };
 
@@ -313,13 +320,14 @@ __device__ __forceinline__ void wait_operands(const typename WVec<4 * Q>::type& 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// (Tried and dropped: touching the scalar-cache line of entry e+4 with a one-dword s_load.  Any
+// use of a scalar load forces lgkmcnt(0), which also waits for the touch, so it cannot fly ahead.)
 // One pipeline step: wait for the current entry's operands, request the next entry's
 // (into the other register set), then issue the current entry's FMAs.
 template <int Q, bool FIRST>
 __device__ __forceinline__ void entry_step(const float* lds, const int R2F_CONSTANT* offs,
                                            const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e, int& off1,
-                                           const typename WVec<4 * Q>::type& cw, const float4v& ca, const float4v& cb,
-                                           typename WVec<4 * Q>::type& nw, float4v& na, float4v& nb,
+                                           const typename WVec<4 * Q>::type& cw, const float4v& ca, const float4v& cb, typename WVec<4 * Q>::type& nw, float4v& na, float4v& nb,
                                            float2v (&part)[Q / 2][4]) {
     wait_operands<Q>(cw, ca, cb);
     const int off2 = offs[e + 2];
@@ -332,28 +340,29 @@ __device__ __forceinline__ void entry_step(const float* lds, const int R2F_CONST
     ++e;
 }
 
+// Accumulate the row steps [row_begin, row_end) of one phase, whose first entry is e0.
 template <int Q>
-__device__ __forceinline__ void stencil_accumulate(const float* lds, const DevStencil& st, float2v (&acc)[Q / 2][4]) {
+__device__ __forceinline__ void stencil_accumulate(const float* lds, const DevStencil& st, int row_begin, int row_end,
+                                                   int e0, float2v (&acc)[Q / 2][4]) {
     static_assert(Q == 2 || Q == 4, "Q must be 2 or 4");
     typedef typename WVec<4 * Q>::type wvec;
     const int R2F_CONSTANT* offs = (const int R2F_CONSTANT*)st.offs;
     const int R2F_CONSTANT* rowcnt = (const int R2F_CONSTANT*)st.rowcnt;
     const wvec R2F_CONSTANT* wstream = (const wvec R2F_CONSTANT*)st.wstream;
-    const int n_rows = st.n_rows;
     const int wmul = st.wmul;
     float2v part[Q / 2][4];
 
-    int e = 0;           // flat entry index
-    int off1 = offs[1];  // LDS offset of entry e+1
+    int e = e0;               // flat entry index
+    int off1 = offs[e0 + 1];  // LDS offset of entry e+1
     // two operand sets: A holds the current entry at the top of every row step
-    wvec wA = wstream[0], wB;
+    wvec wA = wstream[e0 * wmul], wB;
     float4v aA, bA, aB, bB;
     {
-        const int off0 = offs[0];
+        const int off0 = offs[e0];
         aA = *reinterpret_cast<const float4v*>(lds + off0);
         bA = *reinterpret_cast<const float4v*>(lds + off0 + 4);
     }
-    for (int r = 0; r < n_rows; ++r) {
+    for (int r = row_begin; r < row_end; ++r) {
         const int cnt = rowcnt[r];
         // first entry of the row step starts the row partial (multiply instead of fma)
         entry_step<Q, true>(lds, offs, wstream, wmul, e, off1, wA, aA, bA, wB, aB, bB, part);

@@ -216,20 +216,40 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 
 // Fill rows x RS floats of an LDS tile from a source plane with BORDER_REFLECT_101 on the
 // global frame.  Tile element (r, c) <-> global (ty0 + r, tx0 + c).  Columns >= cols_valid are
-// zero (they only meet zero padding taps).  One wave per tile row, lanes along x (coalesced).
+// zero (they only meet zero padding taps).  One wave per tile row, lanes along x (coalesced);
+// each lane first issues all its loads for KR rows, then writes them to LDS, so several global
+// round trips are in flight per wave instead of one.
 template <int NT>
 __device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, int cols_valid, const float* src,
                                                   int src_gy0, int src_rows, int W, int H_global, int ty0, int tx0) {
+    constexpr int NW = NT / 64, KR = 4, KC = 4;  // KC * 64 >= RS is required (checked on the host: RS <= 256)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = wave; r < rows; r += NT / 64) {
-        int sy = reflect101(ty0 + r, H_global) - src_gy0;
-        sy = clampi(sy, 0, src_rows - 1);  // only rows feeding discarded outputs can fall outside
-        const float* srow = src + (long long)sy * W;
-        float* drow = lds + r * RS;
-        for (int c = lane; c < RS; c += 64) {
-            float v = 0.f;
-            if (c < cols_valid) v = srow[reflect101(tx0 + c, W)];
-            drow[c] = v;
+    int sx[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) sx[k] = reflect101(tx0 + lane + 64 * k, W);
+    for (int r0 = wave * KR; r0 < rows; r0 += NW * KR) {
+        float v[KR][KC];
+#pragma unroll
+        for (int i = 0; i < KR; ++i) {
+            int sy = reflect101(ty0 + r0 + i, H_global) - src_gy0;
+            sy = clampi(sy, 0, src_rows - 1);  // only rows feeding discarded outputs can fall outside
+            const float* srow = src + (long long)sy * W;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int c = lane + 64 * k;
+                v[i][k] = (c < cols_valid && r0 + i < rows) ? srow[sx[k]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KR; ++i) {
+            if (r0 + i < rows) {
+                float* drow = lds + (r0 + i) * RS;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int c = lane + 64 * k;
+                    if (c < RS) drow[c] = v[i][k];
+                }
+            }
         }
     }
 }
@@ -238,32 +258,40 @@ template <int BX, int BY, int Q>
 __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = BX * BY, TW = 4 * BX, TH = Q * BY;
-    int bx = blockIdx.x, by = blockIdx.y, ch = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y;
+    const int ch = blockIdx.z;
     if (a.xcd_remap) {
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        int id = xcd_remap(bx + gridDim.x * (by + gridDim.y * ch), nwg);
+        // remap inside the channel's own 2-D tile grid: channels differ wildly in cost (the blue
+        // halation plane is the identity), so a remap across channels would unbalance the XCDs
+        const int nwg = gridDim.x * gridDim.y;
+        const int id = xcd_remap(bx + gridDim.x * by, nwg);
         bx = id % gridDim.x;
-        id /= gridDim.x;
-        by = id % gridDim.y;
-        ch = id / gridDim.y;
+        by = id / gridDim.x;
     }
     const DevStencil st = a.st[ch];
     const int tile_x0 = bx * TW, tile_y0 = a.y0 + by * TH;
     const int RS = st.RS;
-    const int rows = TH + st.kh - 1;
     const float* src = a.src.data + (long long)ch * a.src.plane_stride;
-    if (a.ablate != 1)
-        fill_tile_reflect<NT>(smem, RS, rows, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global,
-                              tile_y0 - st.ay, tile_x0 - st.ax);
-    __syncthreads();
-
     const int tx = threadIdx.x % BX, ty = threadIdx.x / BX;
+    const float* lds_lane = smem + ty * Q * RS + 4 * tx;
     float2v acc[Q / 2][4];
 #pragma unroll
     for (int j = 0; j < Q / 2; ++j)
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[j][p] = (float2v){0.f, 0.f};
-    if (a.ablate != 2) stencil_accumulate<Q>(smem + ty * Q * RS + 4 * tx, st, acc);
+
+    const int R2F_CONSTANT* phases = (const int R2F_CONSTANT*)st.phases;
+    for (int ph = 0; ph < st.n_phases; ++ph) {
+        const int m0 = phases[4 * ph], lds_rows = phases[4 * ph + 1];
+        const int row_begin = phases[4 * ph + 2], e0 = phases[4 * ph + 3];
+        const int row_end = phases[4 * ph + 6];
+        if (ph > 0) __syncthreads();  // all lanes are done reading the previous phase's rows
+        if (a.ablate != 1)
+            fill_tile_reflect<NT>(smem, RS, lds_rows, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global,
+                                  tile_y0 - st.ay + m0, tile_x0 - st.ax);
+        __syncthreads();
+        if (a.ablate != 2) stencil_accumulate<Q>(lds_lane, st, row_begin, row_end, e0, acc);
+    }
 
     const int gx = tile_x0 + 4 * tx;
     if (gx >= a.W) return;
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 #pragma unroll
             for (int p = 0; p < 4; ++p) G[c][j][p] = (float2v){0.f, 0.f};
         const float* plane = smem + (mono ? 0 : c * plane_sz);
-        stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], G[c]);
+        stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
     }
 
     const int gx = tile_x0 + 4 * tx;
@@ -378,14 +406,14 @@ __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan) {
     size_t best = 0;
     for (int c = 0; c < nchan; ++c) {
-        size_t b = ((size_t)(v.TW() + st[c].kw_pad) * (size_t)(v.TH() + st[c].kh - 1) + 16) * sizeof(float);
+        size_t b = ((size_t)st[c].RS * (size_t)st[c].max_lds_rows + 16) * sizeof(float);
         if (b > best) best = b;
     }
     return best;
 }
 
 size_t tail_lds_bytes(const DevStencil* gk, int mono) {
-    const size_t plane = (size_t)(4 * kTailBX + gk[0].kw_pad) * (size_t)(kTailQ * kTailBY + gk[0].kh - 1) + 16;
+    const size_t plane = (size_t)gk[0].RS * (size_t)gk[0].max_lds_rows + 16;
     return plane * (mono ? 1 : 3) * sizeof(float);
 }
 

@@ -16,6 +16,7 @@ ap.add_argument("--w", type=int, default=12288)
 ap.add_argument("--h", type=int, default=8192)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--variants", type=str, default="0,1")
+ap.add_argument("--lds-kb", dest="lds_kb", type=str, default="160,80,53,40")
 args = ap.parse_args()
 
 H, W = args.h, args.w
@@ -58,15 +59,21 @@ print(f"front->D        {t[0]:8.3f} ms  ({24*H*W/t[0]/1e6:.0f} GB/s)")
 p0 = ctx.make_params(matrix=True)
 t = timeit(lambda: ctx.stage_front(img, p0, 2, out_f32=out))
 print(f"front->out      {t[0]:8.3f} ms  ({24*H*W/t[0]/1e6:.0f} GB/s)")
+ctx.set_option("xcd_remap", 0)
 for v in [int(x) for x in args.variants.split(",")]:
     ctx.set_option("stencil_variant", v)
-    for remap in (1, 0):
-        ctx.set_option("xcd_remap", remap)
-        t = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
-        print(f"halation v{v} remap{remap} {t[0]:8.3f} ms")
-    t = timeit(lambda: ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H))
-    print(f"mtf      v{v}        {t[0]:8.3f} ms")
-ctx.set_option("xcd_remap", 0)
+    for kb in [int(x) for x in args.lds_kb.split(",")]:
+        ctx.set_option("stencil_lds_kb", kb)
+        try:
+            t = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
+        except Exception as ex:
+            t = (float("nan"),)
+        try:
+            t2 = timeit(lambda: ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H))
+        except Exception as ex:
+            t2 = (float("nan"),)
+        print(f"v{v} lds {kb:3d} KB: halation {t[0]:8.3f} ms   mtf {t2[0]:8.3f} ms")
+ctx.set_option("stencil_lds_kb", 80)
 for v in [int(x) for x in args.variants.split(",")]:
     ctx.set_option("stencil_variant", v)
     for ab in (1, 2, 3):
@@ -76,6 +83,8 @@ for v in [int(x) for x in args.variants.split(",")]:
 ctx.set_option("stencil_ablate", 0)
 ctx.set_option("stencil_variant", -1)
 ctx.set_option("xcd_remap", 1)
+t = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
+print(f"halation auto, xcd remap on {t[0]:8.3f} ms")
 t = timeit(lambda: ctx.stage_tail(D2, params, out_f32=out, y0=0, y1=H, H_global=H))
 print(f"tail(grain)     {t[0]:8.3f} ms")
 pn = ctx.make_params(matrix=True, halation=True, mtf=True)
