@@ -1,0 +1,245 @@
+"""Multi-GPU layers over the single-GPU path (nothing like them exists upstream).
+
+RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GPU
+    (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+    Pixels are independent except for the two stencils, so a frame costs two neighbour
+    exchanges and no reduction:
+        S0+S1 on own rows -> exposure E            exchange r_h rows of E  (halation halo)
+        S2+S3+S4 on own rows -> density D          exchange r_m rows of D  (MTF halo)
+        S5 -> S6 (hash noise at GLOBAL coordinates, no exchange) -> S8 -> own output rows
+    Each exchange is one send + one receive per neighbour, batched (`batch_isend_irecv`, i.e.
+    ncclGroupStart/End): at 100 MP that is 43 / 17 rows x 12288 px x 3 planes x 4 B = 6.3 / 2.5 MB
+    per direction -- latency-bound, every pair on its own xGMI link.  Global top/bottom edges are
+    reflected (BORDER_REFLECT_101) inside the kernels.  Because every stage accumulates taps in a
+    tile-independent order, the sharded result is bit-identical to the single-GPU result.
+
+BatchSharder -- MANY frames (batch export, gui.py:2393-2514): frame i -> rank i mod world, no
+    collectives; per rank a producer thread runs the host phase (`extract_image_data_cpu`) one
+    frame ahead of the device phase (`process_preloaded`) through a depth-1 queue, and a frame
+    whose host phase fails is skipped -- the semantics of GpuWorker.run_tasks (gui_objects.py:65-115).
+
+The compute itself is behind a small backend protocol so that the exchange logic can be tested
+on CPU tensors (tests/test_sharding_cpu.py); `HipStageBackend` is the product backend.
+"""
+
+from __future__ import annotations
+
+import queue
+import threading
+from dataclasses import dataclass
+
+
+def shard_rows(H: int, world: int) -> list[tuple[int, int]]:
+    """Contiguous row ranges [(r0, r1)] per rank, sizes differing by at most one row."""
+    base, extra = divmod(H, world)
+    out, r = [], 0
+    for k in range(world):
+        n = base + (1 if k < extra else 0)
+        out.append((r, r + n))
+        r += n
+    return out
+
+
+@dataclass
+class ShardPlan:
+    H: int
+    W: int
+    rank: int
+    world: int
+    r0: int
+    r1: int
+    halo_e: tuple[int, int]  # (above, below) exposure halo rows needed by the halation stencil
+    halo_d: tuple[int, int]  # (above, below) density halo rows needed by the MTF stencil
+
+    @property
+    def rows(self) -> int:
+        return self.r1 - self.r0
+
+
+class HipStageBackend:
+    """Stage calls of one GPU's HipContext on (3, rows, W) float32 CUDA tensors."""
+
+    def __init__(self, ctx, params, halation_taps=(0, 0), mtf_taps=(0, 0)):
+        import torch
+
+        self.torch = torch
+        self.ctx = ctx
+        self.params = params
+        self.halation_taps = halation_taps  # (rows above, rows below) the stencil reaches
+        self.mtf_taps = mtf_taps
+        self.device = ctx.device
+
+    def empty(self, rows, W):
+        return self.torch.empty((3, rows, W), dtype=self.torch.float32, device=self.device)
+
+    def front(self, image_rows, in_gy0, upto, dst, dst_gy0, y0, y1, H):
+        self.ctx.stage_front(image_rows, self.params, upto, in_gy0=in_gy0, dst=dst, dst_gy0=dst_gy0, y0=y0, y1=y1, H_global=H)
+
+    def halation(self, E, e_gy0, D, d_gy0, y0, y1, H):
+        self.ctx.stage_halation(E, D, self.params, src_gy0=e_gy0, dst_gy0=d_gy0, y0=y0, y1=y1, H_global=H)
+
+    def mtf(self, D, d_gy0, D2, d2_gy0, y0, y1, H):
+        self.ctx.stage_mtf(D, D2, self.params, src_gy0=d_gy0, dst_gy0=d2_gy0, y0=y0, y1=y1, H_global=H)
+
+    def tail(self, D, d_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
+        self.ctx.stage_tail(D, self.params, src_gy0=d_gy0, out_f32=out_f32, out_u8=out_u8, out_gy0=out_gy0, y0=y0, y1=y1, H_global=H)
+
+    def front_to_output(self, image_rows, in_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
+        self.ctx.stage_front(image_rows, self.params, 2, in_gy0=in_gy0, out_f32=out_f32, out_u8=out_u8, out_gy0=out_gy0,
+                             y0=y0, y1=y1, H_global=H)
+
+
+class RowShardedRenderer:
+    """Render one H x W frame whose rows are sharded over the ranks of a process group.
+
+    backend:   object with empty/front/halation/mtf/tail/front_to_output (see HipStageBackend)
+    halation / mtf / grain: which stages are enabled (the stage gates of cpu_processor.py:368,382,387)
+    """
+
+    def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, group=None, rank=None, world=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.backend = backend
+        self.group = group
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        r0, r1 = shard_rows(H, world)[rank]
+        ha, hb = backend.halation_taps if halation else (0, 0)
+        ma, mb = backend.mtf_taps if mtf else (0, 0)
+        self.halation, self.mtf = halation, mtf
+        self.plan = ShardPlan(H, W, rank, world, r0, r1, (ha, hb), (ma, mb))
+        smallest = min(b - a for a, b in shard_rows(H, world))
+        need = max(ha, hb, ma, mb)
+        if world > 1 and smallest < need:
+            raise ValueError(
+                f"row shards of {smallest} rows are shorter than the {need}-row stencil halo; use fewer ranks for this frame"
+            )
+        p = self.plan
+        # extended planes: own rows plus the halo rows that exist inside the frame
+        self.e_lo, self.e_hi = max(p.r0 - ha, 0), min(p.r1 + hb, H)
+        self.d_lo, self.d_hi = max(p.r0 - ma, 0), min(p.r1 + mb, H)
+        self.E = backend.empty(self.e_hi - self.e_lo, W) if halation else None
+        self.D = backend.empty(self.d_hi - self.d_lo, W) if (halation or mtf) else None
+        self.D2 = backend.empty(p.rows, W) if mtf else None
+        self.Dplain = backend.empty(p.rows, W) if not (halation or mtf) else None
+
+    # ------------------------------------------------------------------ neighbour exchange
+    def _exchange(self, buf, buf_gy0: int, above: int, below: int):
+        """Fill the halo rows of `buf` (global rows [buf_gy0, ...)) from the neighbours' own rows.
+        Rank k sends its first `below_of_prev` rows up and its last `above_of_next` rows down."""
+        p, dist, torch = self.plan, self.dist, self.torch
+        if p.world == 1 or (above == 0 and below == 0):
+            return
+        ops, recvs = [], []
+        own0 = p.r0 - buf_gy0  # buffer row of the first own row
+        if p.rank > 0:  # neighbour above: it needs my top `below` rows, I need its bottom `above` rows
+            if below:
+                send = buf[:, own0:own0 + below, :].contiguous()
+                ops.append(dist.P2POp(dist.isend, send, self._peer(p.rank - 1), self.group))
+            if above:
+                recv = torch.empty((3, above, p.W), dtype=buf.dtype, device=buf.device)
+                ops.append(dist.P2POp(dist.irecv, recv, self._peer(p.rank - 1), self.group))
+                recvs.append((recv, own0 - above))
+        if p.rank < p.world - 1:  # neighbour below
+            if above:
+                send = buf[:, own0 + p.rows - above:own0 + p.rows, :].contiguous()
+                ops.append(dist.P2POp(dist.isend, send, self._peer(p.rank + 1), self.group))
+            if below:
+                recv = torch.empty((3, below, p.W), dtype=buf.dtype, device=buf.device)
+                ops.append(dist.P2POp(dist.irecv, recv, self._peer(p.rank + 1), self.group))
+                recvs.append((recv, own0 + p.rows))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for recv, row in recvs:
+            buf[:, row:row + recv.shape[1], :].copy_(recv)
+
+    def _peer(self, group_rank: int) -> int:
+        if self.group is None:
+            return group_rank
+        return self.dist.get_global_rank(self.group, group_rank)
+
+    # ------------------------------------------------------------------ one frame
+    def render(self, image_rows, out_f32=None, out_u8=None):
+        """image_rows: this rank's own rows of the decoded frame ((rows, W, 3|4) or (3, rows, W)).
+        out_*: this rank's own rows of the result, (rows, W, 3)."""
+        p, be = self.plan, self.backend
+        H = p.H
+        if not (self.halation or self.mtf):
+            be.front(image_rows, p.r0, 1, self.Dplain, p.r0, p.r0, p.r1, H)
+            be.tail(self.Dplain, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+            return out_f32, out_u8
+        if self.halation:
+            be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
+            self._exchange(self.E, self.e_lo, *p.halo_e)
+            be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
+        else:
+            be.front(image_rows, p.r0, 1, self.D, self.d_lo, p.r0, p.r1, H)
+        if self.mtf:
+            self._exchange(self.D, self.d_lo, *p.halo_d)
+            be.mtf(self.D, self.d_lo, self.D2, p.r0, p.r0, p.r1, H)
+            be.tail(self.D2, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+        else:
+            be.tail(self.D, self.d_lo, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+        return out_f32, out_u8
+
+
+class BatchSharder:
+    """Frame-per-GPU batch export without collectives.
+
+    tasks[i] is handled by rank i % world.  `prepare(task)` is the host phase (decode / load,
+    `HipProcessor.extract_image_data_cpu`), `execute(task, payload)` the device phase
+    (`HipProcessor.process_preloaded` + export).  One producer thread keeps the host phase one
+    frame ahead of the device phase through a `Queue(maxsize=1)`; a frame whose host phase raises
+    is skipped and the batch continues (gui_objects.py:86-87,101-103); `cancel()` stops both sides.
+    """
+
+    def __init__(self, rank: int = 0, world: int = 1):
+        self.rank, self.world = rank, world
+        self._cancel = threading.Event()
+
+    def my_tasks(self, tasks):
+        return [(i, t) for i, t in enumerate(tasks) if i % self.world == self.rank]
+
+    def cancel(self):
+        self._cancel.set()
+
+    def run(self, tasks, prepare, execute, progress=None):
+        mine = self.my_tasks(tasks)
+        q: queue.Queue = queue.Queue(maxsize=1)
+        results, skipped = {}, []
+
+        def producer():
+            for idx, task in mine:
+                if self._cancel.is_set():
+                    break
+                try:
+                    payload = prepare(task)
+                except Exception:  # noqa: BLE001 -- same "skip the frame" rule as upstream
+                    payload = None
+                while not self._cancel.is_set():
+                    try:
+                        q.put((idx, task, payload), timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+            q.put((None, None, None))
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        while not self._cancel.is_set():
+            idx, task, payload = q.get()
+            if idx is None:
+                break
+            if payload is None:
+                skipped.append(idx)
+                continue
+            results[idx] = execute(task, payload)
+            if progress is not None:
+                progress(idx, len(mine))
+        th.join(timeout=1.0)
+        return results, skipped

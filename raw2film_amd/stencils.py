@@ -84,3 +84,16 @@ def mtf_stencil_from_table(mtf, scale: float, sharpening_strength: float = 0.0, 
 @lru_cache(maxsize=50)  # same cache shape as effects.py:165
 def mtf_stencil(stock, scale: float, sharpening_strength: float = 0.0, sharpening_sigma: float = 1.0) -> np.ndarray:
     return mtf_stencil_from_table(stock.mtf, scale, sharpening_strength, sharpening_sigma)
+
+
+def vertical_reach(stencil: np.ndarray) -> tuple[int, int]:
+    """(rows above, rows below) the anchor that hold a non-zero tap in any channel: the halo a
+    row shard needs for this stencil (anchor = kh // 2, as cv.filter2D / convolution.wgsl:31)."""
+    k = np.asarray(stencil)
+    if k.ndim == 2:
+        k = k[..., None]
+    rows = np.nonzero(np.any(k != 0, axis=(1, 2)))[0]
+    if rows.size == 0:
+        return 0, 0
+    anchor = k.shape[0] // 2
+    return max(anchor - int(rows[0]), 0), max(int(rows[-1]) - anchor, 0)

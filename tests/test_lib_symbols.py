@@ -1,0 +1,45 @@
+"""The C-ABI library builds, loads without a GPU, and exports every symbol include/r2f.h declares."""
+
+import ctypes
+import os
+import re
+
+from raw2film_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "r2f.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(r2f_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m raw2film_amd.build` (the driver's build() does)"
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert getattr(raw, name) is not None
+    assert b"gfx950" in lib.r2f_version()
+
+
+def test_struct_layouts_match_the_header():
+    # r2f_params: 2 x u32, 2 x f32, 2 x i32 ; r2f_planes: ptr, i64, 2 x i32
+    assert ctypes.sizeof(_lib.Params) == 24
+    assert ctypes.sizeof(_lib.Planes) == 24
+    assert _lib.Planes.plane_stride.offset == 8 and _lib.Planes.gy0.offset == 16
+
+
+def test_workspace_bytes_needs_no_gpu():
+    lib = _lib.load()
+    p = _lib.Params(_lib.F_HALATION | _lib.F_MTF | _lib.F_GRAIN, 1, 1e-6, 0.25, 0, 0)
+    assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 2 * 3 * 100 * 200 * 4
+    p.flags = _lib.F_GRAIN
+    assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 3 * 100 * 200 * 4
+    p.flags = 0
+    assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 0

@@ -1,0 +1,169 @@
+"""Host logic of the HipProcessor operator surface, with the device context replaced by a recorder
+(no GPU needed): keyword surface, stage gating, upload caching, out-of-scope errors, settings merge."""
+
+import inspect
+
+import numpy as np
+import pytest
+
+from raw2film_amd import _lib, filmstock, settings
+from raw2film_amd.hip_processor import REC709_TO_XYZ, HipProcessor
+
+REFERENCE_PROCESS_KWARGS = [  # cpu_processor.py:269-322 (+ dst_texture/histogram_texture of gpu_processor.py:1547-1548)
+    "lens_correction", "print_film", "exp_comp", "red_light", "green_light", "blue_light", "projector_kelvin",
+    "shadow_comp", "sat_adjust", "gamma_func", "exp_kelvin", "tint", "inversion_gamma", "idealized_curve", "inversion",
+    "push_pull", "white_balance", "white_clip", "icc_transform", "resolution", "frame_width", "frame_height", "rotation",
+    "zoom", "rotate_times", "flip", "cam", "lens", "canvas_mode", "canvas_scale", "canvas_ratio", "halation_intensity",
+    "halation", "halation_size", "halation_green_factor", "sharpness", "sharpening_strength", "sharpening_sigma",
+    "chroma_nr", "grain", "highlight_burn", "burn_scale", "half_size", "cache", "color_masking", "max_scale",
+]
+REFERENCE_DEFAULTS = dict(lens_correction=True, print_film=None, exp_comp=0.0, projector_kelvin=6500, sat_adjust=1.0,
+                          gamma_func="sRGB", exp_kelvin=6500, inversion_gamma=4.0, frame_width=36, frame_height=24,
+                          halation=True, halation_size=1.0, halation_green_factor=0.4, sharpness=True, grain=2,
+                          half_size=True, cache=True, color_masking=None, max_scale=400.0, burn_scale=50.0)
+
+
+class RecorderContext:
+    def __init__(self):
+        self.calls = []
+        self.device = "fake"
+
+    def __getattr__(self, name):
+        if name.startswith("set_"):
+            return lambda *a, **k: self.calls.append(name)
+        raise AttributeError(name)
+
+    def make_params(self, **kw):
+        self.calls.append(("params", kw))
+        return kw
+
+    def layout_of(self, image):
+        return 0, image.shape[0], image.shape[1]
+
+    def render(self, image, params, want_f32=False, want_u8=True):
+        self.calls.append("render")
+        return None, np.zeros(image.shape[:2] + (3,), np.uint8)
+
+
+@pytest.fixture
+def proc():
+    p = HipProcessor.__new__(HipProcessor)
+    p.ctx = RecorderContext()
+    p.device = "fake"
+    p.cameras = p.lenses = None
+    for name in ("input", "curve", "output", "halation", "mtf", "grain_kernel", "grain_lut"):
+        setattr(p, f"{name}_param_dict", None)
+    p.matrix_key = None
+    p.uploads = 0
+    return p
+
+
+def test_process_keeps_the_reference_keyword_surface():
+    sig = inspect.signature(HipProcessor.process)
+    names = list(sig.parameters)
+    assert names[:5] == ["self", "src", "negative_film", "grain_size", "grain_sigma"]
+    for kw in REFERENCE_PROCESS_KWARGS:
+        assert kw in sig.parameters, kw
+    for kw, default in REFERENCE_DEFAULTS.items():
+        assert sig.parameters[kw].default == default, kw
+    assert any(p.kind is inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())  # **_ swallows GUI extras
+
+
+def test_stage_gating_and_upload_caching(proc):
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    params = proc.prepare(neg, 6, 0.4, (600, 400), print_film=prt, seed=5, matrix=REC709_TO_XYZ, profile="x", film_format="135")
+    assert params["halation"] and params["mtf"] and params["grain"] and not params["grain_mono"] and params["seed"] == 5
+    first = proc.uploads
+    assert first == 7  # 2-D LUT, curve, 3-D LUT, halation, MTF, grain LUT, grain kernel
+    proc.prepare(neg, 6, 0.4, (600, 400), print_film=prt, seed=6, matrix=REC709_TO_XYZ)
+    assert proc.uploads == first  # nothing changed -> nothing re-uploaded (cpu_processor.py:157-158 convention)
+    proc.prepare(neg, 6, 0.4, (600, 400), print_film=prt, exp_comp=0.5)
+    assert proc.uploads == first + 1  # only the input LUT depends on exp_comp
+    proc.prepare(neg, 6, 0.4, (1200, 800), print_film=prt, exp_comp=0.5)
+    assert proc.uploads == first + 1 + 4  # new px/mm: halation, MTF, grain LUT, grain kernel
+    p2 = proc.prepare(neg, 6, 0.4, (600, 400), print_film=prt, halation=False, sharpness=False, grain=1)
+    assert not p2["halation"] and not p2["mtf"] and p2["grain"] and p2["grain_mono"]
+    p3 = proc.prepare(prt, 6, 0.4, (600, 400))  # print stock: no MTF table, no granularity -> stages off
+    assert not p3["mtf"] and not p3["grain"]
+
+
+def test_bw_stock_sets_equal_halation_factors(proc, monkeypatch):
+    from raw2film_amd import stencils
+
+    seen = {}
+    real = stencils.halation_stencil
+    monkeypatch.setattr(stencils, "halation_stencil", lambda *a, **k: seen.update(k) or real(*a, **k))
+    bw = filmstock.builtin_stocks()["Kodak Tri-X 400"]
+    proc.prepare(bw, 6, 0.4, (600, 400))
+    assert seen["bw"] is True
+
+
+def test_random_seed_when_not_given(proc):
+    neg = filmstock.builtin_stocks()["Kodak Portra 400"]
+    seeds = {proc.prepare(neg, 6, 0.4, (60, 40))["seed"] for _ in range(4)}
+    assert len(seeds) > 1  # upstream draws a new seed every render (gpu_processor.py:591)
+
+
+def test_out_of_scope_requests_raise(proc):
+    neg = filmstock.builtin_stocks()["Kodak Portra 400"]
+    img = np.zeros((40, 60, 3), np.float32)
+    with pytest.raises(NotImplementedError):
+        proc.process("photo.cr3", neg, 6, 0.4)
+    with pytest.raises(NotImplementedError):
+        proc.extract_image_data_cpu(img, rotation=3.0)
+    with pytest.raises(NotImplementedError):
+        proc.extract_image_data_cpu(img, frame_width=0.1, frame_height=0.07)  # finer than max_scale
+    with pytest.raises(NotImplementedError):
+        proc.prepare(neg, 6, 0.4, (60, 40), highlight_burn=0.5)
+    with pytest.raises(NotImplementedError):
+        proc.process(img, neg, 6, 0.4, dst_texture=object())
+
+
+def test_extract_image_data_cpu_payload(proc):
+    img = np.full((40, 60, 3), 70000.0, np.float32)
+    payload = proc.extract_image_data_cpu(img)
+    assert payload["image_array"].shape == (40, 60, 4) and payload["image_array"].dtype == np.float32
+    assert payload["image_array"][..., :3].max() == 65504.0 and np.all(payload["image_array"][..., 3] == 1.0)
+    assert payload["output_resolution"] == (60, 40) and payload["pipeline_resolution"] == (60, 40)
+    assert payload["canvas_resolution"] is None
+
+
+def test_settings_merge_and_preview_gating():
+    stocks = filmstock.builtin_stocks()
+    args = settings.build_processing_params(stocks, image_params={"exp_comp": 1.0}, profile_params={"grain_size": 9})
+    assert args["negative_film"] is stocks["Kodak Portra 400"] and args["print_film"] is stocks["Fuji Crystal Archive Maxima"]
+    assert args["exp_comp"] == 1.0 and args["grain_size"] == 9 and args["halation_green_factor"] == 0.3
+    assert args["exp_kelvin"] == 6000 and args["color_masking"] == 1.0
+    quick = settings.build_processing_params(stocks, full_preview=False)
+    assert quick["sharpness"] is False and quick["grain"] == 0 and quick["halation"] is False
+    inv = settings.build_processing_params(stocks, profile_params={"print_film": "Inversion"})
+    assert inv["inversion"] is True and inv["print_film"] is None
+    assert settings.FORMATS["135"] == (36, 24)
+
+
+def test_synthetic_stock_lut_shapes():
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    assert neg.get_input_lut(6000, 0, 0).shape == (64, 64, 3)
+    c = neg.get_density_curve(0.0, 1.0)
+    assert c.shape == (4, 1024) and np.all(np.diff(c[0]) > 0) and np.all(np.diff(c[1:], axis=1) >= 0)
+    assert neg.get_grain_curve(341.33).shape == (4, 256)
+    lut = filmstock.create_lut(neg, prt)
+    assert lut.shape == (33, 33, 33, 3) and lut.min() >= 0 and lut.max() <= 1
+    assert filmstock.grain_kernel(1 / 341.33).shape == (9, 9) and filmstock.grain_kernel(1 / 14.22) is None
+    assert prt.mtf is None and prt.rms_density is None and len(neg.mtf) == 3
+    assert hash(neg) is not None and _lib.F_GRAIN == 8
+
+
+def test_bundle_roundtrip(tmp_path):
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    path = str(tmp_path / "portra.npz")
+    filmstock.save_bundle(path, lut_2d=neg.get_input_lut(), lut_1d=neg.get_density_curve(), lut_3d=filmstock.create_lut(neg, prt),
+                          grain_lut=neg.get_grain_curve(100.0), rms_density=neg.rms_density, d_ref=np.array(neg.d_ref),
+                          mtf_logf=np.stack([m[0] for m in neg.mtf]), mtf_vals=np.stack([m[1] for m in neg.mtf]))
+    b = filmstock.load_bundle(path, "portra-bundle")
+    np.testing.assert_array_equal(b.get_input_lut(6500, 0, 0), neg.get_input_lut())
+    np.testing.assert_array_equal(filmstock.create_lut(b, None), filmstock.create_lut(neg, prt))
+    assert len(b.mtf) == 3 and b.rms_density is not None and b.name == "portra-bundle"

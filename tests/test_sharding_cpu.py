@@ -1,0 +1,195 @@
+"""Row-sharded rendering and batch sharding, exercised on CPU: 2 processes, gloo backend.
+The exchange logic of raw2film_amd.sharding is compute-agnostic; here the stage backend is the
+NumPy oracle (tests may use it), so the test checks halo bookkeeping, reflect handling at the
+global edges and the neighbour exchange -- not the HIP kernels (tests/test_gpu_parity.py does)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import stages as st
+from raw2film_amd import sharding, stencils
+
+from helpers import SEED, oracle_inputs, stocks, synthetic_frame
+
+
+class OracleStageBackend:
+    """Same protocol as sharding.HipStageBackend, on CPU tensors, computed by the oracle."""
+
+    def __init__(self, p: st.RenderInputs):
+        self.p = p
+        self.halation_taps = stencils.vertical_reach(p.halation_kernel) if p.halation_kernel is not None else (0, 0)
+        self.mtf_taps = stencils.vertical_reach(p.mtf_kernel) if p.mtf_kernel is not None else (0, 0)
+
+    def empty(self, rows, W):
+        return torch.full((3, rows, W), float("nan"), dtype=torch.float32)
+
+    @staticmethod
+    def _hwc(t):
+        return t.numpy() if t.shape[-1] in (3, 4) else np.transpose(t.numpy(), (1, 2, 0))
+
+    def _front(self, image_rows, in_gy0, upto, y0, y1):
+        x = self._hwc(image_rows)[y0 - in_gy0:y1 - in_gy0, :, :3]
+        if self.p.matrix is not None:
+            x = st.apply_matrix3x3(x, self.p.matrix)
+        x = st.apply_2d_lut(x, self.p.lut_2d)
+        if upto >= 1:
+            x = st.multi_channel_interp(st.log_clip(x), self.p.lut_1d)
+        return x
+
+    def front(self, image_rows, in_gy0, upto, dst, dst_gy0, y0, y1, H):
+        x = self._front(image_rows, in_gy0, upto, y0, y1)
+        dst[:, y0 - dst_gy0:y1 - dst_gy0, :] = torch.from_numpy(np.transpose(x, (2, 0, 1)).copy())
+
+    @staticmethod
+    def _stencil(src, src_gy0, kernel, y0, y1, H):
+        above, below = kernel.shape[0] // 2, kernel.shape[0] - 1 - kernel.shape[0] // 2
+        rows = np.arange(y0 - above, y1 + below)
+        period = max(2 * H - 2, 1)
+        rows = np.abs(((rows % period) + period) % period)
+        rows = np.where(rows >= H, period - rows, rows)  # reflect-101 on the global frame
+        used = kernel.any(axis=(1, 2))
+        lo, hi = np.nonzero(used)[0][[0, -1]]
+        need = rows[lo:len(rows) - (kernel.shape[0] - 1 - hi)]
+        assert need.min() >= src_gy0 and need.max() < src_gy0 + src.shape[1], "halo rows missing"
+        idx = np.clip(rows - src_gy0, 0, src.shape[1] - 1)
+        gathered = np.transpose(src.numpy()[:, idx, :], (1, 2, 0))
+        assert not np.isnan(gathered[lo:len(rows) - (kernel.shape[0] - 1 - hi)]).any(), "halo rows were never filled"
+        gathered = np.nan_to_num(gathered)
+        full = st.convolve_2d(gathered, kernel)
+        return full[above:above + (y1 - y0)]
+
+    def halation(self, E, e_gy0, D, d_gy0, y0, y1, H):
+        x = self._stencil(E, e_gy0, self.p.halation_kernel, y0, y1, H)
+        x = st.multi_channel_interp(st.log_clip(x), self.p.lut_1d)
+        D[:, y0 - d_gy0:y1 - d_gy0, :] = torch.from_numpy(np.transpose(x, (2, 0, 1)).copy())
+
+    def mtf(self, D, d_gy0, D2, d2_gy0, y0, y1, H):
+        x = self._stencil(D, d_gy0, self.p.mtf_kernel, y0, y1, H)
+        D2[:, y0 - d2_gy0:y1 - d2_gy0, :] = torch.from_numpy(np.transpose(x, (2, 0, 1)).copy())
+
+    def tail(self, D, d_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
+        x = np.transpose(D.numpy()[:, y0 - d_gy0:y1 - d_gy0, :], (1, 2, 0))
+        if self.p.grain_lut is not None:
+            gk = self.p.grain_kernel if self.p.grain_kernel is not None else np.ones((1, 1), np.float32)
+            x = st.apply_grain(x, self.p.grain_lut, gk, self.p.seed, self.p.grain_mono, row0=y0, H_global=H)
+        x = st.apply_lut_tetrahedral(x, self.p.lut_3d, 0.25)
+        out_f32[y0 - out_gy0:y1 - out_gy0] = torch.from_numpy(x)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _inputs(H, W, scale, **kw):
+    neg, prt, _ = stocks()
+    return oracle_inputs(neg, prt, scale, seed=SEED, **kw), synthetic_frame(H, W, seed=5)
+
+
+def _worker(rank, world, port, H, W, scale, flags, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p, img = _inputs(H, W, scale, **flags)
+        be = OracleStageBackend(p)
+        rr = sharding.RowShardedRenderer(be, H, W, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None)
+        r0, r1 = rr.plan.r0, rr.plan.r1
+        out = torch.zeros((r1 - r0, W, 3), dtype=torch.float32)
+        rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
+        gathered = [torch.zeros((b - a, W, 3), dtype=torch.float32) for a, b in sharding.shard_rows(H, world)]
+        if world > 1:
+            # shards may differ by one row: gather through a padded buffer
+            rows_max = max(t.shape[0] for t in gathered)
+            pad = torch.zeros((rows_max, W, 3), dtype=torch.float32)
+            pad[: out.shape[0]] = out
+            bufs = [torch.zeros_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad)
+            gathered = [b[: g.shape[0]] for b, g in zip(bufs, gathered)]
+        else:
+            gathered = [out]
+        if rank == 0:
+            np.save(result_path, torch.cat(gathered).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize(
+    "H,W,scale,flags",
+    [
+        (97, 64, 120.0, dict()),  # halation + MTF + grain, odd split (49 / 48 rows)
+        (64, 48, 100.0, dict(mtf=False)),
+        (64, 48, 160.0, dict(halation=False, grain=0)),
+        (40, 32, 60.0, dict(halation=False, mtf=False)),
+    ],
+)
+def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
+    world = 2
+    path = str(tmp_path / "out.npy")
+    mp.spawn(_worker, args=(world, _free_port(), H, W, scale, flags, path), nprocs=world, join=True)
+    got = np.load(path)
+    p, img = _inputs(H, W, scale, **flags)
+    ref = st.render(img, p)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_shard_rows_partition():
+    for H in (1, 7, 8192, 8191):
+        for world in (1, 2, 3, 8):
+            parts = sharding.shard_rows(H, world)
+            assert parts[0][0] == 0 and parts[-1][1] == H
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shards_shorter_than_halo_are_rejected():
+    p, _ = _inputs(32, 32, 341.33)  # 87-tap halation: 42-row halo
+    be = OracleStageBackend(p)
+    with pytest.raises(ValueError, match="shorter than"):
+        sharding.RowShardedRenderer(be, 32, 32, halation=True, mtf=True, rank=0, world=2)
+
+
+def test_batch_sharder_round_robin_skip_and_order():
+    tasks = [f"frame{i}" for i in range(11)]
+    seen = {}
+    for rank in range(4):
+        bs = sharding.BatchSharder(rank, 4)
+
+        def prepare(t):
+            if t == "frame5":
+                raise RuntimeError("decode failed")
+            return t.upper()
+
+        results, skipped = bs.run(tasks, prepare, lambda t, payload: (t, payload))
+        for i, r in results.items():
+            assert i % 4 == rank and r == (tasks[i], tasks[i].upper())
+            seen[i] = rank
+        assert all(i % 4 == rank for i in skipped)
+        if rank == 1:
+            assert skipped == [5]
+    assert sorted(seen) == [i for i in range(11) if i != 5]
+
+
+def test_batch_sharder_cancel():
+    bs = sharding.BatchSharder(0, 1)
+    done = []
+
+    def execute(t, payload):
+        done.append(t)
+        if len(done) == 2:
+            bs.cancel()
+        return t
+
+    bs.run(list(range(100)), lambda t: t, execute)
+    assert 2 <= len(done) < 100
