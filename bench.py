@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/s of the full film pipeline (neg + print + grain + halation + MTF).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4_100mp|cfg3_45mp|cfg2_24mp]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (S0..S8, float32 output) over one synthetic decoded frame
+that is already resident in HBM.  N = 1: the whole frame on one MI355X.  N > 1: the SAME frame,
+row-sharded over N GPUs with the two RCCL neighbour exchanges of raw2film_amd.sharding (strong
+scaling: total work fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line (see DESIGN.md "Measurement"):
+  roofline      the dominant kernel (halation stencil), timed live with events on the launch
+                stream inside the timed steps; fp32 VALU bound.
+  roofline_hbm  whole-pipeline algorithmic bytes (12 B/px read + 12 B/px written) vs HBM peak.
+  cpu_baseline  the NumPy oracle ("port") timed on this box's host cores on a bounded sample
+                (rank 0, N = 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak == fp32 (f32-input) MFMA dense peak
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GRAIN_SEED = 20260630
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg4_100mp", choices=["cfg4_100mp", "cfg3_45mp", "cfg2_24mp"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raw2film_amd import HipProcessor, filmstock, stencils
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+    from raw2film_amd.synthetic import CONFIGS, synthetic_frame_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+
+    W, H = CONFIGS[args.config]
+    effects = args.config != "cfg2_24mp"  # config 2 = negative + print LUTs only
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    settings = dict(print_film=prt, frame_width=36, frame_height=24, exp_kelvin=6000, color_masking=1.0,
+                    halation=effects, halation_size=1.0, halation_green_factor=0.3, halation_intensity=1.0,
+                    sharpness=effects, sharpening_strength=0.0, grain=2 if effects else 0)
+
+    proc = HipProcessor(device=local_rank)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=GRAIN_SEED, matrix=REC709_TO_XYZ, **settings)
+    scale = max(H, W) / 36.0
+    hal_k = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3) if effects else None
+    mtf_k = stencils.mtf_stencil(neg, scale, 0.0, 1.0) if effects else None
+    backend = HipStageBackend(proc.ctx, params,
+                              halation_taps=stencils.vertical_reach(hal_k) if effects else (0, 0),
+                              mtf_taps=stencils.vertical_reach(mtf_k) if effects else (0, 0))
+    renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects)
+    r0, r1 = renderer.plan.r0, renderer.plan.r1
+
+    # this rank's rows of the synthetic frame, resident in HBM before the clock starts
+    frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}")
+    out = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device=frame.device)
+
+    # time the dominant kernel with events on the launch stream, inside the timed steps
+    hal_events = []
+    if effects:
+        real_halation = backend.halation
+
+        def timed_halation(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            real_halation(*a, **k)
+            e1.record()
+            hal_events.append((e0, e1))
+
+        backend.halation = timed_halation
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        renderer.render(frame, out_f32=out)
+    barrier()
+    hal_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        renderer.render(frame, out_f32=out)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=frame.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    mp_per_s = H * W / 1e6 * args.steps / dt
+
+    result = {
+        "metric": "megapixels/sec full film pipeline (neg+print+grain+halation+MTF), 100MP frame",
+        "value": mp_per_s,
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 frame, 36x24 mm, "
+                        + ("full pipeline S0-S8: 3x3 + 2-D LUT + halation 87x87 + log/curve + MTF 35x35 + grain 9x9 + tetrahedral 3-D LUT"
+                           if args.config == "cfg4_100mp" else
+                           ("full pipeline S0-S8" if effects else "LUTs only (S0+S1+S3+S4+S8), effects off"))
+                        + ", fp32 HWC in -> fp32 HWC out",
+            "stocks": "synthetic stand-ins portra400_like + k2383_like (spectral_film_lut data unavailable offline)",
+            "sharding": "single GPU" if world == 1 else f"row-sharded over {world} GPUs, RCCL halo exchange (E: halation rows, D: MTF rows)",
+        },
+    }
+
+    if effects and hal_events:
+        hal_ms = float(np.mean([a.elapsed_time(b) for a, b in hal_events]))
+        px = (r1 - r0) * W
+        nnz = [int(np.count_nonzero(hal_k[..., c])) for c in range(3)]
+        flops_nnz = 2.0 * sum(nnz) * px  # one FMA per non-zero tap per pixel
+        flops_s8d = 2.0 * 2 * hal_k.shape[0] * hal_k.shape[1] * px  # 2 channels x K^2 taps, zeros included
+        achieved = flops_nnz / (hal_ms * 1e-3) / 1e12
+        traffic = None
+        # HBM bytes per launch from the PMC passes of tools/profile_round.sh (not measurable inside a live run)
+        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if tfiles and world == 1 and args.config == "cfg4_100mp":
+            for name, rec in json.load(open(os.path.join(ROOT, "profiles", tfiles[-1]))).items():
+                if "stencil_kernel" in name and name.rstrip(")").endswith("(r2f::StencilArgs") and ", 1>" in name:
+                    traffic = rec["hbm_bytes_per_launch"]
+        result["roofline"] = {
+            "kernel": "r2f::stencil_kernel<32,16,4,1> (S2 halation + S3 log + S4 curve)",
+            "bound": "mfma",
+            "engine": "fp32 VALU (v_pk_fma_f32); no MFMA is issued -- the fp32 dense MFMA peak equals the fp32 VALU peak on gfx950",
+            "achieved": achieved,
+            "peak": FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP32_PEAK_TFLOPS,
+            "traffic": traffic,
+            "kernel_ms": hal_ms,
+            "flops_per_launch": flops_nnz,
+            "flops_counted": f"2 x non-zero taps ({nnz[0]} + {nnz[1]} + {nnz[2]} per pixel) x {px} pixels",
+            "achieved_survey_8d": flops_s8d / (hal_ms * 1e-3) / 1e12,
+        }
+    bytes_alg = 24.0 * H * W
+    gbps = bytes_alg / (ms_per_step * 1e-3) / 1e9
+    result["roofline_hbm"] = {
+        "scope": "whole step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": gbps / HBM_PEAK_GBPS, "bytes_per_px": 24,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import oracle_inputs  # oracle as the timed CPU baseline only
+        from oracle import baseline
+
+        p = oracle_inputs(neg, prt, scale, halation=effects, mtf=effects, grain=2 if effects else 0, seed=GRAIN_SEED)
+        result["cpu_baseline"] = baseline.time_cpu_baseline(p, target_seconds=args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    proc.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,8 @@ REC709_TO_XYZ = np.array(
     dtype=F32,
 )
 
+FFT_WORKERS = -1  # threads scipy.fft may use inside one correlation (-1 = all); the baseline pool sets 1
+
 LOG_EPS = 1e-6  # lut_1d.wgsl:24
 LUT3D_SCALE = 0.25  # cpu_processor.py:405, lut_3d.wgsl:1
 
@@ -115,8 +117,8 @@ def correlate_reflect101(plane: np.ndarray, kernel: np.ndarray, method: str = "f
     fh = sfft.next_fast_len(padded.shape[0], real=True)
     fw = sfft.next_fast_len(padded.shape[1], real=True)
     # correlation == convolution with the flipped kernel; "valid" part starts at (kh-1, kw-1)
-    spec = sfft.rfft2(padded, (fh, fw), workers=-1) * sfft.rfft2(k[::-1, ::-1], (fh, fw), workers=-1)
-    full = sfft.irfft2(spec, (fh, fw), workers=-1)
+    spec = sfft.rfft2(padded, (fh, fw), workers=FFT_WORKERS) * sfft.rfft2(k[::-1, ::-1], (fh, fw), workers=FFT_WORKERS)
+    full = sfft.irfft2(spec, (fh, fw), workers=FFT_WORKERS)
     return full[kh - 1 : kh - 1 + H, kw - 1 : kw - 1 + W].astype(F32)
 
 

@@ -254,7 +254,9 @@ __device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, 
     }
 }
 
-template <int BX, int BY, int Q>
+// EPI: 0 = plain stencil (S5 MTF, tests), 1 = + S3 log + S4 density curve (S2 halation).  A template
+// parameter rather than a runtime flag so that the two stages show up as two kernels in profiles.
+template <int BX, int BY, int Q, int EPI>
 __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = BX * BY, TW = 4 * BX, TH = Q * BY;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
         const int gy = tile_y0 + ty * Q + q;
         if (gy >= a.y1) break;
         float v[4] = {acc[q / 2][0][q & 1], acc[q / 2][1][q & 1], acc[q / 2][2][q & 1], acc[q / 2][3][q & 1]};
-        if (a.epilogue == 1) {
+        if (EPI == 1) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) v[p] = log_curve(a.curve, ch, v[p], a.log_eps);
         }
@@ -423,9 +425,12 @@ hipError_t init_kernel_attributes() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)kMaxLds);                                                            \
     if (e != hipSuccess) return e;
-    R2F_SET_LDS((stencil_kernel<32, 16, 4>))
-    R2F_SET_LDS((stencil_kernel<32, 32, 2>))
-    R2F_SET_LDS((stencil_kernel<16, 8, 4>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1>))
+    R2F_SET_LDS((stencil_kernel<32, 32, 2, 0>))
+    R2F_SET_LDS((stencil_kernel<32, 32, 2, 1>))
+    R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
+    R2F_SET_LDS((stencil_kernel<16, 8, 4, 1>))
     R2F_SET_LDS(tail_kernel)
 #undef R2F_SET_LDS
     return hipSuccess;
@@ -444,10 +449,14 @@ hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
     const StencilVariant& v = kStencilVariants[variant];
     const size_t lds = stencil_lds_bytes(v, a.st, a.nchan);
     dim3 block(v.BX * v.BY), grid((a.W + v.TW() - 1) / v.TW(), (a.y1 - a.y0 + v.TH() - 1) / v.TH(), a.nchan);
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4>), grid, block, lds, s, a); break;
-        case 1: hipLaunchKernelGGL((stencil_kernel<32, 32, 2>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((stencil_kernel<16, 8, 4>), grid, block, lds, s, a); break;
+    const int key = variant * 2 + (a.epilogue == 1 ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0>), grid, block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 1>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((stencil_kernel<32, 32, 2, 0>), grid, block, lds, s, a); break;
+        case 3: hipLaunchKernelGGL((stencil_kernel<32, 32, 2, 1>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 0>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 1>), grid, block, lds, s, a); break;
     }
     return hipGetLastError();
 }
