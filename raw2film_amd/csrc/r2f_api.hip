@@ -49,8 +49,8 @@ struct r2f_ctx {
     DeviceBuf lut2d_buf, lut3d_buf, curve_buf, grain_lut_buf;
     DevLut2D lut2d{nullptr, 0};
     DevLut3D lut3d{nullptr, 0};
-    DevCurve curve{nullptr, 0, 0.f, 0.f};
-    DevCurve grain_lut{nullptr, 0, 0.f, 0.f};
+    DevCurve curve{};
+    DevCurve grain_lut{};
     StencilSet stencil[3];
     int opt_variant = -1;  // -1 auto
     int opt_xcd_remap = 1;
@@ -86,34 +86,30 @@ int upload(r2f_ctx* ctx, DeviceBuf& buf, const void* host, size_t bytes) {
     return R2F_OK;
 }
 
-// (4, m) table -> xp[m] | per channel fp[m], slope[m]; slopes in double like np.interp.
+// (4, m) table -> per channel m-1 cells {xp[i], xp[i+1], fp[i], slope[i]}; slopes in double like np.interp.
 int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, int m) {
-    if (!lut || m < 1) return fail(ctx, R2F_EINVAL, "curve: need a (4, m) table with m >= 1");
-    std::vector<float> packed((size_t)7 * m);
-    for (int i = 0; i < m; ++i) packed[i] = lut[i];
-    for (int c = 0; c < 3; ++c) {
-        const float* fp = lut + (size_t)(1 + c) * m;
-        float* dfp = packed.data() + (size_t)m * (1 + 2 * c);
-        float* dsl = dfp + m;
-        for (int i = 0; i < m; ++i) {
-            dfp[i] = fp[i];
-            if (i + 1 < m) {
-                const double dx = (double)lut[i + 1] - (double)lut[i];
-                dsl[i] = dx != 0.0 ? (float)(((double)fp[i + 1] - (double)fp[i]) / dx) : 0.f;
-            } else {
-                dsl[i] = 0.f;
-            }
-        }
-    }
+    if (!lut || m < 2) return fail(ctx, R2F_EINVAL, "curve: need a (4, m) table with m >= 2");
     for (int i = 0; i + 1 < m; ++i)
         if (!(lut[i + 1] >= lut[i])) return fail(ctx, R2F_EINVAL, "curve: xp must be non-decreasing");
-    int rc = upload(ctx, buf, packed.data(), packed.size() * sizeof(float));
+    std::vector<float4> cells((size_t)3 * (m - 1));
+    for (int c = 0; c < 3; ++c) {
+        const float* fp = lut + (size_t)(1 + c) * m;
+        for (int i = 0; i + 1 < m; ++i) {
+            const double dx = (double)lut[i + 1] - (double)lut[i];
+            const float slope = dx != 0.0 ? (float)(((double)fp[i + 1] - (double)fp[i]) / dx) : 0.f;
+            cells[(size_t)c * (m - 1) + i] = make_float4(lut[i], lut[i + 1], fp[i], slope);
+        }
+        cv.f_first[c] = fp[0];
+        cv.f_last[c] = fp[m - 1];
+    }
+    int rc = upload(ctx, buf, cells.data(), cells.size() * sizeof(float4));
     if (rc) return rc;
-    cv.data = static_cast<const float*>(buf.p);
+    cv.cells = static_cast<const float4*>(buf.p);
     cv.m = m;
     cv.x0 = lut[0];
+    cv.x1 = lut[m - 1];
     const float range = lut[m - 1] - lut[0];
-    cv.inv_step = (m > 1 && range > 0.f) ? (float)(m - 1) / range : 0.f;
+    cv.inv_step = range > 0.f ? (float)(m - 1) / range : 0.f;
     return R2F_OK;
 }
 
@@ -331,7 +327,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
         rc = check_stencil_source(ctx, "stencil src", src, y0, y1, d.ay, d.kh - 1 - d.ay, H);
         if (rc) return rc;
     }
-    if (epilogue == 1 && !ctx->curve.data) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
+    if (epilogue == 1 && !ctx->curve.cells) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
     StencilArgs a;
     for (int c = 0; c < 3; ++c) {
         a.st[c] = set.dev[c];
@@ -504,7 +500,7 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
     a.lut3d_scale = p->lut3d_scale;
     a.lut3d_mode = p->lut3d_mode;
     bool vec = W % 4 == 0 && aligned16(in);
-    if (upto >= R2F_UPTO_DENSITY && !ctx->curve.data) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
+    if (upto >= R2F_UPTO_DENSITY && !ctx->curve.cells) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
     if (upto == R2F_UPTO_OUTPUT) {
         if (!ctx->lut3d.tex) return fail(ctx, R2F_EINVAL, "output LUT not set (r2f_set_lut3d)");
         if (!out_f32 && !out_u8) return fail(ctx, R2F_EINVAL, "front: no output buffer");
@@ -576,7 +572,7 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
                 ? 1
                 : 0;
     if (a.grain) {
-        if (!ctx->grain_lut.data) return fail(ctx, R2F_EINVAL, "grain LUT not set (r2f_set_grain_lut)");
+        if (!ctx->grain_lut.cells) return fail(ctx, R2F_EINVAL, "grain LUT not set (r2f_set_grain_lut)");
         if (!ctx->stencil[R2F_KERNEL_GRAIN].present) {
             // gpu_processor.py:931-932: no grain kernel -> 1x1 ones
             const float one = 1.f;

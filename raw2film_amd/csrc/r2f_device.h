@@ -15,12 +15,15 @@
 namespace r2f {
 
 // ---------------------------------------------------------------------------- tables
-// 1-D curve (S4 density curve, S6c grain LUT).  data = xp[m] | fp0[m] slope0[m] | fp1 slope1 | fp2 slope2
+// 1-D curve (S4 density curve, S6c grain LUT): one float4 {xp[i], xp[i+1], fp[i], slope[i]} per cell
+// and channel, so an evaluation is ONE 16-byte gather (plus a rare neighbour step, see curve_eval).
 struct DevCurve {
-    const float* data;
+    const float4* cells;  // [3][m-1]
     int m;
     float x0;        // xp[0]
-    float inv_step;  // (m-1)/(xp[m-1]-xp[0]): first guess of the cell, corrected against xp[]
+    float x1;        // xp[m-1]
+    float inv_step;  // (m-1)/(xp[m-1]-xp[0]): first guess of the cell, corrected against the cell's own bounds
+    float f_first[3], f_last[3];  // fp[ch][0], fp[ch][m-1]: the clamped ends of np.interp
 };
 
 struct DevLut2D {  // S1: n*n float4 texels (rgb + pad), texel (xi, yi) at xi*n + yi
@@ -78,19 +81,19 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// np.interp semantics: linear, clamped to fp[0] / fp[m-1] outside [xp[0], xp[m-1]].
+// np.interp semantics: linear, clamped to fp[0] / fp[m-1] outside [xp[0], xp[m-1]].  The cell index is
+// guessed from a uniform grid and then walked until the cell's own bounds contain x, so any
+// non-decreasing xp gives exact np.interp results (uniform grids never take a step).
 __device__ __forceinline__ float curve_eval(const DevCurve& cv, int ch, float x) {
-    const float* xp = cv.data;
-    const float* fp = cv.data + (size_t)cv.m * (1 + 2 * ch);
-    const float* sl = fp + cv.m;
-    const int m = cv.m;
-    if (!(x > xp[0])) return fp[0];
-    if (x >= xp[m - 1]) return fp[m - 1];
-    int i = (int)((x - cv.x0) * cv.inv_step);
-    i = clampi(i, 0, m - 2);
-    while (i > 0 && x < xp[i]) --i;
-    while (i < m - 2 && x >= xp[i + 1]) ++i;
-    return fmaf(sl[i], x - xp[i], fp[i]);
+    if (!(x > cv.x0)) return cv.f_first[ch];
+    if (x >= cv.x1) return cv.f_last[ch];
+    const int last = cv.m - 2;
+    const float4* cells = cv.cells + ch * (cv.m - 1);
+    int i = clampi((int)((x - cv.x0) * cv.inv_step), 0, last);
+    float4 c = cells[i];
+    while (x < c.x && i > 0) c = cells[--i];
+    while (x >= c.y && i < last) c = cells[++i];
+    return fmaf(c.w, x - c.x, c.z);
 }
 
 // S0: out = M . in, ((m0*r + m1*g) + m2*b)
@@ -136,7 +139,8 @@ __device__ __forceinline__ void apply_lut2d(const DevLut2D& L, float& X, float& 
 
 // S3 + S4: log10(max(x, eps)) then the density curve.
 __device__ __forceinline__ float log_curve(const DevCurve& cv, int ch, float x, float eps) {
-    return curve_eval(cv, ch, log10f(fmaxf(x, eps)));
+    // v_log_f32 (1 ulp) * log10(2): |error| <= ~1e-7 * |log2 x|, the same order as the ocml log10f result's own ulp
+    return curve_eval(cv, ch, __log2f(fmaxf(x, eps)) * 0.30102999566398120f);
 }
 
 // S8 tetrahedral: utils.py:247-380 (tie rules `>=` kept), fp32.

@@ -73,7 +73,7 @@ struct StencilVariant {
 };
 constexpr int kNumStencilVariants = 3;
 extern const StencilVariant kStencilVariants[kNumStencilVariants];
-constexpr int kTailBX = 16, kTailBY = 16, kTailQ = 4;  // grain/tail tile 64 x 64, 256 threads
+constexpr int kTailBX = 16, kTailBY = 32, kTailQ = 2;  // grain/tail tile 64 x 64, 512 threads
 constexpr size_t kMaxLds = 160 * 1024;
 
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan);
