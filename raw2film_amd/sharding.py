@@ -136,20 +136,30 @@ class RowShardedRenderer:
             return
         ops, recvs = [], []
         own0 = p.r0 - buf_gy0  # buffer row of the first own row
+        # RCCL moves device buffers directly and orders them against the current stream.  gloo (CPU tests,
+        # single-GPU validation) is a host transport: stage through host memory explicitly.
+        host_staging = buf.is_cuda and dist.get_backend(self.group) == "gloo"
+
+        def outgoing(t):
+            t = t.contiguous()
+            return t.cpu() if host_staging else t
+
+        def incoming(rows):
+            return torch.empty((3, rows, p.W), dtype=buf.dtype, device="cpu" if host_staging else buf.device)
+
         if p.rank > 0:  # neighbour above: it needs my top `below` rows, I need its bottom `above` rows
             if below:
-                send = buf[:, own0:own0 + below, :].contiguous()
-                ops.append(dist.P2POp(dist.isend, send, self._peer(p.rank - 1), self.group))
+                ops.append(dist.P2POp(dist.isend, outgoing(buf[:, own0:own0 + below, :]), self._peer(p.rank - 1), self.group))
             if above:
-                recv = torch.empty((3, above, p.W), dtype=buf.dtype, device=buf.device)
+                recv = incoming(above)
                 ops.append(dist.P2POp(dist.irecv, recv, self._peer(p.rank - 1), self.group))
                 recvs.append((recv, own0 - above))
         if p.rank < p.world - 1:  # neighbour below
             if above:
-                send = buf[:, own0 + p.rows - above:own0 + p.rows, :].contiguous()
-                ops.append(dist.P2POp(dist.isend, send, self._peer(p.rank + 1), self.group))
+                ops.append(dist.P2POp(dist.isend, outgoing(buf[:, own0 + p.rows - above:own0 + p.rows, :]),
+                                      self._peer(p.rank + 1), self.group))
             if below:
-                recv = torch.empty((3, below, p.W), dtype=buf.dtype, device=buf.device)
+                recv = incoming(below)
                 ops.append(dist.P2POp(dist.irecv, recv, self._peer(p.rank + 1), self.group))
                 recvs.append((recv, own0 + p.rows))
         if ops:

@@ -1,0 +1,69 @@
+"""RowShardedRenderer with the HIP stage backend.  One GPU is enough: world_size 2 over gloo with both
+ranks on cuda:0 (RCCL refuses two ranks on one device; the exchange code path is the same
+`batch_isend_irecv`, only the transport differs)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from helpers import SEED, stocks, synthetic_frame  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _render(rank, world, H, W, fw):
+    from raw2film_amd import HipProcessor, stencils
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+
+    neg, prt, _ = stocks()
+    proc = HipProcessor(device=0)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
+                          frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
+    scale = max(H, W) / fw
+    hal = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
+    mtf = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
+    be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
+    rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=rank, world=world)
+    img = torch.from_numpy(synthetic_frame(H, W, seed=31)).cuda()
+    out = torch.empty((rr.plan.rows, W, 3), dtype=torch.float32, device="cuda")
+    rr.render(img[rr.plan.r0:rr.plan.r1].contiguous(), out_f32=out)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), proc, params, img
+
+
+def _worker(rank, world, port, H, W, fw, path):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out, _, _, _ = _render(rank, world, H, W, fw)
+        np.save(f"{path}.{rank}.npy", out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
+    import torch.multiprocessing as mp
+
+    H, W, fw = 210, 256, 1.0  # 256 px/mm -> 65-tap halation, 27-tap MTF; shards of 105 rows
+    path = str(tmp_path / "shard")
+    mp.spawn(_worker, args=(2, _free_port(), H, W, fw, path), nprocs=2, join=True)
+    sharded = np.concatenate([np.load(f"{path}.{r}.npy") for r in range(2)])
+    whole, proc, params, img = _render(0, 1, H, W, fw)
+    np.testing.assert_array_equal(sharded, whole)
+    ref, _ = proc.ctx.render(img, params)
+    np.testing.assert_array_equal(whole, ref.cpu().numpy())
