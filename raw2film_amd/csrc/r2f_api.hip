@@ -34,6 +34,7 @@ struct StencilSet {
     int built_q = 0;          // 0 = device form stale
     int built_tw = 0, built_th = 0;
     size_t built_budget = 0;
+    bool built_sym = false;
     bool common_box = false;
     DevStencil dev[3];
     DeviceBuf wbuf[3], mbuf[3];
@@ -55,6 +56,7 @@ struct r2f_ctx {
     int opt_variant = -1;  // -1 auto
     int opt_xcd_remap = 1;
     int opt_ablate = 0;
+    int opt_sym = 1;      // use the mirror-symmetric entry form when a channel's taps allow it
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
 };
 
@@ -120,19 +122,23 @@ int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, i
 // Row steps are grouped into phases of at most `mp` steps; LDS offsets are relative to the phase.
 struct StreamHost {
     std::vector<float> w;
-    std::vector<int> offs, rowcnt, phases;
+    std::vector<int> offs, offs_r, rowcnt, phases;
     int n_phases = 0, n_rowsteps = 0, max_lds_rows = 0;
 };
 
-void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int j_hi, int Q, int RS, int TH, int mp,
-                  StreamHost& out) {
-    const int kh = i_hi - i_lo + 1, kw = j_hi - j_lo + 1;
-    const int nch = (kw + 3) / 4;
+// `tap(i, j)` = weight of the (virtual) cropped stencil, 0 outside; kh x kw virtual taps.
+// sym: kw = 2r + 1 with r even, mirror symmetric; entries cover columns 0..r, centre column at half weight.
+template <class Tap>
+void build_stream(Tap tap, int kh, int kw, bool sym, int Q, int RS, int TH, int mp, StreamHost& out) {
+    const int r = (kw - 1) / 2;
+    const int ncols = sym ? r + 1 : kw;  // columns that own entries
+    const int nch = (ncols + 3) / 4;
     const int M = kh + Q - 1;
     out = StreamHost();
-    auto tap = [&](int i, int j) -> float {
-        if (i < 0 || i >= kh || j < 0 || j >= kw) return 0.f;
-        return k[(size_t)(i + i_lo) * kw_full + (j + j_lo)];
+    auto wt = [&](int i, int j) -> float {
+        if (!sym) return tap(i, j);
+        if (j > r) return 0.f;
+        return j == r ? 0.5f * tap(i, j) : tap(i, j);
     };
     if (mp < 1) mp = 1;
     for (int m0 = 0; m0 < M; m0 += mp) {
@@ -150,7 +156,7 @@ void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int
                 bool nz = false;
                 for (int q = 0; q < Q && !nz; ++q)
                     for (int t = 0; t < 4; ++t)
-                        if (tap(m - q, 4 * c + t) != 0.f) {
+                        if (wt(m - q, 4 * c + t) != 0.f) {
                             nz = true;
                             break;
                         }
@@ -163,8 +169,9 @@ void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int
             out.rowcnt.push_back(c_hi - c_lo + 1);
             for (int c = c_lo; c <= c_hi; ++c) {
                 out.offs.push_back((m - m0) * RS + 4 * c);
+                out.offs_r.push_back((m - m0) * RS + 2 * r - 4 * c - 4);
                 for (int t = 0; t < 4; ++t)
-                    for (int q = 0; q < Q; ++q) out.w.push_back(tap(m - q, 4 * c + t));
+                    for (int q = 0; q < Q; ++q) out.w.push_back(wt(m - q, 4 * c + t));
             }
         }
     }
@@ -176,6 +183,7 @@ void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int
     out.phases.push_back((int)out.offs.size());
     for (int d = 0; d < 2; ++d) {  // two dummy entries: targets of the last prefetches
         out.offs.push_back(0);
+        out.offs_r.push_back(0);
         for (int i = 0; i < 4 * Q; ++i) out.w.push_back(0.f);
     }
     if (out.rowcnt.empty()) out.rowcnt.push_back(0);
@@ -184,9 +192,11 @@ void build_stream(const float* k, int kw_full, int i_lo, int i_hi, int j_lo, int
 // Build (or reuse) the device form of stencil `which` for a tile TW x TH, Q rows per lane, and an LDS
 // budget in bytes (0 = whole stencil height in one phase).
 int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_budget, bool common_box) {
+    const bool allow_sym = ctx->opt_sym != 0;
     StencilSet& s = ctx->stencil[which];
     if (!s.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
-    if (s.built_q == Q && s.built_tw == TW && s.built_th == TH && s.built_budget == lds_budget && s.common_box == common_box)
+    if (s.built_q == Q && s.built_tw == TW && s.built_th == TH && s.built_budget == lds_budget && s.common_box == common_box &&
+        s.built_sym == allow_sym)
         return R2F_OK;
     int box[3][4];
     for (int c = 0; c < 3; ++c) {
@@ -217,13 +227,34 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
     for (int c = 0; c < 3; ++c) {
         const int kc = s.kc == 1 ? 0 : c;
         for (size_t i = 0; i < plane.size(); ++i) plane[i] = s.host[i * s.kc + kc];
+        const int i_lo = box[c][0], j_lo0 = box[c][2];
+        const int bh = box[c][1] - box[c][0] + 1, bw = box[c][3] - box[c][2] + 1;
+        // mirror symmetry about the anchor column, bit for bit?  (needs an odd box centred on the anchor)
+        bool sym = allow_sym && !common_box && bw % 2 == 1 && bw >= 9 && s.kw / 2 - j_lo0 == (bw - 1) / 2;
+        for (int i = 0; sym && i < bh; ++i)
+            for (int j = 0; j < bw / 2; ++j) {
+                const float a = plane[(size_t)(i + i_lo) * s.kw + j_lo0 + j], b2 = plane[(size_t)(i + i_lo) * s.kw + j_lo0 + bw - 1 - j];
+                if (memcmp(&a, &b2, sizeof a) != 0) {
+                    sym = false;
+                    break;
+                }
+            }
+        // virtual stencil: the cropped box, widened by one zero column per side when sym needs an even r
+        const int pad = (sym && ((bw - 1) / 2) % 2 == 1) ? 1 : 0;
+        const int vkw = bw + 2 * pad, vkh = bh;
+        auto tap = [&](int i, int j) -> float {
+            j -= pad;
+            if (i < 0 || i >= bh || j < 0 || j >= bw) return 0.f;
+            return plane[(size_t)(i + i_lo) * s.kw + (j + j_lo0)];
+        };
         DevStencil& d = s.dev[c];
-        d.kh = box[c][1] - box[c][0] + 1;
-        d.kw = box[c][3] - box[c][2] + 1;
-        d.kw_pad = (d.kw + 3) / 4 * 4;
+        d.kh = vkh;
+        d.kw = vkw;
+        d.kw_pad = (vkw + 3) / 4 * 4;
         d.RS = TW + d.kw_pad;
-        d.ay = s.kh / 2 - box[c][0];  // anchor (kh/2, kw/2): convolution.wgsl:31, cv.filter2D default
-        d.ax = s.kw / 2 - box[c][2];
+        d.ay = s.kh / 2 - i_lo;  // anchor (kh/2, kw/2): convolution.wgsl:31, cv.filter2D default
+        d.ax = s.kw / 2 - j_lo0 + pad;
+        d.sym = sym ? 1 : 0;
         d.wmul = 1;
         const int M = d.kh + Q - 1;
         int mp = M;
@@ -235,15 +266,16 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
             const int nph = (M + mp - 1) / mp;
             mp = (M + nph - 1) / nph;
         }
-        build_stream(plane.data(), s.kw, box[c][0], box[c][1], box[c][2], box[c][3], Q, d.RS, TH, mp, sh);
+        build_stream(tap, vkh, vkw, sym, Q, d.RS, TH, mp, sh);
         d.n_phases = sh.n_phases;
         d.n_rowsteps = sh.n_rowsteps;
         d.max_lds_rows = sh.max_lds_rows;
         int rc = upload(ctx, s.wbuf[c], sh.w.data(), sh.w.size() * sizeof(float));
         if (rc) return rc;
-        // offsets, row counts and phase records share one allocation: [offs | rowcnt | phases]
+        // offsets, mirrored offsets, row counts and phase records share one allocation
         std::vector<int> meta(sh.offs);
         const size_t n_off = meta.size();
+        meta.insert(meta.end(), sh.offs_r.begin(), sh.offs_r.end());
         meta.insert(meta.end(), sh.rowcnt.begin(), sh.rowcnt.end());
         const size_t n_rc = sh.rowcnt.size();
         meta.insert(meta.end(), sh.phases.begin(), sh.phases.end());
@@ -251,13 +283,15 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
         if (rc) return rc;
         d.wstream = static_cast<const float*>(s.wbuf[c].p);
         d.offs = static_cast<const int*>(s.mbuf[c].p);
-        d.rowcnt = d.offs + n_off;
+        d.offs_r = d.offs + n_off;
+        d.rowcnt = d.offs_r + n_off;
         d.phases = d.rowcnt + n_rc;
     }
     s.built_q = Q;
     s.built_tw = TW;
     s.built_th = TH;
     s.built_budget = lds_budget;
+    s.built_sym = allow_sym;
     s.common_box = common_box;
     return R2F_OK;
 }
@@ -397,6 +431,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_lds_kb")) {
         if (value < 8 || value > 160) return fail(ctx, R2F_EINVAL, "stencil_lds_kb must be in [8, 160]");
         ctx->opt_lds_kb = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_sym")) {
+        ctx->opt_sym = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_ablate")) {

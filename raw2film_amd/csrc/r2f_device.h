@@ -47,6 +47,7 @@ struct DevStencil {
     const float* wstream;  // per entry: 4*Q floats  w[t][q] = K[m-q][4c+t]  (0 outside the taps)
     const int* offs;       // per entry: LDS float offset (m - m0(phase))*RS + 4c
     const int* rowcnt;     // per non-empty row step: number of entries (>= 1)
+    const int* offs_r;     // sym only, per entry: LDS float offset of the mirrored 8-float block (m - m0)*RS + 2r - 4c - 4
     const int* phases;     // per phase 4 ints: {m0, lds_rows, first row step (index into rowcnt), first entry}
                            // + one terminator {., ., n_rowsteps, n_entries}
     int n_phases;
@@ -56,6 +57,7 @@ struct DevStencil {
     int ay, ax;            // anchor inside the cropped box
     int RS;                // LDS row stride (floats) the offsets were built for
     int max_lds_rows;      // largest lds_rows over the phases
+    int sym;               // 1: taps are left-right mirror symmetric -> entries cover columns 0..r only (see below)
     int wmul;              // 1; 0 = profiling aid (every entry reads entry 0's weights -> scalar-cache hits)
 };
 
@@ -342,6 +344,106 @@ __device__ __forceinline__ void entry_step(const float* lds, const int R2F_CONST
     entry_fma<Q, FIRST>(cw, ca, cb, part);
     off1 = off2;
     ++e;
+}
+
+// ---- mirror-symmetric stencils -------------------------------------------------------------
+// When K[i][j] == K[i][2r - j] bit for bit (halation discs and |ifft2| MTF kernels are), the two
+// mirrored taps of a kernel row share their weight:  w * x[+j] + w * x[-j]  ->  w * (x[+j] + x[-j]).
+// An entry then covers 4 columns j = 4c..4c+3 of the LEFT half (the centre column j = r carries half
+// its weight and is paired with itself, which is exact: (w/2) * (x + x) == w * x).  Per entry the lane
+// reads two 8-float blocks, L at columns 4c.. and the mirrored R at columns 2r-4c-4.. (r is made even
+// on the host so that R is 16-byte aligned), forms 16 sums s[p][t] = L[p+t] + R[4+p-t], and issues the
+// same 8*Q packed FMAs as a plain entry -- for twice the taps.  1.5x fewer VALU instructions per tap.
+template <int Q, bool FIRST>
+__device__ __forceinline__ void entry_fma_sym(const typename WVec<4 * Q>::type& w, const float4v& la, const float4v& lb,
+                                              const float4v& ra, const float4v& rb, float2v (&part)[Q / 2][4]) {
+    const float lw[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+    const float rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float sum[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sum[p] = lw[p + t] + rw[4 + p - t];
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j) {
+            const float2v wv = {w[t * Q + 2 * j], w[t * Q + 2 * j + 1]};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float2v px = {sum[p], sum[p]};
+                if (FIRST && t == 0)
+                    part[j][p] = wv * px;
+                else
+                    part[j][p] = __builtin_elementwise_fma(wv, px, part[j][p]);
+            }
+        }
+    }
+}
+
+template <int Q>
+struct SymOperands {
+    typename WVec<4 * Q>::type w;
+    float4v la, lb, ra, rb;
+};
+
+template <int Q, bool FIRST>
+__device__ __forceinline__ void entry_step_sym(const float* lds, const int R2F_CONSTANT* offs, const int R2F_CONSTANT* offs_r,
+                                               const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
+                                               int& off1, int& off1r, const SymOperands<Q>& cur, SymOperands<Q>& nxt,
+                                               float2v (&part)[Q / 2][4]) {
+    asm volatile("" ::"s"(cur.w[0]), "s"(cur.w[4 * Q - 1]), "v"(cur.la.x), "v"(cur.lb.w), "v"(cur.ra.x), "v"(cur.rb.w));
+    __builtin_amdgcn_sched_barrier(0);
+    const int off2 = offs[e + 2], off2r = offs_r[e + 2];
+    nxt.w = wstream[(e + 1) * wmul];
+    nxt.la = *reinterpret_cast<const float4v*>(lds + off1);
+    nxt.lb = *reinterpret_cast<const float4v*>(lds + off1 + 4);
+    nxt.ra = *reinterpret_cast<const float4v*>(lds + off1r);
+    nxt.rb = *reinterpret_cast<const float4v*>(lds + off1r + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    entry_fma_sym<Q, FIRST>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part);
+    off1 = off2;
+    off1r = off2r;
+    ++e;
+}
+
+template <int Q>
+__device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const DevStencil& st, int row_begin, int row_end,
+                                                       int e0, float2v (&acc)[Q / 2][4]) {
+    typedef typename WVec<4 * Q>::type wvec;
+    const int R2F_CONSTANT* offs = (const int R2F_CONSTANT*)st.offs;
+    const int R2F_CONSTANT* offs_r = (const int R2F_CONSTANT*)st.offs_r;
+    const int R2F_CONSTANT* rowcnt = (const int R2F_CONSTANT*)st.rowcnt;
+    const wvec R2F_CONSTANT* wstream = (const wvec R2F_CONSTANT*)st.wstream;
+    const int wmul = st.wmul;
+    float2v part[Q / 2][4];
+    int e = e0;
+    int off1 = offs[e0 + 1], off1r = offs_r[e0 + 1];
+    SymOperands<Q> A, B;
+    A.w = wstream[e0 * wmul];
+    {
+        const int o = offs[e0], orr = offs_r[e0];
+        A.la = *reinterpret_cast<const float4v*>(lds + o);
+        A.lb = *reinterpret_cast<const float4v*>(lds + o + 4);
+        A.ra = *reinterpret_cast<const float4v*>(lds + orr);
+        A.rb = *reinterpret_cast<const float4v*>(lds + orr + 4);
+    }
+    for (int r = row_begin; r < row_end; ++r) {
+        const int cnt = rowcnt[r];
+        entry_step_sym<Q, true>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, A, B, part);
+        int i = 1;
+        for (; i + 1 < cnt; i += 2) {
+            entry_step_sym<Q, false>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, B, A, part);
+            entry_step_sym<Q, false>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, A, B, part);
+        }
+        if (i < cnt) {
+            entry_step_sym<Q, false>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, B, A, part);
+        } else {
+            A = B;
+        }
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[j][p] += part[j][p];
+    }
 }
 
 // Accumulate the row steps [row_begin, row_end) of one phase, whose first entry is e0.

@@ -14,8 +14,7 @@ namespace r2f {
 
 const StencilVariant kStencilVariants[kNumStencilVariants] = {
     {0, 32, 16, 4},  // 512 threads, tile 128 x 64, 4x4 outputs per lane
-    {1, 32, 32, 2},  // 1024 threads, tile 128 x 64, 4x2 outputs per lane
-    {2, 16, 8, 4},   // 128 threads, tile 64 x 32: fallback for very large stencils
+    {1, 16, 8, 4},   // 128 threads, tile 64 x 32: fallback for very wide stencils
 };
 
 // ------------------------------------------------------------------------------ output
@@ -292,7 +291,12 @@ __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
             fill_tile_reflect<NT>(smem, RS, lds_rows, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global,
                                   tile_y0 - st.ay + m0, tile_x0 - st.ax);
         __syncthreads();
-        if (a.ablate != 2) stencil_accumulate<Q>(lds_lane, st, row_begin, row_end, e0, acc);
+        if (a.ablate != 2) {
+            if (st.sym)  // per channel, wave-uniform
+                stencil_accumulate_sym<Q>(lds_lane, st, row_begin, row_end, e0, acc);
+            else
+                stencil_accumulate<Q>(lds_lane, st, row_begin, row_end, e0, acc);
+        }
     }
 
     const int gx = tile_x0 + 4 * tx;
@@ -427,8 +431,6 @@ hipError_t init_kernel_attributes() {
     if (e != hipSuccess) return e;
     R2F_SET_LDS((stencil_kernel<32, 16, 4, 0>))
     R2F_SET_LDS((stencil_kernel<32, 16, 4, 1>))
-    R2F_SET_LDS((stencil_kernel<32, 32, 2, 0>))
-    R2F_SET_LDS((stencil_kernel<32, 32, 2, 1>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 1>))
     R2F_SET_LDS(tail_kernel)
@@ -453,9 +455,7 @@ hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
     switch (key) {
         case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0>), grid, block, lds, s, a); break;
         case 1: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 1>), grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((stencil_kernel<32, 32, 2, 0>), grid, block, lds, s, a); break;
-        case 3: hipLaunchKernelGGL((stencil_kernel<32, 32, 2, 1>), grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 0>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 0>), grid, block, lds, s, a); break;
         default: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 1>), grid, block, lds, s, a); break;
     }
     return hipGetLastError();

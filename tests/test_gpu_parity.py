@@ -152,7 +152,7 @@ def test_stencil_non_square_and_even_sizes(ctx):
     assert_close(from_planes(dst), ref, 1e-5, 1e-2, "non-square stencil")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1])
 def test_stencil_tile_variants_agree_bitwise(ctx, variant):
     """Every tile variant accumulates taps in the same order -> identical bits."""
     rng = np.random.default_rng(7)
@@ -168,6 +168,54 @@ def test_stencil_tile_variants_agree_bitwise(ctx, variant):
         outs.append(dst.cpu().numpy())
     ctx.set_option("stencil_variant", -1)
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("lds_kb", [160, 80, 48])
+def test_stencil_phasing_is_bitwise_neutral(ctx, lds_kb):
+    """The LDS budget only changes how many row steps share a tile fill, never the tap order."""
+    rng = np.random.default_rng(8)
+    img = rng.uniform(0.0, 2.0, (140, 200, 3)).astype(np.float32)
+    ctx.set_kernel(0, ok.compute_halation_kernel(229.33, halation_green_factor=0.3))
+    src = to_planes(img)
+    outs = []
+    for kb in (80, lds_kb):
+        ctx.set_option("stencil_lds_kb", kb)
+        dst = torch.empty((3, 140, 200), dtype=torch.float32, device="cuda")
+        ctx.stage_stencil(0, src, dst, y0=0, y1=140, H_global=140)
+        outs.append(dst.cpu().numpy())
+    ctx.set_option("stencil_lds_kb", 80)
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_mirror_symmetric_fast_path(ctx):
+    """Bit-for-bit mirror-symmetric stencils take the paired-tap path; it must agree with the plain
+    path to rounding, and a stencil that is symmetric only up to one ulp must not take it."""
+    rng = np.random.default_rng(9)
+    H, W = 100, 150
+    img = rng.uniform(0.0, 2.0, (H, W, 3)).astype(np.float32)
+    src = to_planes(img)
+
+    def run(k, sym):
+        ctx.set_option("stencil_sym", sym)
+        ctx.set_kernel(1, k)
+        dst = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_stencil(1, src, dst, y0=0, y1=H, H_global=H)
+        ctx.set_option("stencil_sym", 1)
+        return from_planes(dst)
+
+    for k in (ok.compute_halation_kernel(341.33, halation_green_factor=0.3),   # r = 42 (even)
+              ok.compute_halation_kernel(229.33, halation_green_factor=0.3),   # r = 28
+              ok.compute_halation_kernel(60.0),                                 # r = 7 (odd -> padded)
+              ok.mtf_kernel(stocks()[0].mtf, 341.33), ok.mtf_kernel(stocks()[0].mtf, 229.33, 0.7, 1.0)):
+        a, b = run(k, 1), run(k, 0)
+        ref = st.convolve_2d(img, k)
+        assert_close(a, ref, 1e-5, 1e-2, "sym path")
+        assert_close(b, ref, 1e-5, 1e-2, "plain path")
+        assert np.abs(a - b).max() <= 2e-6
+        assert not np.array_equal(a, b), "the symmetric path was not taken"
+    k = ok.compute_halation_kernel(229.33, halation_green_factor=0.3).copy()
+    k[3, 20, 0] = np.nextafter(k[3, 20, 0], np.float32(1))  # break the symmetry of the red plane by one ulp
+    np.testing.assert_array_equal(run(k, 1)[..., 0], run(k, 0)[..., 0])
 
 
 @pytest.mark.parametrize("scale", [14.22, 166.67, 341.33])

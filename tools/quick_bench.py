@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--w", type=int, default=12288)
 ap.add_argument("--h", type=int, default=8192)
 ap.add_argument("--iters", type=int, default=3)
-ap.add_argument("--variants", type=str, default="0,1")
+ap.add_argument("--variants", type=str, default="0")
 ap.add_argument("--lds-kb", dest="lds_kb", type=str, default="160,80,53,40")
 args = ap.parse_args()
 
@@ -85,6 +85,11 @@ ctx.set_option("stencil_variant", -1)
 ctx.set_option("xcd_remap", 1)
 t = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
 print(f"halation auto, xcd remap on {t[0]:8.3f} ms")
+ctx.set_option("stencil_sym", 0)
+t = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
+t2 = timeit(lambda: ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H))
+print(f"symmetric path OFF: halation {t[0]:8.3f} ms   mtf {t2[0]:8.3f} ms")
+ctx.set_option("stencil_sym", 1)
 t = timeit(lambda: ctx.stage_tail(D2, params, out_f32=out, y0=0, y1=H, H_global=H))
 print(f"tail(grain)     {t[0]:8.3f} ms")
 pn = ctx.make_params(matrix=True, halation=True, mtf=True)
