@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cfg4_100mp", choices=["cfg4_100mp", "cfg3_45mp", "cfg2_24mp"])
+    ap.add_argument("--config", default="cfg4_100mp", choices=["cfg4_100mp", "cfg3_45mp", "cfg2_24mp", "cfg5_batch"])
+    ap.add_argument("--frames", type=int, default=64, help="cfg5_batch: frames per step, dealt round-robin to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -61,11 +62,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
-    W, H = CONFIGS[args.config]
+    batch = args.config == "cfg5_batch"  # BASELINE config 5: 64 x 24 MP frames, full pipeline, frame-per-GPU, no collectives
+    W, H = CONFIGS["cfg2_24mp" if batch else args.config]
     effects = args.config != "cfg2_24mp"  # config 2 = negative + print LUTs only
     stocks = filmstock.builtin_stocks()
     neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
@@ -81,7 +84,12 @@ def main():
     backend = HipStageBackend(proc.ctx, params,
                               halation_taps=stencils.vertical_reach(hal_k) if effects else (0, 0),
                               mtf_taps=stencils.vertical_reach(mtf_k) if effects else (0, 0))
-    renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects)
+    if batch:  # whole frames per rank: a renderer of world size 1, and this rank's share of the frames per step
+        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, rank=0, world=1)
+        frames_here = len([i for i in range(args.frames) if i % world == rank])
+    else:
+        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects)
+        frames_here = 1
     r0, r1 = renderer.plan.r0, renderer.plan.r1
 
     # this rank's rows of the synthetic frame, resident in HBM before the clock starts
@@ -104,26 +112,30 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        for _ in range(frames_here):
+            renderer.render(frame, out_f32=out)
+
     for _ in range(args.warmup):
-        renderer.render(frame, out_f32=out)
+        step()
     barrier()
     hal_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        renderer.render(frame, out_f32=out)
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=frame.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
-    mp_per_s = H * W / 1e6 * args.steps / dt
+    mp_per_s = H * W / 1e6 * (args.frames if batch else 1) * args.steps / dt
 
     result = {
         "metric": "megapixels/sec full film pipeline (neg+print+grain+halation+MTF), 100MP frame",
@@ -139,13 +151,15 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 frame, 36x24 mm, "
+            "workload": f"{args.config}: " + (f"{args.frames} x " if batch else "") + f"{W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 frame, 36x24 mm, "
                         + ("full pipeline S0-S8: 3x3 + 2-D LUT + halation 87x87 + log/curve + MTF 35x35 + grain 9x9 + tetrahedral 3-D LUT"
                            if args.config == "cfg4_100mp" else
                            ("full pipeline S0-S8" if effects else "LUTs only (S0+S1+S3+S4+S8), effects off"))
                         + ", fp32 HWC in -> fp32 HWC out",
             "stocks": "synthetic stand-ins portra400_like + k2383_like (spectral_film_lut data unavailable offline)",
-            "sharding": "single GPU" if world == 1 else f"row-sharded over {world} GPUs, RCCL halo exchange (E: halation rows, D: MTF rows)",
+            "sharding": (f"batch of {args.frames} frames, frame i -> rank i mod {world}, no collectives" if batch else
+                         "single GPU" if world == 1 else
+                         f"row-sharded over {world} GPUs, RCCL halo exchange (E: halation rows, D: MTF rows)"),
         },
     }
 
@@ -179,7 +193,7 @@ def main():
                              "reference's stencil needs; the kernel pairs mirror-symmetric taps (w*(a+b)), so it issues ~0.64x as many VALU lane-ops",
             "achieved_survey_8d": flops_s8d / (hal_ms * 1e-3) / 1e12,
         }
-    bytes_alg = 24.0 * H * W
+    bytes_alg = 24.0 * H * W * (args.frames if batch else 1)
     gbps = bytes_alg / (ms_per_step * 1e-3) / 1e9
     result["roofline_hbm"] = {
         "scope": "whole step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -196,7 +210,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     proc.close()
 

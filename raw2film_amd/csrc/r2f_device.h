@@ -86,16 +86,21 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // np.interp semantics: linear, clamped to fp[0] / fp[m-1] outside [xp[0], xp[m-1]].  The cell index is
 // guessed from a uniform grid and then walked until the cell's own bounds contain x, so any
 // non-decreasing xp gives exact np.interp results (uniform grids never take a step).
-__device__ __forceinline__ float curve_eval(const DevCurve& cv, int ch, float x) {
+template <class CellPtr>
+__device__ __forceinline__ float curve_eval_at(CellPtr cells_base, const DevCurve& cv, int ch, float x) {
     if (!(x > cv.x0)) return cv.f_first[ch];
     if (x >= cv.x1) return cv.f_last[ch];
     const int last = cv.m - 2;
-    const float4* cells = cv.cells + ch * (cv.m - 1);
+    CellPtr cells = cells_base + ch * (cv.m - 1);
     int i = clampi((int)((x - cv.x0) * cv.inv_step), 0, last);
     float4 c = cells[i];
     while (x < c.x && i > 0) c = cells[--i];
     while (x >= c.y && i < last) c = cells[++i];
     return fmaf(c.w, x - c.x, c.z);
+}
+
+__device__ __forceinline__ float curve_eval(const DevCurve& cv, int ch, float x) {
+    return curve_eval_at(cv.cells, cv, ch, x);
 }
 
 // S0: out = M . in, ((m0*r + m1*g) + m2*b)
@@ -140,6 +145,10 @@ __device__ __forceinline__ void apply_lut2d(const DevLut2D& L, float& X, float& 
 }
 
 // S3 + S4: log10(max(x, eps)) then the density curve.
+__device__ __forceinline__ float log10_fast(float x, float eps) {
+    return __log2f(fmaxf(x, eps)) * 0.30102999566398120f;
+}
+
 __device__ __forceinline__ float log_curve(const DevCurve& cv, int ch, float x, float eps) {
     // v_log_f32 (1 ulp) * log10(2): |error| <= ~1e-7 * |log2 x|, the same order as the ocml log10f result's own ulp
     return curve_eval(cv, ch, __log2f(fmaxf(x, eps)) * 0.30102999566398120f);

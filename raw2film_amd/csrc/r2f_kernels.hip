@@ -116,69 +116,88 @@ __device__ __forceinline__ void apply_lut3d(const DevLut3D& L, float scale, int 
 }
 
 // ------------------------------------------------------------------------------ front
-// One lane = 4 consecutive pixels of one row.  Block (64, 4).
-__global__ __launch_bounds__(256) void front_kernel(const FrontArgs a) {
+// One lane = 4 consecutive pixels of one row.  Block (64, BYF); each block walks down the frame in
+// steps of gridDim.y * BYF rows.  LDSC: the density curve (3 x (m-1) float4 cells, 48 KB at m = 1024)
+// is copied to LDS once per block, so the three data-dependent curve look-ups per pixel are LDS reads
+// instead of scattered 16-byte global gathers (which made the fused LUT-only pass gather-bound).
+constexpr int kFrontBY = 8;
+
+template <bool LDSC>
+__global__ __launch_bounds__(64 * kFrontBY) void front_kernel(const FrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 cells_lds[];
+    if (LDSC) {
+        const int n = 3 * (a.curve.m - 1);
+        for (int i = threadIdx.y * 64 + threadIdx.x; i < n; i += 64 * kFrontBY) cells_lds[i] = a.curve.cells[i];
+        __syncthreads();
+    }
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int gy = a.y0 + blockIdx.y * 4 + threadIdx.y;
-    if (x >= a.W || gy >= a.y1) return;
+    if (x >= a.W) return;
     const int W = a.W;
     const int nv = min(4, W - x);
     const bool vec = a.vec != 0;
-    const long long irow = gy - a.in_gy0;
-    float r[4], g[4], b[4];
     const float* in = static_cast<const float*>(a.in);
-    if (a.in_layout == R2F_LAYOUT_CHW) {
-        DevPlanes pl;
-        pl.data = const_cast<float*>(in);
-        pl.plane_stride = (long long)a.in_rows * W;
-        pl.gy0 = a.in_gy0;
-        pl.rows = a.in_rows;
-        load_planes4(pl, gy, x, W, nv, vec, r, g, b);
-    } else if (a.in_layout == R2F_LAYOUT_HWC3) {
-        const float* p = in + (irow * W + x) * 3;
-        if (vec && nv == 4) {
-            const float4* p4 = reinterpret_cast<const float4*>(p);
-            const float4 v0 = p4[0], v1 = p4[1], v2 = p4[2];
-            r[0] = v0.x; g[0] = v0.y; b[0] = v0.z;
-            r[1] = v0.w; g[1] = v1.x; b[1] = v1.y;
-            r[2] = v1.z; g[2] = v1.w; b[2] = v2.x;
-            r[3] = v2.y; g[3] = v2.z; b[3] = v2.w;
-        } else {
+    for (int gy = a.y0 + blockIdx.y * kFrontBY + threadIdx.y; gy < a.y1; gy += gridDim.y * kFrontBY) {
+        const long long irow = gy - a.in_gy0;
+        float r[4], g[4], b[4];
+        if (a.in_layout == R2F_LAYOUT_CHW) {
+            DevPlanes pl;
+            pl.data = const_cast<float*>(in);
+            pl.plane_stride = (long long)a.in_rows * W;
+            pl.gy0 = a.in_gy0;
+            pl.rows = a.in_rows;
+            load_planes4(pl, gy, x, W, nv, vec, r, g, b);
+        } else if (a.in_layout == R2F_LAYOUT_HWC3) {
+            const float* p = in + (irow * W + x) * 3;
+            if (vec && nv == 4) {
+                const float4* p4 = reinterpret_cast<const float4*>(p);
+                const float4 v0 = p4[0], v1 = p4[1], v2 = p4[2];
+                r[0] = v0.x; g[0] = v0.y; b[0] = v0.z;
+                r[1] = v0.w; g[1] = v1.x; b[1] = v1.y;
+                r[2] = v1.z; g[2] = v1.w; b[2] = v2.x;
+                r[3] = v2.y; g[3] = v2.z; b[3] = v2.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = q < nv;
+                    r[q] = ok ? p[3 * q + 0] : 0.f;
+                    g[q] = ok ? p[3 * q + 1] : 0.f;
+                    b[q] = ok ? p[3 * q + 2] : 0.f;
+                }
+            }
+        } else {  // HWC4, alpha ignored (gpu_processor.py:765)
+            const float4* p4 = reinterpret_cast<const float4*>(in + (irow * W + x) * 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool ok = q < nv;
-                r[q] = ok ? p[3 * q + 0] : 0.f;
-                g[q] = ok ? p[3 * q + 1] : 0.f;
-                b[q] = ok ? p[3 * q + 2] : 0.f;
+                if (q < nv) {
+                    const float4 v = p4[q];
+                    r[q] = v.x; g[q] = v.y; b[q] = v.z;
+                } else {
+                    r[q] = g[q] = b[q] = 0.f;
+                }
             }
         }
-    } else {  // HWC4, alpha ignored (gpu_processor.py:765)
-        const float4* p4 = reinterpret_cast<const float4*>(in + (irow * W + x) * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (q < nv) {
-                const float4 v = p4[q];
-                r[q] = v.x; g[q] = v.y; b[q] = v.z;
-            } else {
-                r[q] = g[q] = b[q] = 0.f;
+            if (a.use_matrix) apply_matrix(a.mat, r[q], g[q], b[q]);
+            apply_lut2d(a.lut2d, r[q], g[q], b[q]);
+            if (a.upto >= R2F_UPTO_DENSITY) {
+                if (LDSC) {
+                    r[q] = curve_eval_at(cells_lds, a.curve, 0, log10_fast(r[q], a.log_eps));
+                    g[q] = curve_eval_at(cells_lds, a.curve, 1, log10_fast(g[q], a.log_eps));
+                    b[q] = curve_eval_at(cells_lds, a.curve, 2, log10_fast(b[q], a.log_eps));
+                } else {
+                    r[q] = log_curve(a.curve, 0, r[q], a.log_eps);
+                    g[q] = log_curve(a.curve, 1, g[q], a.log_eps);
+                    b[q] = log_curve(a.curve, 2, b[q], a.log_eps);
+                }
             }
+            if (a.upto == R2F_UPTO_OUTPUT) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[q], g[q], b[q]);
         }
+        if (a.upto == R2F_UPTO_OUTPUT)
+            emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, x, W, nv, vec, r, g, b);
+        else
+            store_planes4(a.dst, gy, x, W, nv, vec, r, g, b);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (a.use_matrix) apply_matrix(a.mat, r[q], g[q], b[q]);
-        apply_lut2d(a.lut2d, r[q], g[q], b[q]);
-        if (a.upto >= R2F_UPTO_DENSITY) {
-            r[q] = log_curve(a.curve, 0, r[q], a.log_eps);
-            g[q] = log_curve(a.curve, 1, g[q], a.log_eps);
-            b[q] = log_curve(a.curve, 2, b[q], a.log_eps);
-        }
-        if (a.upto == R2F_UPTO_OUTPUT) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[q], g[q], b[q]);
-    }
-    if (a.upto == R2F_UPTO_OUTPUT)
-        emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, x, W, nv, vec, r, g, b);
-    else
-        store_planes4(a.dst, gy, x, W, nv, vec, r, g, b);
 }
 
 // ------------------------------------------------------------------------------ lut3d
@@ -434,6 +453,7 @@ hipError_t init_kernel_attributes() {
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 1>))
     R2F_SET_LDS(tail_kernel)
+    R2F_SET_LDS(front_kernel<true>)
 #undef R2F_SET_LDS
     return hipSuccess;
 }
@@ -441,8 +461,20 @@ hipError_t init_kernel_attributes() {
 hipError_t launch_front(const FrontArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     const int quads = (a.W + 3) / 4;
-    dim3 block(64, 4), grid((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4);
-    hipLaunchKernelGGL(front_kernel, grid, block, 0, s, a);
+    const int gx = (quads + 63) / 64;
+    const int row_groups = (a.y1 - a.y0 + kFrontBY - 1) / kFrontBY;
+    dim3 block(64, kFrontBY);
+    const size_t cell_bytes = (size_t)3 * (a.curve.m > 1 ? a.curve.m - 1 : 0) * sizeof(float4);
+    const bool ldsc = a.upto >= R2F_UPTO_DENSITY && cell_bytes > 0 && cell_bytes <= 64 * 1024;
+    if (ldsc) {
+        // persistent-ish grid: ~2 blocks per CU in total, so the table copy is amortised over many rows
+        int gy = (2 * 256 + gx - 1) / gx;
+        if (gy > row_groups) gy = row_groups;
+        if (gy < 1) gy = 1;
+        hipLaunchKernelGGL(front_kernel<true>, dim3(gx, gy), block, cell_bytes, s, a);
+    } else {
+        hipLaunchKernelGGL(front_kernel<false>, dim3(gx, row_groups), block, 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -96,7 +96,8 @@ class RowShardedRenderer:
     halation / mtf / grain: which stages are enabled (the stage gates of cpu_processor.py:368,382,387)
     """
 
-    def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, group=None, rank=None, world=None):
+    def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, group=None, rank=None,
+                 world=None):
         import torch
         import torch.distributed as dist
 
@@ -110,7 +111,7 @@ class RowShardedRenderer:
         r0, r1 = shard_rows(H, world)[rank]
         ha, hb = backend.halation_taps if halation else (0, 0)
         ma, mb = backend.mtf_taps if mtf else (0, 0)
-        self.halation, self.mtf = halation, mtf
+        self.halation, self.mtf, self.grain = halation, mtf, grain
         self.plan = ShardPlan(H, W, rank, world, r0, r1, (ha, hb), (ma, mb))
         smallest = min(b - a for a, b in shard_rows(H, world))
         need = max(ha, hb, ma, mb)
@@ -179,6 +180,9 @@ class RowShardedRenderer:
         out_*: this rank's own rows of the result, (rows, W, 3)."""
         p, be = self.plan, self.backend
         H = p.H
+        if not (self.halation or self.mtf or self.grain):  # LUTs only: one fused pointwise pass
+            be.front_to_output(image_rows, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+            return out_f32, out_u8
         if not (self.halation or self.mtf):
             be.front(image_rows, p.r0, 1, self.Dplain, p.r0, p.r0, p.r1, H)
             be.tail(self.Dplain, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)

@@ -81,6 +81,10 @@ class OracleStageBackend:
         x = st.apply_lut_tetrahedral(x, self.p.lut_3d, 0.25)
         out_f32[y0 - out_gy0:y1 - out_gy0] = torch.from_numpy(x)
 
+    def front_to_output(self, image_rows, in_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
+        x = self._front(image_rows, in_gy0, 1, y0, y1)
+        out_f32[y0 - out_gy0:y1 - out_gy0] = torch.from_numpy(st.apply_lut_tetrahedral(x, self.p.lut_3d, 0.25))
+
 
 def _free_port():
     s = socket.socket()
@@ -102,7 +106,8 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
     try:
         p, img = _inputs(H, W, scale, **flags)
         be = OracleStageBackend(p)
-        rr = sharding.RowShardedRenderer(be, H, W, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None)
+        rr = sharding.RowShardedRenderer(be, H, W, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None,
+                                         grain=p.grain_lut is not None)
         r0, r1 = rr.plan.r0, rr.plan.r1
         out = torch.zeros((r1 - r0, W, 3), dtype=torch.float32)
         rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
@@ -130,6 +135,7 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
         (64, 48, 100.0, dict(mtf=False)),
         (64, 48, 160.0, dict(halation=False, grain=0)),
         (40, 32, 60.0, dict(halation=False, mtf=False)),
+        (40, 32, 60.0, dict(halation=False, mtf=False, grain=0)),  # LUTs only: fused pointwise pass
     ],
 )
 def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
