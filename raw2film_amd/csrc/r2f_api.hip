@@ -230,15 +230,20 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
         const int i_lo = box[c][0], j_lo0 = box[c][2];
         const int bh = box[c][1] - box[c][0] + 1, bw = box[c][3] - box[c][2] + 1;
         // mirror symmetry about the anchor column, bit for bit?  (needs an odd box centred on the anchor)
-        bool sym = allow_sym && !common_box && bw % 2 == 1 && bw >= 9 && s.kw / 2 - j_lo0 == (bw - 1) / 2;
-        for (int i = 0; sym && i < bh; ++i)
-            for (int j = 0; j < bw / 2; ++j) {
-                const float a = plane[(size_t)(i + i_lo) * s.kw + j_lo0 + j], b2 = plane[(size_t)(i + i_lo) * s.kw + j_lo0 + bw - 1 - j];
-                if (memcmp(&a, &b2, sizeof a) != 0) {
-                    sym = false;
-                    break;
+        auto channel_symmetric = [&](int ch) {
+            const int kcc = s.kc == 1 ? 0 : ch;
+            if (!(bw % 2 == 1 && bw >= 9 && s.kw / 2 - j_lo0 == (bw - 1) / 2)) return false;
+            for (int i = 0; i < bh; ++i)
+                for (int j = 0; j < bw / 2; ++j) {
+                    const float a = s.host[((size_t)(i + i_lo) * s.kw + j_lo0 + j) * s.kc + kcc];
+                    const float b2 = s.host[((size_t)(i + i_lo) * s.kw + j_lo0 + bw - 1 - j) * s.kc + kcc];
+                    if (memcmp(&a, &b2, sizeof a) != 0) return false;
                 }
-            }
+            return true;
+        };
+        bool sym = allow_sym && channel_symmetric(c);
+        if (sym && common_box)  // shared geometry (grain): pair taps only if every channel allows it
+            sym = channel_symmetric(0) && channel_symmetric(1) && channel_symmetric(2);
         // virtual stencil: the cropped box, widened by one zero column per side when sym needs an even r
         const int pad = (sym && ((bw - 1) / 2) % 2 == 1) ? 1 : 0;
         const int vkw = bw + 2 * pad, vkh = bh;

@@ -378,7 +378,10 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 #pragma unroll
             for (int p = 0; p < 4; ++p) G[c][j][p] = (float2v){0.f, 0.f};
         const float* plane = smem + (mono ? 0 : c * plane_sz);
-        stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
+        if (a.gk[c].sym)
+            stencil_accumulate_sym<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
+        else
+            stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
     }
 
     const int gx = tile_x0 + 4 * tx;
