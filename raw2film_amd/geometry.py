@@ -1,0 +1,99 @@
+"""Host-side frame geometry on either side of the render path: aspect crop / zoom / quarter turns
+before it, canvas (letterbox border) after it.  Pure index arithmetic, pinned against the
+reference's own functions through tests/golden/geometry.npz.
+
+  crop_box / crop_to_frame   <->  effects.crop_image, raw_conversion.crop_rotate_zoom   effects.py:77-111, raw_conversion.py:56-72
+  canvas_layout / add_canvas <->  effects.get_canvas_data, effects.add_canvas            effects.py:290-357
+
+Free rotation by an arbitrary angle (effects.rotate -> cv.warpAffine) is NOT provided here: it is an
+interpolating resample that belongs to the pre-path rows SURVEY.md 8f lists as "next".
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+CANVAS_MODES = ("No", "Proportional white", "Proportional black", "Uniform white", "Uniform black", "Fixed white", "Fixed black")
+
+
+def crop_box(rows: int, cols: int, zoom: float = 1, aspect: float = 1.5, flip: bool = False) -> tuple[int, int, int, int]:
+    """(row0, col0, n_rows, n_cols) that effects.crop_image keeps (effects.py:77-111).
+
+    The longer side is matched to `aspect` (inverted when `flip`), centred with ceil() at both ends;
+    then `zoom` > 1 trims ceil((zoom-1)/(2 zoom) * extent) from every side."""
+    if flip:
+        aspect = 1 / aspect
+    r0, r1, c0, c1 = 0, rows, 0, cols
+    if rows > cols:
+        if rows > aspect * cols:
+            r0, r1 = math.ceil(rows / 2 - cols * aspect / 2), math.ceil(rows / 2 + cols * aspect / 2)
+        else:
+            c0, c1 = math.ceil(cols / 2 - rows / aspect / 2), math.ceil(cols / 2 + rows / aspect / 2)
+    elif cols > aspect * rows:
+        c0, c1 = math.ceil(cols / 2 - rows * aspect / 2), math.ceil(cols / 2 + rows * aspect / 2)
+    else:
+        r0, r1 = math.ceil(rows / 2 - cols / aspect / 2), math.ceil(rows / 2 + cols / aspect / 2)
+    r0, c0 = max(r0, 0), max(c0, 0)
+    r1, c1 = min(r1, rows), min(c1, cols)
+    if zoom > 1:
+        f = (zoom - 1) / (2 * zoom)
+        tr, tc = math.ceil(f * (r1 - r0)), math.ceil(f * (c1 - c0))
+        r0, r1, c0, c1 = r0 + tr, r1 - tr, c0 + tc, c1 - tc
+    return r0, c0, r1 - r0, c1 - c0
+
+
+def crop_to_frame(image: np.ndarray, frame_width: float = 36, frame_height: float = 24, zoom: float = 1.0,
+                  rotate_times: int = 0, flip: bool = False) -> np.ndarray:
+    """raw_conversion.crop_rotate_zoom without the free rotation: aspect crop (honouring `flip`), zoom crop at
+    the frame aspect, then `rotate_times` quarter turns (raw_conversion.py:66-70)."""
+    aspect = frame_width / frame_height
+    r0, c0, nr, nc = crop_box(image.shape[0], image.shape[1], 1, aspect, flip)
+    image = image[r0:r0 + nr, c0:c0 + nc]
+    r0, c0, nr, nc = crop_box(image.shape[0], image.shape[1], zoom, aspect, False)
+    image = image[r0:r0 + nr, c0:c0 + nc]
+    return np.rot90(image, k=rotate_times)
+
+
+def canvas_layout(shape, canvas_mode: str, canvas_scale: float = 1.0, canvas_ratio: float = 1.0):
+    """((out_rows, out_cols), (r, g, b), (row_offset, col_offset)) of effects.get_canvas_data (effects.py:290-333).
+    "Proportional" replaces the ratio by the image's own (so it always takes the second branch), "Fixed" uses
+    `canvas_ratio`, "Uniform" adds int(max_side * (scale - 1)) to both sides."""
+    rows, cols = int(shape[0]), int(shape[1])
+    color = (255, 255, 255) if "white" in canvas_mode else (0, 0, 0) if "black" in canvas_mode else (128, 128, 128)
+    if "Uniform" in canvas_mode:
+        border = int(max(rows, cols) * (canvas_scale - 1))
+        out = (rows + border, cols + border)
+    elif "Proportional" in canvas_mode or "Fixed" in canvas_mode:
+        ratio = cols / rows if "Proportional" in canvas_mode else canvas_ratio
+        if cols / rows > ratio:
+            out = (int(cols / ratio * canvas_scale), int(cols * canvas_scale))
+        else:
+            out = (int(rows * canvas_scale), int(rows * ratio * canvas_scale))
+    else:
+        raise ValueError(f"unknown canvas mode {canvas_mode!r}")
+    offset = ((out[0] - rows) // 2, (out[1] - cols) // 2)
+    return out, color, offset
+
+
+def add_canvas(image, canvas_mode: str, canvas_scale: float = 1.0, canvas_ratio: float = 1.0):
+    """effects.add_canvas (effects.py:336-357) for a uint8 (H, W, 3) NumPy array or torch tensor (any device):
+    the frame pasted at `offset` onto a canvas of the mode's colour."""
+    if canvas_mode == "No":
+        return image
+    out, color, (oy, ox) = canvas_layout(image.shape, canvas_mode, canvas_scale, canvas_ratio)
+    h, w = int(image.shape[0]), int(image.shape[1])
+    if oy < 0 or ox < 0:
+        raise ValueError("canvas smaller than the frame (canvas_scale < 1)")
+    if isinstance(image, np.ndarray):
+        canvas = np.empty((out[0], out[1], 3), dtype=np.uint8)
+        canvas[...] = np.asarray(color, dtype=np.uint8)
+        canvas[oy:oy + h, ox:ox + w] = image
+        return canvas
+    import torch
+
+    canvas = torch.empty((out[0], out[1], 3), dtype=torch.uint8, device=image.device)
+    canvas[...] = torch.tensor(color, dtype=torch.uint8, device=image.device)
+    canvas[oy:oy + h, ox:ox + w] = image
+    return canvas

@@ -5,12 +5,13 @@ Mirrors `CpuProcessor.process` (cpu_processor.py:269-414) / `GpuProcessor.proces
 keyword names and defaults, unknown keywords swallowed, LUTs / stencils rebuilt and
 re-uploaded only when their parameter dict changes (cpu_processor.py:104-105,157-158,...).
 
-Scope: the post-decode per-pixel path.  RAW decoding, lens correction, crop/rotate/zoom,
-chroma NR, the `max_scale` resize, canvas and highlight burn belong to the rows SURVEY.md
-section 8f lists as "next"; asking for them raises NotImplementedError instead of silently
-rendering something else.  `src` is therefore a decoded frame: a float32 (H, W, 3|4) array /
-CUDA tensor in linear CIE XYZ (what `raw_to_linear` returns, raw_conversion.py:33-53), or the
-path of a `.npy` file holding one.
+Scope: the post-decode per-pixel path, plus the index-only geometry around it (aspect crop, zoom,
+quarter turns before; canvas after).  RAW decoding, lens correction, free rotation, chroma NR, the
+`max_scale` resize and highlight burn belong to the rows SURVEY.md section 8f lists as "next";
+asking for them raises NotImplementedError instead of silently rendering something else.
+
+`src` is therefore a decoded frame: a float32 (H, W, 3|4) array / CUDA tensor in linear CIE XYZ
+(what `raw_to_linear` returns, raw_conversion.py:33-53), or the path of a `.npy` file holding one.
 """
 
 from __future__ import annotations
@@ -19,7 +20,7 @@ import random
 
 import numpy as np
 
-from . import _lib, filmstock, stencils
+from . import _lib, filmstock, geometry, stencils
 from .context import LOG_EPS, LUT3D_SCALE, HipContext
 
 REC709_TO_XYZ = np.array(  # data.py:128-135
@@ -155,10 +156,14 @@ class HipProcessor:
         """PHASE 1 of the two-phase batch API (gpu_processor.py:715-783): pure host work, touches
         no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32."""
         image = self._load_decoded(src)
-        if rotation or zoom != 1.0 or rotate_times or chroma_nr or canvas_mode != "No":
+        if rotation:
             raise NotImplementedError(
-                "crop/rotate/zoom, chroma NR and canvas are outside the accelerated path (SURVEY.md section 8f)"
+                "free rotation (effects.rotate -> cv.warpAffine) is outside the accelerated path (SURVEY.md section 8f)"
             )
+        if chroma_nr:
+            raise NotImplementedError("chroma NR is outside the accelerated path (SURVEY.md section 8f)")
+        # aspect crop / zoom / quarter turns: index arithmetic of raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72)
+        image = geometry.crop_to_frame(image, frame_width, frame_height, zoom, rotate_times, flip)
         h, w = image.shape[:2]
         if resolution is not None and tuple(resolution) != (h, w):
             raise NotImplementedError("pre-path resolution scaling is outside the accelerated path (SURVEY.md section 8f)")
@@ -167,13 +172,17 @@ class HipProcessor:
                 f"frame is finer than max_scale={max_scale} px/mm; the reference down-scales first "
                 "(cpu_processor.py:128-134), which is outside the accelerated path"
             )
+        canvas_res = None
+        if canvas_mode != "No":  # gpu_processor.py:767-771
+            res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
+            canvas_res = (res[1], res[0])
         if image.shape[2] == 3:
             image = np.concatenate([image, np.ones_like(image[..., :1])], axis=-1)  # gpu_processor.py:765
         image = np.ascontiguousarray(image, dtype=np.float32)
         return {
             "image_array": image,
             "output_resolution": (w, h),
-            "canvas_resolution": None,
+            "canvas_resolution": canvas_res,
             "pipeline_resolution": (w, h),
         }
 
@@ -223,6 +232,7 @@ class HipProcessor:
             halation_size=halation_size, halation_green_factor=halation_green_factor, sharpness=sharpness,
             sharpening_strength=sharpening_strength, sharpening_sigma=sharpening_sigma, grain=grain,
             highlight_burn=highlight_burn, burn_scale=burn_scale, color_masking=color_masking, seed=seed,
+            canvas_mode=canvas_mode, canvas_scale=canvas_scale, canvas_ratio=canvas_ratio,
         )
 
     def process_preloaded(self, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture=None,
@@ -237,6 +247,9 @@ class HipProcessor:
         image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,
                                            **settings)
+        # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic
+        out_u8 = geometry.add_canvas(out_u8, settings.get("canvas_mode", "No"), settings.get("canvas_scale", 1.0),
+                                     settings.get("canvas_ratio", 1.0))
         return out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
 
     def process_array(self, image, negative_film, grain_size=6, grain_sigma=0.4, *, colorspace="XYZ", seed=None,

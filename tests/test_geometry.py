@@ -1,0 +1,48 @@
+"""Host-side crop / canvas arithmetic vs vectors made by the reference's own crop_image / get_canvas_data."""
+
+import os
+
+import numpy as np
+import pytest
+
+from raw2film_amd import geometry
+
+
+@pytest.fixture(scope="module")
+def geo(golden_dir):
+    return np.load(os.path.join(golden_dir, "geometry.npz"))
+
+
+def test_crop_box_matches_reference(geo):
+    for (h, w, aspect, zoom, flip), box in zip(geo["crop_cases"], geo["crop_boxes"]):
+        got = geometry.crop_box(int(h), int(w), zoom=float(zoom), aspect=float(aspect), flip=bool(flip))
+        assert got == tuple(int(v) for v in box), (h, w, aspect, zoom, flip)
+
+
+def test_canvas_layout_matches_reference(geo):
+    modes = [str(m) for m in geo["canvas_modes"]]
+    for (h, w, mi, scale, ratio), out in zip(geo["canvas_cases"], geo["canvas_out"]):
+        res, color, off = geometry.canvas_layout((int(h), int(w), 3), modes[int(mi)], float(scale), float(ratio))
+        assert (res[0], res[1], *color, off[0], off[1]) == tuple(int(v) for v in out)
+
+
+def test_add_canvas_numpy_and_torch_agree():
+    torch = pytest.importorskip("torch")
+    img = np.random.default_rng(0).integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    a = geometry.add_canvas(img, "Uniform black", 1.2)
+    b = geometry.add_canvas(torch.from_numpy(img), "Uniform black", 1.2).numpy()
+    np.testing.assert_array_equal(a, b)
+    out, color, (oy, ox) = geometry.canvas_layout(img.shape, "Uniform black", 1.2)
+    assert a.shape == (out[0], out[1], 3) and a[0, 0, 0] == 0 and color == (0, 0, 0)
+    np.testing.assert_array_equal(a[oy:oy + 40, ox:ox + 60], img)
+    assert geometry.add_canvas(img, "No") is img
+    white = geometry.add_canvas(img, "Fixed white", 1.0, 1.0)
+    assert white.shape == (60, 60, 3) and white[0, 0, 0] == 255
+
+
+def test_crop_to_frame_quarter_turns():
+    img = np.arange(400 * 600 * 3, dtype=np.float32).reshape(400, 600, 3)
+    out = geometry.crop_to_frame(img, 36, 24, zoom=1.0, rotate_times=1)
+    assert out.shape == (600, 400, 3)
+    sq = geometry.crop_to_frame(img, 56, 56)
+    assert sq.shape == (400, 400, 3) and sq[0, 0, 0] == img[0, 100, 0]

@@ -1,0 +1,104 @@
+"""The HipProcessor operator surface on a real GPU: process / extract_image_data_cpu / process_preloaded /
+process_array against the oracle, with the reference's keyword names."""
+
+import numpy as np
+import pytest
+
+from oracle import stages as st
+
+from helpers import SEED, oracle_inputs, stocks, synthetic_frame
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def proc():
+    from raw2film_amd import HipProcessor
+
+    p = HipProcessor(cameras={}, lenses={}, device=0)
+    yield p
+    p.close()
+
+
+def _xyz(H, W, seed=41):
+    return st.apply_matrix3x3(synthetic_frame(H, W, seed=seed), st.REC709_TO_XYZ)
+
+
+def _u8_close(a, b):
+    d = np.abs(a.astype(int) - b.astype(int))
+    return d.max() <= 1 and (d > 0).mean() <= 2e-3
+
+
+def test_process_returns_uint8_like_the_cpu_processor(proc):
+    neg, prt, _ = stocks()
+    H, W, fw = 120, 180, 1.0
+    img = _xyz(H, W)
+    kw = dict(print_film=prt, frame_width=fw, frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000,
+              color_masking=1.0, seed=SEED, profile="Default", film_format="135")  # GUI extras are swallowed
+    out = proc.process(img, neg, 6, 0.4, **kw)
+    assert out.dtype == np.uint8 and out.shape == (H, W, 3)
+    p = oracle_inputs(neg, prt, max(H, W) / fw, matrix=False)
+    assert _u8_close(out, st.to_uint8(st.render(img, p)))
+    # two-phase batch API gives the same bytes
+    payload = proc.extract_image_data_cpu(img, frame_width=fw, frame_height=fw * H / W)
+    assert payload["image_array"].shape == (H, W, 4)
+    out2 = proc.process_preloaded(payload, neg, 6, 0.4, **kw)
+    np.testing.assert_array_equal(out, out2)
+
+
+def test_process_array_float_and_colorspace(proc):
+    neg, prt, _ = stocks()
+    H, W, fw = 96, 128, 0.6
+    rgb = synthetic_frame(H, W, seed=42)
+    kw = dict(print_film=prt, frame_width=fw, frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000,
+              color_masking=1.0, seed=SEED)
+    out = proc.process_array(rgb, neg, 6, 0.4, colorspace="linear-rec709", return_float=True, **kw)
+    ref = st.render(rgb, oracle_inputs(neg, prt, max(H, W) / fw))
+    assert out.dtype == np.float32
+    assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 0.1)) <= 1e-5
+    dev = proc.process_array(torch.from_numpy(rgb).cuda(), neg, 6, 0.4, colorspace="linear-rec709", return_float=True,
+                             output="device", **kw)
+    assert dev.is_cuda
+    np.testing.assert_array_equal(dev.cpu().numpy(), out)
+
+
+def test_stage_gates_and_negative_only(proc):
+    neg, _, _ = stocks()
+    H, W = 64, 96
+    img = _xyz(H, W, seed=43)
+    out = proc.process(img, neg, 6, 0.4, print_film=None, halation=False, sharpness=False, grain=0, exp_kelvin=6000,
+                       color_masking=1.0)
+    p = oracle_inputs(neg, None, max(H, W) / 36, halation=False, mtf=False, grain=0, matrix=False)
+    assert _u8_close(out, st.to_uint8(st.render(img, p)))
+    mono = proc.process(img, neg, 6, 0.4, print_film=None, halation=False, sharpness=False, grain=1, seed=7,
+                        frame_width=0.375, frame_height=0.25, exp_kelvin=6000, color_masking=1.0)
+    pm = oracle_inputs(neg, None, max(H, W) / 0.375, halation=False, mtf=False, grain=1, seed=7, matrix=False)
+    assert _u8_close(mono, st.to_uint8(st.render(img, pm)))
+
+
+def test_crop_zoom_turn_and_canvas(proc):
+    from raw2film_amd import geometry
+
+    neg, prt, _ = stocks()
+    img = _xyz(100, 180, seed=44)
+    kw = dict(print_film=prt, halation=False, sharpness=False, grain=0, exp_kelvin=6000, color_masking=1.0,
+              frame_width=36, frame_height=24)
+    out = proc.process(img, neg, 6, 0.4, zoom=1.5, rotate_times=1, canvas_mode="Uniform white", canvas_scale=1.25, **kw)
+    pre = np.ascontiguousarray(geometry.crop_to_frame(img, 36, 24, 1.5, 1, False))
+    p = oracle_inputs(neg, prt, max(pre.shape[:2]) / 36, halation=False, mtf=False, grain=0, matrix=False)
+    ref = geometry.add_canvas(st.to_uint8(st.render(pre, p)), "Uniform white", 1.25)
+    assert out.shape == ref.shape and out[0, 0, 0] == 255
+    assert _u8_close(out, ref)
+
+
+def test_uploads_happen_only_on_change(proc):
+    neg, prt, _ = stocks()
+    img = _xyz(48, 64, seed=45)
+    kw = dict(print_film=prt, exp_kelvin=6000, color_masking=1.0, frame_width=0.5, frame_height=0.375, seed=1)
+    proc.process(img, neg, 6, 0.4, **kw)
+    n = proc.uploads
+    proc.process(img, neg, 6, 0.4, **kw)
+    assert proc.uploads == n
+    proc.process(img, neg, 6, 0.4, **{**kw, "halation_size": 1.5})
+    assert proc.uploads == n + 1

@@ -120,6 +120,16 @@ def test_out_of_scope_requests_raise(proc):
         proc.process(img, neg, 6, 0.4, dst_texture=object())
 
 
+def test_extract_crops_zooms_turns_and_reports_canvas(proc):
+    img = np.random.default_rng(1).uniform(0, 1, (400, 640, 3)).astype(np.float32)
+    p = proc.extract_image_data_cpu(img, frame_width=36, frame_height=24, zoom=2.0, rotate_times=1, canvas_mode="Uniform white",
+                                    canvas_scale=1.1, max_scale=None)
+    assert p["pipeline_resolution"] == (p["image_array"].shape[1], p["image_array"].shape[0])
+    assert p["image_array"].shape[0] > p["image_array"].shape[1]  # quarter turn of a landscape crop
+    w, h = p["pipeline_resolution"]
+    assert p["canvas_resolution"] == (w + int(max(h, w) * 0.1), h + int(max(h, w) * 0.1)) or p["canvas_resolution"][0] > w
+
+
 def test_extract_image_data_cpu_payload(proc):
     img = np.full((40, 60, 3), 70000.0, np.float32)
     payload = proc.extract_image_data_cpu(img)

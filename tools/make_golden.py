@@ -11,6 +11,7 @@ What is executed (imported from /root/reference/src, nothing is copied):
   raw2film.effects.compute_halation_kernel        effects.py:239-263
   raw2film.effects.compute_kernel_from_function   effects.py:123-143
   raw2film.effects.mtf_kernel_layer / mtf_kernel  effects.py:159-185
+  raw2film.effects.crop_image / get_canvas_data   effects.py:77-111, 290-333
 
 Third-party modules that are absent from this image are replaced by inert stubs
 (SURVEY.md appendix A).  The only stub with a body is `numba.njit` (identity
@@ -212,7 +213,34 @@ def main():
     mtf["ckf_args"] = np.array(ckf)
     np.savez_compressed(os.path.join(OUT_DIR, "mtf_kernels.npz"), **mtf)
 
-    for name in ("tetrahedral", "halation_kernels", "mtf_kernels"):
+    # ---- 4. host-side geometry of the rows next to the path: crop_image, get_canvas_data ----
+    geo = {}
+    crop_cases, crop_boxes = [], []
+    for (h, w) in ((400, 600), (600, 400), (333, 517), (512, 512), (1000, 300)):
+        for aspect in (1.5, 1.0, 65 / 24, 24 / 36):
+            for zoom in (1, 1.3, 2.5):
+                for flip in (False, True):
+                    idx = np.arange(h * w, dtype=np.int64).reshape(h, w, 1)
+                    out = ref_effects.crop_image(idx, zoom=zoom, aspect=aspect, flip=flip)
+                    y0, x0 = divmod(int(out[0, 0, 0]), w)
+                    crop_cases.append((h, w, aspect, zoom, float(flip)))
+                    crop_boxes.append((y0, x0, out.shape[0], out.shape[1]))
+    geo["crop_cases"] = np.array(crop_cases)
+    geo["crop_boxes"] = np.array(crop_boxes)
+    canvas_cases, canvas_out = [], []
+    modes = ["Proportional white", "Proportional black", "Uniform white", "Uniform black", "Fixed white", "Fixed black"]
+    for (h, w) in ((400, 600), (600, 400), (4000, 6000), (512, 512)):
+        for mi, mode in enumerate(modes):
+            for scale, ratio in ((1.0, 1.0), (1.1, 0.8), (1.25, 1.5)):
+                res, color, off = ref_effects.get_canvas_data((h, w, 3), mode, scale, ratio)
+                canvas_cases.append((h, w, mi, scale, ratio))
+                canvas_out.append((res[0], res[1], color[0], color[1], color[2], off[0], off[1]))
+    geo["canvas_modes"] = np.array(modes)
+    geo["canvas_cases"] = np.array(canvas_cases)
+    geo["canvas_out"] = np.array(canvas_out)
+    np.savez_compressed(os.path.join(OUT_DIR, "geometry.npz"), **geo)
+
+    for name in ("tetrahedral", "halation_kernels", "mtf_kernels", "geometry"):
         p = os.path.join(OUT_DIR, name + ".npz")
         print(f"{p}: {os.path.getsize(p) / 1024:.0f} KiB")
 
