@@ -342,20 +342,21 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     if (W <= 0 || H <= 0 || y0 < 0 || y1 > H) return fail(ctx, R2F_EINVAL, "stencil: bad geometry");
     StencilSet& set = ctx->stencil[which];
     if (!set.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
-    // choose the tile variant: the widest tile whose rows fit the LDS budget and the fill's 256-float row limit
+    // choose the tile variant and LDS budget: the widest tile whose rows fit; wide stencils fall back to the
+    // narrow tile and, if need be, to one workgroup per CU (the whole 160 KB)
     int variant = -1;
-    const size_t budget = (size_t)ctx->opt_lds_kb * 1024;
-    for (int v = 0; v < kNumStencilVariants; ++v) {
-        if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
-        const StencilVariant& sv = kStencilVariants[v];
-        int rc = ensure_stencil(ctx, which, sv.Q, sv.TW(), sv.TH(), budget, false);
-        if (rc == R2F_ETOOLARGE) continue;
-        if (rc) return rc;
-        bool ok = stencil_lds_bytes(sv, set.dev, 3) <= kMaxLds;
-        for (int c = 0; c < 3; ++c) ok = ok && set.dev[c].RS <= 256;
-        if (ok) {
-            variant = v;
-            break;
+    const size_t budgets[2] = {(size_t)ctx->opt_lds_kb * 1024, kMaxLds};
+    for (int b = 0; b < 2 && variant < 0; ++b) {
+        for (int v = 0; v < kNumStencilVariants; ++v) {
+            if (ctx->opt_variant >= 0 && v != ctx->opt_variant) continue;
+            const StencilVariant& sv = kStencilVariants[v];
+            int rc = ensure_stencil(ctx, which, sv.Q, sv.TW(), sv.TH(), budgets[b], false);
+            if (rc == R2F_ETOOLARGE) continue;
+            if (rc) return rc;
+            if (stencil_lds_bytes(sv, set.dev, 3) <= kMaxLds) {
+                variant = v;
+                break;
+            }
         }
     }
     if (variant < 0) return fail(ctx, R2F_ETOOLARGE, "stencil %d: %dx%d taps do not fit an LDS tile", which, set.kh, set.kw);

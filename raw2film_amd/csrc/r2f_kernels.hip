@@ -240,40 +240,40 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 template <int NT>
 __device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, int cols_valid, const float* src,
                                                   int src_gy0, int src_rows, int W, int H_global, int ty0, int tx0) {
-    constexpr int NW = NT / 64, KR = 4, KC = 4;  // KC * 64 >= RS is required (checked on the host: RS <= 256)
+    constexpr int NW = NT / 64, KR = 4, KC = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int sx[KC];
+    for (int cb = 0; cb < RS; cb += 64 * KC) {  // column blocks of 256 (one pass for stencils up to 128 taps wide)
+        int sx[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) sx[k] = reflect101(tx0 + lane + 64 * k, W);
-    for (int r0 = wave * KR; r0 < rows; r0 += NW * KR) {
-        float v[KR][KC];
+        for (int k = 0; k < KC; ++k) sx[k] = reflect101(tx0 + cb + lane + 64 * k, W);
+        for (int r0 = wave * KR; r0 < rows; r0 += NW * KR) {
+            float v[KR][KC];
 #pragma unroll
-        for (int i = 0; i < KR; ++i) {
-            int sy = reflect101(ty0 + r0 + i, H_global) - src_gy0;
-            sy = clampi(sy, 0, src_rows - 1);  // only rows feeding discarded outputs can fall outside
-            const float* srow = src + (long long)sy * W;
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                const int c = lane + 64 * k;
-                v[i][k] = (c < cols_valid && r0 + i < rows) ? srow[sx[k]] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < KR; ++i) {
-            if (r0 + i < rows) {
-                float* drow = lds + (r0 + i) * RS;
+            for (int i = 0; i < KR; ++i) {
+                int sy = reflect101(ty0 + r0 + i, H_global) - src_gy0;
+                sy = clampi(sy, 0, src_rows - 1);  // only rows feeding discarded outputs can fall outside
+                const float* srow = src + (long long)sy * W;
 #pragma unroll
                 for (int k = 0; k < KC; ++k) {
-                    const int c = lane + 64 * k;
-                    if (c < RS) drow[c] = v[i][k];
+                    const int c = cb + lane + 64 * k;
+                    v[i][k] = (c < cols_valid && r0 + i < rows) ? srow[sx[k]] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                if (r0 + i < rows) {
+                    float* drow = lds + (r0 + i) * RS;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int c = cb + lane + 64 * k;
+                        if (c < RS) drow[c] = v[i][k];
+                    }
                 }
             }
         }
     }
 }
 
-// EPI: 0 = plain stencil (S5 MTF, tests), 1 = + S3 log + S4 density curve (S2 halation).  A template
-// parameter rather than a runtime flag so that the two stages show up as two kernels in profiles.
 template <int BX, int BY, int Q, int EPI>
 __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -141,33 +141,38 @@ class RowShardedRenderer:
         # single-GPU validation) is a host transport: stage through host memory explicitly.
         host_staging = buf.is_cuda and dist.get_backend(self.group) == "gloo"
 
-        def outgoing(t):
-            t = t.contiguous()
-            return t.cpu() if host_staging else t
+        # A halo is `n` consecutive rows of each of the 3 planes: 3 contiguous blocks.  On RCCL they are sent
+        # from / received into the plane buffer directly (no staging copies); on gloo through host tensors.
+        def add_send(row, n, peer):
+            for c in range(3):
+                block = buf[c, row:row + n, :]
+                ops.append(dist.P2POp(dist.isend, block.cpu() if host_staging else block, peer, self.group))
 
-        def incoming(rows):
-            return torch.empty((3, rows, p.W), dtype=buf.dtype, device="cpu" if host_staging else buf.device)
+        def add_recv(row, n, peer):
+            for c in range(3):
+                block = buf[c, row:row + n, :]
+                if host_staging:
+                    tmp = torch.empty((n, p.W), dtype=buf.dtype, device="cpu")
+                    ops.append(dist.P2POp(dist.irecv, tmp, peer, self.group))
+                    recvs.append((tmp, block))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, block, peer, self.group))
 
         if p.rank > 0:  # neighbour above: it needs my top `below` rows, I need its bottom `above` rows
             if below:
-                ops.append(dist.P2POp(dist.isend, outgoing(buf[:, own0:own0 + below, :]), self._peer(p.rank - 1), self.group))
+                add_send(own0, below, self._peer(p.rank - 1))
             if above:
-                recv = incoming(above)
-                ops.append(dist.P2POp(dist.irecv, recv, self._peer(p.rank - 1), self.group))
-                recvs.append((recv, own0 - above))
+                add_recv(own0 - above, above, self._peer(p.rank - 1))
         if p.rank < p.world - 1:  # neighbour below
             if above:
-                ops.append(dist.P2POp(dist.isend, outgoing(buf[:, own0 + p.rows - above:own0 + p.rows, :]),
-                                      self._peer(p.rank + 1), self.group))
+                add_send(own0 + p.rows - above, above, self._peer(p.rank + 1))
             if below:
-                recv = incoming(below)
-                ops.append(dist.P2POp(dist.irecv, recv, self._peer(p.rank + 1), self.group))
-                recvs.append((recv, own0 + p.rows))
+                add_recv(own0 + p.rows, below, self._peer(p.rank + 1))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for recv, row in recvs:
-            buf[:, row:row + recv.shape[1], :].copy_(recv)
+        for tmp, block in recvs:
+            block.copy_(tmp)
 
     def _peer(self, group_rank: int) -> int:
         if self.group is None:

@@ -137,6 +137,22 @@ def test_generic_stencil_reflect101(ctx, shape, ksize):
     assert_close(from_planes(dst), ref, 1e-5, 1e-3, f"stencil {ksize}")
 
 
+@pytest.mark.parametrize("ksize", [173, 301])
+def test_very_wide_stencils_fall_back_to_narrow_tiles(ctx, ksize):
+    """halation_size / sharpening can ask for stencils far wider than a 128-px tile row in LDS: the narrow tile
+    variant and, beyond that, the one-workgroup-per-CU budget take over; results stay exact."""
+    rng = np.random.default_rng(ksize)
+    H, W = 70, 90
+    img = rng.uniform(0.0, 2.0, (H, W, 3)).astype(np.float32)
+    k = ok.exponential_blur_kernel(float(ksize - 1)).astype(np.float32)
+    assert k.shape == (ksize, ksize)
+    ref = st.convolve_2d(img, k)
+    ctx.set_kernel(1, k)
+    src, dst = to_planes(img), torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_stencil(1, src, dst, y0=0, y1=H, H_global=H)
+    assert_close(from_planes(dst), ref, 1e-5, 1e-3, f"wide stencil {ksize}")
+
+
 def test_stencil_non_square_and_even_sizes(ctx):
     rng = np.random.default_rng(11)
     img = rng.uniform(0.0, 1.0, (40, 72, 3)).astype(np.float32)
