@@ -370,3 +370,58 @@ def test_errors_are_reported(ctx):
     with pytest.raises(ValueError):
         c.set_curve1d(np.zeros((3, 8), np.float32))
     c.close()
+
+
+# ------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 7), (9, 129), (130, 5)])
+def test_tiny_and_ragged_frames_full_pipeline(ctx, shape):
+    """Frames smaller than any tile, than every stencil, and with widths that defeat the float4 paths."""
+    neg, prt, _ = stocks()
+    H, W = shape
+    p = oracle_inputs(neg, prt, 120.0)  # 31-tap halation, 13-tap MTF, grain on
+    img = synthetic_frame(H, W, seed=50 + H)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    out, u8 = ctx.render(dev(img), params, want_f32=True, want_u8=True)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, f"tiny frame {shape}")
+    assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1
+
+
+def test_black_frame_and_speculars(ctx):
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 200.0)
+    params = setup_ctx(ctx, p)
+    black = np.zeros((40, 56, 3), np.float32)  # S < 1e-12 everywhere: exposure 0, log clipped at 1e-6
+    out, _ = ctx.render(dev(black), params)
+    assert_close(out.cpu().numpy(), st.render(black, p), 1e-5, 1e-1, "black frame")
+    hot = synthetic_frame(64, 96, seed=61)
+    hot[10, 20] = 65504.0  # the largest value the decode path lets through (gpu_processor.py:275)
+    hot[40:43, 60:63] = 4000.0
+    out, _ = ctx.render(dev(hot), params)
+    assert_close(out.cpu().numpy(), st.render(hot, p), 1e-5, 1e-1, "speculars")
+
+
+def test_empty_row_range_is_a_no_op_and_empty_frame_is_an_error(ctx):
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0)
+    params = setup_ctx(ctx, p)
+    E = torch.zeros((3, 8, 16), dtype=torch.float32, device="cuda")
+    D = torch.full((3, 8, 16), -1.0, dtype=torch.float32, device="cuda")
+    ctx.stage_halation(E, D, params, y0=3, y1=3, H_global=8)
+    assert float(D.min()) == -1.0 and float(D.max()) == -1.0
+    with pytest.raises(ValueError):
+        ctx.stage_halation(E, D, params, y0=0, y1=9, H_global=8)  # rows outside the frame
+    small = torch.zeros((3, 4, 16), dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError, match="not inside"):
+        ctx.stage_mtf(small, D, params, src_gy0=0, dst_gy0=0, y0=0, y1=8, H_global=8)  # source rows missing
+
+
+def test_uint8_only_output(ctx):
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 150.0)
+    img = synthetic_frame(72, 100, seed=62)
+    params = setup_ctx(ctx, p)
+    f32, u8 = ctx.render(dev(img), params, want_f32=False, want_u8=True)
+    assert f32 is None and u8.dtype == torch.uint8
+    d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(st.render(img, p)).astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-3
