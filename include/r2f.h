@@ -51,7 +51,8 @@ enum {
     R2F_F_HALATION = 1u << 1, /* S2 */
     R2F_F_MTF = 1u << 2,      /* S5 */
     R2F_F_GRAIN = 1u << 3,    /* S6 (+ the clip of cpu_processor.py:397) */
-    R2F_F_GRAIN_MONO = 1u << 4 /* grain == 1: noise_bw.wgsl */
+    R2F_F_GRAIN_MONO = 1u << 4, /* grain == 1: noise_bw.wgsl */
+    R2F_F_BURN = 1u << 5        /* S7 highlight burn (effects.py:396-418), needs burn_* below */
 };
 
 /* `upto` of r2f_stage_front */
@@ -63,7 +64,9 @@ typedef struct r2f_params {
     float log_eps;      /* lut_1d.wgsl:24 -> 1e-6 */
     float lut3d_scale;  /* cpu_processor.py:405 -> 0.25 */
     int32_t lut3d_mode; /* 0 tetrahedral (utils.py:247, the parity target), 1 trilinear (lut_3d.wgsl) */
-    int32_t reserved;
+    int32_t burn_cell;  /* S7: ceil(min(H, W) / burn_scale), the shrink factor of effects.down_up_blur (effects.py:365) */
+    float burn_strength; /* S7: highlight_burn */
+    float burn_d_ref;    /* S7: negative_film.d_ref[1] (or [0]), effects.py:406 */
 } r2f_params;
 
 /* Three fp32 planes holding global rows [gy0, gy0+rows) of a frame, W floats per row. */
@@ -121,9 +124,23 @@ int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* expo
 /* S5 MTF stencil on density -> density planes. */
 int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
                   int y0, int y1, int W, int H_global, void* stream);
-/* [S6 grain + clip] + S8 3-D LUT (+ S9 uint8 truncation) -> interleaved output. */
-int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* out_f32_hwc,
-                   uint8_t* out_u8_hwc, int out_gy0, int y0, int y1, int W, int H_global, void* stream);
+/* [S6 grain + clip] + [S7 burn subtract + clip, when burn_map != NULL] + S8 3-D LUT (+ S9 uint8 truncation)
+ * -> interleaved output.  With a burn map the grain (if any) must already have been applied by r2f_stage_grain. */
+int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const float* burn_map,
+                   float* out_f32_hwc, uint8_t* out_u8_hwc, int out_gy0, int y0, int y1, int W, int H_global,
+                   void* stream);
+/* S6 grain + clip alone, density planes -> density planes (the first half of the tail when S7 is on: the burn map
+ * is a function of the WHOLE grained frame, so the frame has to exist before any pixel can be finished). */
+int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
+                    int y0, int y1, int W, int H_global, void* stream);
+/* S7 part 1: area-weighted (cv.resize INTER_AREA) partial sums of the green density over rows [y0, y1) into
+ * cell_sums[(H_global / burn_cell) * (W / burn_cell)] (device).  Row shards add their arrays (all-reduce SUM). */
+int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* cell_sums, int y0, int y1,
+                        int W, int H_global, void* stream);
+/* S7 part 2: clip(x - d_ref, 0) and gaussian_filter(sigma=3, truncate=2) on the low-res map (device -> device).
+ * `scratch` holds 2 x the map size. */
+int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums, float* burn_map, float* scratch, int W,
+                       int H_global, void* stream);
 /* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
  * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,

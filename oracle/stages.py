@@ -268,6 +268,80 @@ def apply_grain(
     return np.maximum(density + G * factor, F32(0.0)).astype(F32)
 
 
+# --------------------------------------------------------------------------- S7
+def resize_area(plane: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """`cv.resize(plane, (out_w, out_h), interpolation=cv.INTER_AREA)` for a float32 plane that is being
+    shrunk -- the down-sample of effects.down_up_blur (effects.py:370-375).  PARITY UNPINNED: OpenCV is not
+    installed; this restates its documented area resampling (imgproc/resize.cpp, computeResizeAreaTab): with
+    scale = src/dst, destination sample d averages the source interval [d*scale, (d+1)*scale): whole source
+    pixels weigh 1/cell, the two partially covered ones by their covered fraction (fractions below 1e-3 are
+    dropped, as OpenCV does), cell = min(scale, src - d*scale).  Separable; float64 here, float32 out."""
+    plane = np.asarray(plane, dtype=F32)
+    wy, wx = area_table(plane.shape[0], out_h), area_table(plane.shape[1], out_w)
+    return (wy @ plane.astype(np.float64) @ wx.T).astype(F32)
+
+
+def area_table(ssize: int, dsize: int) -> np.ndarray:
+    """(dsize, ssize) weights of OpenCV's computeResizeAreaTab for one axis (see resize_area)."""
+    scale = ssize / dsize
+    w = np.zeros((dsize, ssize))
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1 = int(np.ceil(f1))
+        s2 = min(int(np.floor(f2)), ssize - 1)
+        s1 = min(s1, s2)
+        if s1 - f1 > 1e-3:
+            w[d, s1 - 1] += (s1 - f1) / cell
+        w[d, s1:s2] += 1.0 / cell
+        if f2 - s2 > 1e-3:
+            w[d, s2] += min(min(f2 - s2, 1.0), cell) / cell
+    return w
+
+
+def burn_geometry(H: int, W: int, burn_scale: float):
+    """(cell, h_lo, w_lo) of effects.down_up_blur: cell = ceil(min(H, W)/scale), low-res size (H//cell, W//cell)."""
+    cell = int(np.ceil(min(H, W) / burn_scale))
+    return cell, H // cell, W // cell
+
+
+def burn_map(green: np.ndarray, d_ref: float, burn_scale: float = 50.0) -> np.ndarray:
+    """The blurred low-res highlight map of effects.burn / down_up_blur (effects.py:360-418), BEFORE the
+    up-sample: INTER_AREA shrink of the green density, clip(x - d_ref, 0), gaussian_filter(sigma=3, truncate=2)."""
+    green = np.asarray(green, dtype=F32)
+    cell, h_lo, w_lo = burn_geometry(green.shape[0], green.shape[1], burn_scale)
+    down = resize_area(green, h_lo, w_lo)
+    down = np.clip(down - F32(d_ref), 0, None)
+    return ndimage.gaussian_filter(down, sigma=3, truncate=2)
+
+
+def burn(image: np.ndarray, d_ref: float, highlight_burn: float, burn_scale: float = 50.0) -> np.ndarray:
+    """S7 highlight burn, effects.py:396-418 for a 3-channel image: the green density's blurred highlight
+    map, up-sampled with ndimage.zoom(order=1) and edge-padded to the frame (effects.py:381-388), is
+    subtracted from all three channels; then clip at 0.  d_ref = stock.d_ref[1] (or [0])."""
+    image = np.asarray(image, dtype=F32)
+    H, W = image.shape[:2]
+    cell, _, _ = burn_geometry(H, W, burn_scale)
+    blurred = burn_map(image[..., 1], d_ref, burn_scale)
+    return burn_apply(image, blurred, cell, highlight_burn)
+
+
+def burn_upsample(blurred: np.ndarray, cell: int, H: int, W: int) -> np.ndarray:
+    """effects.py:381-388: ndimage.zoom(order=1) by the shrink factor, edge-padded / cropped to (H, W)."""
+    up = ndimage.zoom(blurred, cell, order=1)
+    return np.pad(up, [(0, max(H - up.shape[0], 0)), (0, max(W - up.shape[1], 0))], mode="edge")[:H, :W]
+
+
+def burn_apply(image: np.ndarray, blurred: np.ndarray, cell: int, highlight_burn: float, row0: int = 0,
+               H_global: int | None = None) -> np.ndarray:
+    """Subtract the up-sampled map from rows [row0, row0 + image rows) of an H_global-row frame; clip at 0."""
+    image = np.asarray(image, dtype=F32)
+    H = image.shape[0] + row0 if H_global is None else H_global
+    up = burn_upsample(blurred, cell, H, image.shape[1])[row0:row0 + image.shape[0]]
+    return np.clip(image - F32(highlight_burn) * up[..., None], 0, None).astype(F32)
+
+
 # --------------------------------------------------------------------------- S8
 def apply_lut_tetrahedral(image: np.ndarray, lut: np.ndarray, scale: float = 1.0) -> np.ndarray:
     """S8 tetrahedral 3-D LUT -- restates utils.py:247-380 with numba's promotion rules
@@ -376,13 +450,16 @@ class RenderInputs:
     grain_mono: bool = False
     seed: int = 0
     lut3d_mode: str = "tetrahedral"
+    highlight_burn: float = 0.0  # S7 off when 0 (cpu_processor.py:399); the caller applies the stock gate
+    burn_scale: float = 50.0
+    d_ref: float = 0.0
     stages: dict = field(default_factory=dict)
 
 
 def render(image: np.ndarray, p: RenderInputs, method: str = "fft", keep_stages: bool = False) -> np.ndarray:
     """The hot loop of `CpuProcessor.process`, cpu_processor.py:363-405, as float32 (H, W, 3)
     in -> float32 (H, W, 3) display-referred out (before the `*255` cast, :407):
-    S0 -> S1 -> [S2] -> S3 -> S4 -> [S5] -> [S6 + clip] -> S8.  (S7 highlight burn is out of scope.)"""
+    S0 -> S1 -> [S2] -> S3 -> S4 -> [S5] -> [S6 + clip] -> [S7] -> S8."""
     x = np.asarray(image, dtype=F32)
     if p.matrix is not None:
         x = apply_matrix3x3(x, p.matrix)
@@ -405,6 +482,10 @@ def render(image: np.ndarray, p: RenderInputs, method: str = "fft", keep_stages:
         x = apply_grain(x, p.grain_lut, gk, p.seed, p.grain_mono)
         if keep_stages:
             p.stages["grain"] = x
+    if p.highlight_burn:
+        x = burn(x, p.d_ref, p.highlight_burn, p.burn_scale)
+        if keep_stages:
+            p.stages["burn"] = x
     if p.lut3d_mode == "tetrahedral":
         x = apply_lut_tetrahedral(x, p.lut_3d, LUT3D_SCALE)
     else:

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
 # enums of include/r2f.h
 LAYOUT_HWC3, LAYOUT_HWC4, LAYOUT_CHW = 0, 1, 2
 KERNEL_HALATION, KERNEL_MTF, KERNEL_GRAIN = 0, 1, 2
-F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO = 1, 2, 4, 8, 16
+F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO, F_BURN = 1, 2, 4, 8, 16, 32
 UPTO_EXPOSURE, UPTO_DENSITY, UPTO_OUTPUT = 0, 1, 2
 OK, EINVAL, EHIP, ETOOLARGE = 0, -1, -2, -3
 
@@ -27,7 +27,9 @@ class Params(C.Structure):
         ("log_eps", C.c_float),
         ("lut3d_scale", C.c_float),
         ("lut3d_mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("burn_cell", C.c_int32),
+        ("burn_strength", C.c_float),
+        ("burn_d_ref", C.c_float),
     ]
 
 
@@ -74,7 +76,20 @@ _SIGNATURES = {
     ),
     "r2f_stage_tail": (
         C.c_int,
-        [C.c_void_p, _P(Params), _P(Planes), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+        [C.c_void_p, _P(Params), _P(Planes), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_void_p],
+    ),
+    "r2f_stage_grain": (
+        C.c_int,
+        [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_burn_sums": (
+        C.c_int,
+        [C.c_void_p, _P(Params), _P(Planes), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_burn_map": (
+        C.c_int,
+        [C.c_void_p, _P(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     ),
     "r2f_stage_noise": (
         C.c_int,

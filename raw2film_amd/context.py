@@ -64,15 +64,19 @@ class HipContext:
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
     def make_params(self, *, matrix=False, halation=False, mtf=False, grain=False, grain_mono=False, seed=0,
-                    lut3d_mode=0, log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE) -> _lib.Params:
+                    lut3d_mode=0, log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE, burn_strength=0.0, burn_cell=0,
+                    burn_d_ref=0.0) -> _lib.Params:
+        """burn_strength != 0 switches S7 on; burn_cell = ceil(min(H, W) / burn_scale) (effects.py:365)."""
         flags = (
             (_lib.F_MATRIX if matrix else 0)
             | (_lib.F_HALATION if halation else 0)
             | (_lib.F_MTF if mtf else 0)
             | (_lib.F_GRAIN if grain else 0)
             | (_lib.F_GRAIN_MONO if grain_mono else 0)
+            | (_lib.F_BURN if burn_strength else 0)
         )
-        return _lib.Params(flags, int(seed) & 0xFFFFFFFF, float(log_eps), float(lut3d_scale), int(lut3d_mode), 0)
+        return _lib.Params(flags, int(seed) & 0xFFFFFFFF, float(log_eps), float(lut3d_scale), int(lut3d_mode),
+                           int(burn_cell), float(burn_strength), float(burn_d_ref))
 
     def planes(self, t, gy0: int = 0) -> _lib.Planes:
         """Describe a contiguous float32 (3, rows, W) device tensor holding global rows gy0.."""
@@ -212,16 +216,44 @@ class HipContext:
     def stage_stencil(self, which, src, dst, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
         self._stencil_call(self._lib.r2f_stage_stencil, int(which), src, src_gy0, dst, dst_gy0, y0, y1, H_global)
 
-    def stage_tail(self, density, params, *, src_gy0=0, out_f32=None, out_u8=None, out_gy0=0, y0, y1, H_global):
+    def stage_tail(self, density, params, *, src_gy0=0, out_f32=None, out_u8=None, out_gy0=0, y0, y1, H_global,
+                   burn_map=None):
         pd = self.planes(density, src_gy0)
         W = int(density.shape[2])
         rc = self._lib.r2f_stage_tail(
-            self._h, C.byref(params), C.byref(pd),
+            self._h, C.byref(params), C.byref(pd), burn_map.data_ptr() if burn_map is not None else None,
             out_f32.data_ptr() if out_f32 is not None else None,
             out_u8.data_ptr() if out_u8 is not None else None,
             out_gy0, y0, y1, W, H_global, self._stream(),
         )
         self._check(rc)
+
+    def stage_grain(self, density_in, density_out, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
+        """S6 + clip alone (planes -> planes): first half of the tail when S7 is on."""
+        self._stencil_call(self._lib.r2f_stage_grain, C.byref(params), density_in, src_gy0, density_out, dst_gy0, y0, y1, H_global)
+
+    def burn_shape(self, params, H_global, W):
+        return H_global // params.burn_cell, W // params.burn_cell
+
+    def stage_burn_sums(self, density, params, *, src_gy0=0, y0, y1, H_global):
+        """S7 part 1: area-weighted partial sums of the green density over rows [y0, y1) -> (h_lo, w_lo) tensor."""
+        torch = self._torch
+        W = int(density.shape[2])
+        h_lo, w_lo = self.burn_shape(params, H_global, W)
+        sums = torch.empty((h_lo, w_lo), dtype=torch.float32, device=self.device)
+        pd = self.planes(density, src_gy0)
+        self._check(self._lib.r2f_stage_burn_sums(self._h, C.byref(params), C.byref(pd), sums.data_ptr(), y0, y1, W, H_global,
+                                                  self._stream()))
+        return sums
+
+    def stage_burn_map(self, sums, params, *, W, H_global):
+        """S7 part 2: clip(x - d_ref, 0) + Gaussian(sigma 3) on the low-res map."""
+        torch = self._torch
+        out = torch.empty_like(sums)
+        scratch = torch.empty((2,) + tuple(sums.shape), dtype=torch.float32, device=self.device)
+        self._check(self._lib.r2f_stage_burn_map(self._h, C.byref(params), sums.data_ptr(), out.data_ptr(), scratch.data_ptr(), W,
+                                                 H_global, self._stream()))
+        return out
 
     def stage_noise(self, params, y0, y1, W, want_hash=True, want_noise=True):
         torch = self._torch

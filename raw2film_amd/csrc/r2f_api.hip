@@ -395,7 +395,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
 // =============================================================================== C ABI
 extern "C" {
 
-const char* r2f_version(void) { return "r2f-hip 0.1 gfx950 abi1"; }
+const char* r2f_version(void) { return "r2f-hip 0.2 gfx950 abi2"; }
 
 int r2f_create(int device, r2f_ctx** out) {
     if (!out) return R2F_EINVAL;
@@ -586,13 +586,21 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
     return run_stencil(ctx, which, src, dst, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
 }
 
-int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* out_f32, uint8_t* out_u8,
-                   int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
-    if (!ctx || !p) return R2F_EINVAL;
+static bool burn_geometry(const r2f_params* p, int H, int W, int* h_lo, int* w_lo) {
+    if (p->burn_cell < 1) return false;
+    *h_lo = H / p->burn_cell;
+    *w_lo = W / p->burn_cell;
+    return *h_lo >= 1 && *w_lo >= 1;
+}
+
+static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* planes_out,
+                    const float* burn_map, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global,
+                    void* stream) {
     if (y1 <= y0) return R2F_OK;
-    if (W <= 0 || y0 < 0 || y1 > H_global || y0 < out_gy0) return fail(ctx, R2F_EINVAL, "tail: bad geometry");
-    if (!out_f32 && !out_u8) return fail(ctx, R2F_EINVAL, "tail: no output buffer");
-    if (!ctx->lut3d.tex) return fail(ctx, R2F_EINVAL, "output LUT not set (r2f_set_lut3d)");
+    const bool to_planes = planes_out != nullptr;
+    if (W <= 0 || y0 < 0 || y1 > H_global || (!to_planes && y0 < out_gy0)) return fail(ctx, R2F_EINVAL, "tail: bad geometry");
+    if (!to_planes && !out_f32 && !out_u8) return fail(ctx, R2F_EINVAL, "tail: no output buffer");
+    if (!to_planes && !ctx->lut3d.tex) return fail(ctx, R2F_EINVAL, "output LUT not set (r2f_set_lut3d)");
     int rc = check_rows(ctx, "tail src", density, y0, y1);
     if (rc) return rc;
     TailArgs a;
@@ -611,10 +619,31 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
     a.lut3d = ctx->lut3d;
     a.lut3d_scale = p->lut3d_scale;
     a.lut3d_mode = p->lut3d_mode;
-    a.vec = (planes_vec_ok(density, W) && (!out_f32 || aligned16(out_f32)) &&
-             (!out_u8 || (reinterpret_cast<uintptr_t>(out_u8) & 3u) == 0))
-                ? 1
-                : 0;
+    bool vec = planes_vec_ok(density, W);
+    if (to_planes) {
+        if (!a.grain) return fail(ctx, R2F_EINVAL, "grain stage called with the grain flag off");
+        rc = check_rows(ctx, "grain dst", planes_out, y0, y1);
+        if (rc) return rc;
+        a.to_planes = 1;
+        a.dst = to_dev(planes_out);
+        vec = vec && planes_vec_ok(planes_out, W);
+    } else {
+        vec = vec && (!out_f32 || aligned16(out_f32)) && (!out_u8 || (reinterpret_cast<uintptr_t>(out_u8) & 3u) == 0);
+        if (burn_map) {
+            if (a.grain) return fail(ctx, R2F_EINVAL, "tail with a burn map: apply the grain first (r2f_stage_grain) and clear R2F_F_GRAIN");
+            int h_lo, w_lo;
+            if (!burn_geometry(p, H_global, W, &h_lo, &w_lo)) return fail(ctx, R2F_EINVAL, "burn: bad burn_cell");
+            a.burn.map = burn_map;
+            a.burn.h_lo = h_lo;
+            a.burn.w_lo = w_lo;
+            a.burn.h_up = h_lo * p->burn_cell;
+            a.burn.w_up = w_lo * p->burn_cell;
+            a.burn.ry = a.burn.h_up > 1 ? (float)((double)(h_lo - 1) / (double)(a.burn.h_up - 1)) : 0.f;
+            a.burn.rx = a.burn.w_up > 1 ? (float)((double)(w_lo - 1) / (double)(a.burn.w_up - 1)) : 0.f;
+            a.burn.strength = p->burn_strength;
+        }
+    }
+    a.vec = vec ? 1 : 0;
     if (a.grain) {
         if (!ctx->grain_lut.cells) return fail(ctx, R2F_EINVAL, "grain LUT not set (r2f_set_grain_lut)");
         if (!ctx->stencil[R2F_KERNEL_GRAIN].present) {
@@ -631,6 +660,67 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
         a.grain_lut = ctx->grain_lut;
     }
     R2F_HIP(ctx, launch_tail(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const float* burn_map, float* out_f32,
+                   uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    return run_tail(ctx, p, density, nullptr, burn_map, out_f32, out_u8, out_gy0, y0, y1, W, H_global, stream);
+}
+
+int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1, int W,
+                    int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    if (!dout) return fail(ctx, R2F_EINVAL, "grain: null destination");
+    return run_tail(ctx, p, din, dout, nullptr, nullptr, nullptr, 0, y0, y1, W, H_global, stream);
+}
+
+int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* cell_sums, int y0, int y1, int W,
+                        int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    int h_lo, w_lo;
+    if (!cell_sums || !burn_geometry(p, H_global, W, &h_lo, &w_lo)) return fail(ctx, R2F_EINVAL, "burn sums: bad arguments");
+    if (y0 < 0 || y1 > H_global || y1 < y0) return fail(ctx, R2F_EINVAL, "burn sums: bad rows");
+    if (y1 > y0) {
+        int rc = check_rows(ctx, "burn src", density, y0, y1);
+        if (rc) return rc;
+    }
+    BurnSumsArgs a;
+    a.src = to_dev(density);
+    a.cell_sums = cell_sums;
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.H_global = H_global;
+    a.h_lo = h_lo;
+    a.w_lo = w_lo;
+    R2F_HIP(ctx, launch_burn_sums(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums, float* burn_map, float* scratch, int W,
+                       int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    int h_lo, w_lo;
+    if (!cell_sums || !burn_map || !scratch || !burn_geometry(p, H_global, W, &h_lo, &w_lo))
+        return fail(ctx, R2F_EINVAL, "burn map: bad arguments");
+    BurnMapArgs a;
+    a.cell_sums = cell_sums;
+    a.map = burn_map;
+    a.scratch = scratch;
+    a.h_lo = h_lo;
+    a.w_lo = w_lo;
+    a.d_ref = p->burn_d_ref;
+    // scipy.ndimage._filters._gaussian_kernel1d(sigma=3, order=0, radius=int(truncate*sigma + 0.5) = 6)
+    double sum = 0.0;
+    for (int t = 0; t < 13; ++t) {
+        const double x = t - 6;
+        a.w[t] = exp(-0.5 / 9.0 * x * x);
+        sum += a.w[t];
+    }
+    for (int t = 0; t < 13; ++t) a.w[t] /= sum;
+    R2F_HIP(ctx, launch_burn_map(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
 
@@ -652,13 +742,20 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
 // ------------------------------------------------------------------------------- whole frame
 static size_t plane_set_floats(int H, int W) { return ((size_t)H * W + 3) / 4 * 4 * 3; }
 
+static size_t burn_scratch_floats(const r2f_params* p, int H, int W) {  // cell sums + map + 2 x scratch
+    int h_lo, w_lo;
+    if (!(p->flags & R2F_F_BURN) || !burn_geometry(p, H, W, &h_lo, &w_lo)) return 0;
+    return ((size_t)4 * h_lo * w_lo + 3) / 4 * 4;
+}
+
 size_t r2f_workspace_bytes(const r2f_params* p, int H, int W) {
     if (!p || H <= 0 || W <= 0) return 0;
     const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF, grain = p->flags & R2F_F_GRAIN;
+    const bool burn = p->flags & R2F_F_BURN;
     int sets = 0;
-    if (hal || mtf || grain) sets = 1;
-    if (hal || mtf) sets = 2;
-    return sets * plane_set_floats(H, W) * sizeof(float);
+    if (hal || mtf || grain || burn) sets = 1;
+    if (hal || mtf || (grain && burn)) sets = 2;
+    return (sets * plane_set_floats(H, W) + burn_scratch_floats(p, H, W)) * sizeof(float);
 }
 
 int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32, uint8_t* out_u8, int H,
@@ -668,13 +765,14 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     const size_t need = r2f_workspace_bytes(p, H, W);
     if (need > workspace_bytes || (need && !workspace)) return fail(ctx, R2F_EINVAL, "render: workspace too small (%zu needed)", need);
     if (need && !aligned16(workspace)) return fail(ctx, R2F_EINVAL, "render: workspace must be 16-byte aligned");
-    const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF;
-    const bool any = hal || mtf || (p->flags & R2F_F_GRAIN);
-    if (!any)  // config "LUTs only": one fused pointwise pass
+    const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF, grain = p->flags & R2F_F_GRAIN;
+    const bool burn = p->flags & R2F_F_BURN;
+    if (!(hal || mtf || grain || burn))  // config "LUTs only": one fused pointwise pass
         return r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_OUTPUT, nullptr, out_f32, out_u8, 0, 0, H, W, H, stream);
     const size_t set_floats = plane_set_floats(H, W);
-    r2f_planes A{static_cast<float*>(workspace), (int64_t)(set_floats / 3), 0, H};
-    r2f_planes B{static_cast<float*>(workspace) + set_floats, (int64_t)(set_floats / 3), 0, H};
+    float* base = static_cast<float*>(workspace);
+    r2f_planes A{base, (int64_t)(set_floats / 3), 0, H};
+    r2f_planes B{base + set_floats, (int64_t)(set_floats / 3), 0, H};
     int rc = r2f_stage_front(ctx, p, in, in_layout, 0, H, hal ? R2F_UPTO_EXPOSURE : R2F_UPTO_DENSITY, &A, nullptr, nullptr,
                              0, 0, H, W, H, stream);
     if (rc) return rc;
@@ -690,7 +788,27 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
         if (rc) return rc;
         std::swap(cur, other);
     }
-    return r2f_stage_tail(ctx, p, cur, out_f32, out_u8, 0, 0, H, W, H, stream);
+    if (!burn) return r2f_stage_tail(ctx, p, cur, nullptr, out_f32, out_u8, 0, 0, H, W, H, stream);
+    // S7: the burn map depends on the whole grained frame -> grain to planes, reduce, blur, then finish
+    int sets_used = (hal || mtf) ? 2 : 1;
+    if (grain) {
+        if (sets_used == 1) sets_used = 2;
+        rc = r2f_stage_grain(ctx, p, cur, other, 0, H, W, H, stream);
+        if (rc) return rc;
+        std::swap(cur, other);
+    }
+    int h_lo, w_lo;
+    if (!burn_geometry(p, H, W, &h_lo, &w_lo)) return fail(ctx, R2F_EINVAL, "render: bad burn_cell");
+    float* sums = base + (size_t)sets_used * set_floats;
+    float* map = sums + (size_t)h_lo * w_lo;
+    float* scratch = map + (size_t)h_lo * w_lo;
+    rc = r2f_stage_burn_sums(ctx, p, cur, sums, 0, H, W, H, stream);
+    if (rc) return rc;
+    rc = r2f_stage_burn_map(ctx, p, sums, map, scratch, W, H, stream);
+    if (rc) return rc;
+    r2f_params q = *p;
+    q.flags &= ~(uint32_t)R2F_F_GRAIN;
+    return r2f_stage_tail(ctx, &q, cur, map, out_f32, out_u8, 0, 0, H, W, H, stream);
 }
 
 }  // extern "C"

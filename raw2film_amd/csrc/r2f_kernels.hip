@@ -210,7 +210,21 @@ struct Lut3dArgs {
     float lut3d_scale;
     int lut3d_mode;
     int vec;
+    BurnUp burn;
 };
+
+// S7: the highlight map at pixel (gy, x): ndimage.zoom(map, cell, order=1) = linear interpolation with the
+// first / last samples pinned to the first / last zoomed pixels, then edge padding (effects.py:381-388).
+__device__ __forceinline__ float burn_sample(const BurnUp& bu, int gy, int x) {
+    const float fy = (float)min(gy, bu.h_up - 1) * bu.ry, fx = (float)min(x, bu.w_up - 1) * bu.rx;
+    const int y0 = min((int)fy, bu.h_lo - 1), x0 = min((int)fx, bu.w_lo - 1);
+    const int y1 = min(y0 + 1, bu.h_lo - 1), x1 = min(x0 + 1, bu.w_lo - 1);
+    const float ty = fy - (float)y0, tx = fx - (float)x0;
+    const float a = bu.map[y0 * bu.w_lo + x0], b = bu.map[y0 * bu.w_lo + x1];
+    const float c = bu.map[y1 * bu.w_lo + x0], d = bu.map[y1 * bu.w_lo + x1];
+    const float top = a + tx * (b - a), bot = c + tx * (d - c);
+    return top + ty * (bot - top);
+}
 
 __global__ __launch_bounds__(256) void lut3d_kernel(const Lut3dArgs a) {
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
@@ -220,7 +234,15 @@ __global__ __launch_bounds__(256) void lut3d_kernel(const Lut3dArgs a) {
     float r[4], g[4], b[4];
     load_planes4(a.src, gy, x, a.W, nv, a.vec != 0, r, g, b);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[q], g[q], b[q]);
+    for (int q = 0; q < 4; ++q) {
+        if (a.burn.map) {  // S7: subtract the up-sampled highlight map from all three channels, clip at 0
+            const float v = a.burn.strength * burn_sample(a.burn, gy, x + q);
+            r[q] = fmaxf(r[q] - v, 0.f);
+            g[q] = fmaxf(g[q] - v, 0.f);
+            b[q] = fmaxf(b[q] - v, 0.f);
+        }
+        apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[q], g[q], b[q]);
+    }
     emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, x, a.W, nv, a.vec != 0, r, g, b);
 }
 
@@ -400,9 +422,95 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
             r[p] = fmaxf(r[p] + G[0][q / 2][p][q & 1] * curve_eval(a.grain_lut, 0, r[p]), 0.f);
             g[p] = fmaxf(g[p] + G[1][q / 2][p][q & 1] * curve_eval(a.grain_lut, 1, g[p]), 0.f);
             b[p] = fmaxf(b[p] + G[2][q / 2][p][q & 1] * curve_eval(a.grain_lut, 2, b[p]), 0.f);
-            apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
+            if (!a.to_planes) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
         }
-        emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, gx, a.W, nv, vec, r, g, b);
+        if (a.to_planes)
+            store_planes4(a.dst, gy, gx, a.W, nv, vec, r, g, b);
+        else
+            emit_hwc(a.out_f32, a.out_u8, gy - a.out_gy0, gx, a.W, nv, vec, r, g, b);
+    }
+}
+
+// ------------------------------------------------------------------------------ S7 highlight burn
+// cv.resize INTER_AREA weight of source sample s for destination sample d (computeResizeAreaTab).
+__device__ __forceinline__ void area_cell(int d, double scale, int ssize, int& s_first, int& s_last, int& s1, int& s2,
+                                          double& w_first, double& w_full, double& w_last) {
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)ssize - f1);
+    s1 = (int)ceil(f1);
+    s2 = min((int)floor(f2), ssize - 1);
+    s1 = min(s1, s2);
+    w_first = (s1 - f1 > 1e-3) ? (s1 - f1) / cell : 0.0;
+    w_full = 1.0 / cell;
+    w_last = (f2 - s2 > 1e-3) ? fmin(fmin(f2 - s2, 1.0), cell) / cell : 0.0;
+    s_first = max(s1 - 1, 0);
+    s_last = s2;
+}
+
+__device__ __forceinline__ float area_weight(int s, int s1, int s2, double w_first, double w_full, double w_last) {
+    if (s == s1 - 1) return (float)w_first;
+    if (s >= s1 && s < s2) return (float)w_full;
+    if (s == s2) return (float)w_last;
+    return 0.f;
+}
+
+// One workgroup per low-res cell: area-weighted sum of the green density over the cell's source pixels that
+// lie in rows [y0, y1) (a row shard contributes its part; shards' arrays add up to the full-frame value).
+__global__ __launch_bounds__(256) void burn_sums_kernel(const BurnSumsArgs a) {
+    const int j = blockIdx.x, i = blockIdx.y;
+    int ry0, ry1, rs1, rs2, cx0, cx1, cs1, cs2;
+    double wyf, wy, wyl, wxf, wx, wxl;
+    area_cell(i, (double)a.H_global / a.h_lo, a.H_global, ry0, ry1, rs1, rs2, wyf, wy, wyl);
+    area_cell(j, (double)a.W / a.w_lo, a.W, cx0, cx1, cs1, cs2, wxf, wx, wxl);
+    const int ra = max(ry0, a.y0), rb = min(ry1, a.y1 - 1);
+    const int ncols = cx1 - cx0 + 1;
+    const float* green = a.src.data + a.src.plane_stride;
+    float acc = 0.f;
+    if (rb >= ra) {
+        const int n = (rb - ra + 1) * ncols;
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
+            const int rr = idx / ncols, cc = idx - rr * ncols;
+            const int y = ra + rr, x = cx0 + cc;
+            const float w = area_weight(y, rs1, rs2, wyf, wy, wyl) * area_weight(x, cs1, cs2, wxf, wx, wxl);
+            acc += w * green[(long long)(y - a.src.gy0) * a.W + x];
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.cell_sums[i * a.w_lo + j] = red[0];
+}
+
+// scipy.ndimage "reflect" boundary: d c b a | a b c d | d c b a
+__device__ __forceinline__ int reflect_sym(int i, int n) {
+    while (i < 0 || i >= n) i = i < 0 ? -i - 1 : 2 * n - 1 - i;
+    return i;
+}
+
+// clip(x - d_ref, 0) then gaussian_filter(sigma=3, truncate=2): two 13-tap passes (axis 0, then axis 1), double
+// accumulation and a float32 store after each pass, like scipy's correlate1d.  One workgroup; the map is tiny.
+__global__ __launch_bounds__(256) void burn_map_kernel(const BurnMapArgs a) {
+    const int n = a.h_lo * a.w_lo;
+    float* t0 = a.scratch;
+    float* t1 = a.scratch + n;
+    for (int k = threadIdx.x; k < n; k += 256) t0[k] = fmaxf(a.cell_sums[k] - a.d_ref, 0.f);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int i = k / a.w_lo, j = k - i * a.w_lo;
+        double acc = 0.0;
+        for (int t = 0; t < 13; ++t) acc += a.w[t] * (double)t0[reflect_sym(i + t - 6, a.h_lo) * a.w_lo + j];
+        t1[k] = (float)acc;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int i = k / a.w_lo, j = k - i * a.w_lo;
+        double acc = 0.0;
+        for (int t = 0; t < 13; ++t) acc += a.w[t] * (double)t1[i * a.w_lo + reflect_sym(j + t - 6, a.w_lo)];
+        a.map[k] = (float)acc;
     }
 }
 
@@ -511,6 +619,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
         l.lut3d_scale = a.lut3d_scale;
         l.lut3d_mode = a.lut3d_mode;
         l.vec = a.vec;
+        l.burn = a.burn;
         const int quads = (a.W + 3) / 4;
         dim3 block(64, 4), grid((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4);
         hipLaunchKernelGGL(lut3d_kernel, grid, block, 0, s, l);
@@ -519,6 +628,17 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     const int TW = 4 * kTailBX, TH = kTailQ * kTailBY;
     dim3 block(kTailBX * kTailBY), grid((a.W + TW - 1) / TW, (a.y1 - a.y0 + TH - 1) / TH);
     hipLaunchKernelGGL(tail_kernel, grid, block, tail_lds_bytes(a.gk, a.mono), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s) {
+    if (a.h_lo <= 0 || a.w_lo <= 0) return hipSuccess;
+    hipLaunchKernelGGL(burn_sums_kernel, dim3(a.w_lo, a.h_lo), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(burn_map_kernel, dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

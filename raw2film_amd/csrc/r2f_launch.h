@@ -39,6 +39,31 @@ struct StencilArgs {
     int ablate;  // profiling aid: 1 = skip the tile fill, 2 = skip the accumulation (results invalid)
 };
 
+// S7: the blurred low-res highlight map and how to up-sample it (ndimage.zoom(order=1) + edge pad, effects.py:381-388)
+struct BurnUp {
+    const float* map;  // h_lo x w_lo, nullptr = burn off
+    int h_lo, w_lo;
+    int h_up, w_up;    // h_lo * cell, w_lo * cell: extent of the zoomed map; beyond it the edge is repeated
+    float ry, rx;      // (h_lo - 1) / (h_up - 1), (w_lo - 1) / (w_up - 1)
+    float strength;
+};
+
+struct BurnSumsArgs {
+    DevPlanes src;
+    float* cell_sums;
+    int y0, y1, W, H_global;
+    int h_lo, w_lo;
+};
+
+struct BurnMapArgs {
+    const float* cell_sums;
+    float* map;
+    float* scratch;
+    int h_lo, w_lo;
+    float d_ref;
+    double w[13];  // scipy's gaussian kernel for sigma = 3, truncate = 2
+};
+
 struct TailArgs {
     DevPlanes src;
     float* out_f32;
@@ -46,6 +71,9 @@ struct TailArgs {
     int out_gy0;
     int y0, y1, W, H_global;
     int grain;  // 0/1
+    int to_planes;  // 1: stop after grain + clip and write density planes `dst` (S7 needs the whole grained frame)
+    DevPlanes dst;
+    BurnUp burn;
     int mono;
     uint32_t seed;
     DevStencil gk[3];  // grain stencil, common geometry for the 3 channels
@@ -84,5 +112,7 @@ hipError_t launch_front(const FrontArgs& a, hipStream_t s);
 hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s);
 hipError_t launch_tail(const TailArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
+hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s);
+hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s);
 
 }  // namespace r2f

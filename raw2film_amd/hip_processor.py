@@ -6,8 +6,8 @@ keyword names and defaults, unknown keywords swallowed, LUTs / stencils rebuilt 
 re-uploaded only when their parameter dict changes (cpu_processor.py:104-105,157-158,...).
 
 Scope: the post-decode per-pixel path, plus the index-only geometry around it (aspect crop, zoom,
-quarter turns before; canvas after).  RAW decoding, lens correction, free rotation, chroma NR, the
-`max_scale` resize and highlight burn belong to the rows SURVEY.md section 8f lists as "next";
+quarter turns before; canvas after) and the highlight burn (S7).  RAW decoding, lens correction, free
+rotation, chroma NR and the `max_scale` resize belong to the rows SURVEY.md section 8f lists as "next";
 asking for them raises NotImplementedError instead of silently rendering something else.
 
 `src` is therefore a decoded frame: a float32 (H, W, 3|4) array / CUDA tensor in linear CIE XYZ
@@ -16,6 +16,7 @@ asking for them raises NotImplementedError instead of silently rendering somethi
 
 from __future__ import annotations
 
+import math
 import random
 
 import numpy as np
@@ -282,8 +283,6 @@ class HipProcessor:
                 highlight_burn=0.0, burn_scale=50.0, color_masking=None, matrix=None, seed=None, lut3d_mode=0, **_):
         """Upload whatever changed and return the r2f_params for this render: the table half of
         `_execute_gpu_pipeline` (gpu_processor.py:1735-1756, 1772-1825)."""
-        if highlight_burn:
-            raise NotImplementedError("highlight burn is outside the accelerated path (SURVEY.md section 8f)")
         self.load_input_lut(negative_film, exp_kelvin, tint, exp_comp)
         self.load_density_curve(negative_film, push_pull, color_masking)
         self.load_output_lut(negative_film, print_film, red_light, green_light, blue_light, projector_kelvin,
@@ -306,9 +305,16 @@ class HipProcessor:
             self.matrix_key = mkey
         if seed is None:
             seed = random.randint(0, 100000000)  # gpu_processor.py:591: a new seed every render
+        # S7 gate: cpu_processor.py:399-402
+        do_burn = bool(highlight_burn) and (print_film is not None or negative_film.density_measure in ["status_m", "bw"])
+        burn_kw = {}
+        if do_burn:
+            d_ref = negative_film.d_ref[1 if len(negative_film.d_ref) > 1 else 0]  # effects.py:406
+            burn_kw = dict(burn_strength=float(highlight_burn), burn_d_ref=float(d_ref),
+                           burn_cell=math.ceil(min(pipeline_resolution) / burn_scale))  # effects.py:365
         return self.ctx.make_params(matrix=matrix is not None, halation=do_hal, mtf=do_mtf, grain=do_grain,
                                     grain_mono=grain == 1, seed=seed, lut3d_mode=lut3d_mode,
-                                    log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE)
+                                    log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE, **burn_kw)
 
     def _execute_pipeline(self, image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True, **settings):
         _, H, W = self.ctx.layout_of(image)

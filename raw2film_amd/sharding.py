@@ -7,6 +7,7 @@ RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GP
         S0+S1 on own rows -> exposure E            exchange r_h rows of E  (halation halo)
         S2+S3+S4 on own rows -> density D          exchange r_m rows of D  (MTF halo)
         S5 -> S6 (hash noise at GLOBAL coordinates, no exchange) -> S8 -> own output rows
+        [S7 highlight burn, when on: one all-reduce (SUM) of the ~50 x 75 low-res cell sums between S6 and S8]
     Each exchange is one send + one receive per neighbour, batched (`batch_isend_irecv`, i.e.
     ncclGroupStart/End): at 100 MP that is 43 / 17 rows x 12288 px x 3 planes x 4 B = 6.3 / 2.5 MB
     per direction -- latency-bound, every pair on its own xGMI link.  Global top/bottom edges are
@@ -81,8 +82,24 @@ class HipStageBackend:
     def mtf(self, D, d_gy0, D2, d2_gy0, y0, y1, H):
         self.ctx.stage_mtf(D, D2, self.params, src_gy0=d_gy0, dst_gy0=d2_gy0, y0=y0, y1=y1, H_global=H)
 
-    def tail(self, D, d_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
-        self.ctx.stage_tail(D, self.params, src_gy0=d_gy0, out_f32=out_f32, out_u8=out_u8, out_gy0=out_gy0, y0=y0, y1=y1, H_global=H)
+    def tail(self, D, d_gy0, out_f32, out_u8, out_gy0, y0, y1, H, burn_map=None):
+        params = self.params
+        if burn_map is not None:  # the grain has been applied by grain() already
+            from . import _lib
+
+            params = _lib.Params.from_buffer_copy(self.params)
+            params.flags &= ~_lib.F_GRAIN
+        self.ctx.stage_tail(D, params, src_gy0=d_gy0, out_f32=out_f32, out_u8=out_u8, out_gy0=out_gy0, y0=y0, y1=y1,
+                            H_global=H, burn_map=burn_map)
+
+    def grain(self, D, d_gy0, G, g_gy0, y0, y1, H):
+        self.ctx.stage_grain(D, G, self.params, src_gy0=d_gy0, dst_gy0=g_gy0, y0=y0, y1=y1, H_global=H)
+
+    def burn_sums(self, D, d_gy0, y0, y1, H):
+        return self.ctx.stage_burn_sums(D, self.params, src_gy0=d_gy0, y0=y0, y1=y1, H_global=H)
+
+    def burn_map(self, sums, W, H):
+        return self.ctx.stage_burn_map(sums, self.params, W=W, H_global=H)
 
     def front_to_output(self, image_rows, in_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
         self.ctx.stage_front(image_rows, self.params, 2, in_gy0=in_gy0, out_f32=out_f32, out_u8=out_u8, out_gy0=out_gy0,
@@ -96,8 +113,8 @@ class RowShardedRenderer:
     halation / mtf / grain: which stages are enabled (the stage gates of cpu_processor.py:368,382,387)
     """
 
-    def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, group=None, rank=None,
-                 world=None):
+    def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,
+                 group=None, rank=None, world=None):
         import torch
         import torch.distributed as dist
 
@@ -111,7 +128,7 @@ class RowShardedRenderer:
         r0, r1 = shard_rows(H, world)[rank]
         ha, hb = backend.halation_taps if halation else (0, 0)
         ma, mb = backend.mtf_taps if mtf else (0, 0)
-        self.halation, self.mtf, self.grain = halation, mtf, grain
+        self.halation, self.mtf, self.grain, self.burn = halation, mtf, grain, burn
         self.plan = ShardPlan(H, W, rank, world, r0, r1, (ha, hb), (ma, mb))
         smallest = min(b - a for a, b in shard_rows(H, world))
         need = max(ha, hb, ma, mb)
@@ -127,6 +144,7 @@ class RowShardedRenderer:
         self.D = backend.empty(self.d_hi - self.d_lo, W) if (halation or mtf) else None
         self.D2 = backend.empty(p.rows, W) if mtf else None
         self.Dplain = backend.empty(p.rows, W) if not (halation or mtf) else None
+        self.G = backend.empty(p.rows, W) if (burn and grain) else None  # grained density, needed whole before S7
 
     # ------------------------------------------------------------------ neighbour exchange
     def _exchange(self, buf, buf_gy0: int, above: int, below: int):
@@ -185,25 +203,36 @@ class RowShardedRenderer:
         out_*: this rank's own rows of the result, (rows, W, 3)."""
         p, be = self.plan, self.backend
         H = p.H
-        if not (self.halation or self.mtf or self.grain):  # LUTs only: one fused pointwise pass
+        if not (self.halation or self.mtf or self.grain or self.burn):  # LUTs only: one fused pointwise pass
             be.front_to_output(image_rows, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
             return out_f32, out_u8
         if not (self.halation or self.mtf):
             be.front(image_rows, p.r0, 1, self.Dplain, p.r0, p.r0, p.r1, H)
-            be.tail(self.Dplain, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+            cur, cur_lo = self.Dplain, p.r0
+        else:
+            if self.halation:
+                be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
+                self._exchange(self.E, self.e_lo, *p.halo_e)
+                be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
+            else:
+                be.front(image_rows, p.r0, 1, self.D, self.d_lo, p.r0, p.r1, H)
+            cur, cur_lo = self.D, self.d_lo
+            if self.mtf:
+                self._exchange(self.D, self.d_lo, *p.halo_d)
+                be.mtf(self.D, self.d_lo, self.D2, p.r0, p.r0, p.r1, H)
+                cur, cur_lo = self.D2, p.r0
+        if not self.burn:
+            be.tail(cur, cur_lo, out_f32, out_u8, p.r0, p.r0, p.r1, H)
             return out_f32, out_u8
-        if self.halation:
-            be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
-            self._exchange(self.E, self.e_lo, *p.halo_e)
-            be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
-        else:
-            be.front(image_rows, p.r0, 1, self.D, self.d_lo, p.r0, p.r1, H)
-        if self.mtf:
-            self._exchange(self.D, self.d_lo, *p.halo_d)
-            be.mtf(self.D, self.d_lo, self.D2, p.r0, p.r0, p.r1, H)
-            be.tail(self.D2, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
-        else:
-            be.tail(self.D, self.d_lo, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+        # S7: the highlight map is a function of the whole grained frame -> grain to planes, every rank reduces the
+        # cells its rows touch, one tiny all-reduce adds the partial sums, every rank blurs the (replicated) map.
+        if self.grain:
+            be.grain(cur, cur_lo, self.G, p.r0, p.r0, p.r1, H)
+            cur, cur_lo = self.G, p.r0
+        sums = be.burn_sums(cur, cur_lo, p.r0, p.r1, H)
+        if p.world > 1:
+            self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM, group=self.group)
+        be.tail(cur, cur_lo, out_f32, out_u8, p.r0, p.r0, p.r1, H, burn_map=be.burn_map(sums, p.W, H))
         return out_f32, out_u8
 
 

@@ -425,3 +425,40 @@ def test_uint8_only_output(ctx):
     assert f32 is None and u8.dtype == torch.uint8
     d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(st.render(img, p)).astype(int))
     assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+
+
+# ------------------------------------------------------------------------------- S7 highlight burn
+@pytest.mark.parametrize("shape,burn_scale", [((150, 230), 50.0), ((96, 96), 8.0), ((301, 177), 25.0)])
+def test_burn_area_sums_and_map(ctx, shape, burn_scale):
+    H, W = shape
+    rng = np.random.default_rng(H)
+    dens = rng.uniform(0.0, 3.0, (H, W, 3)).astype(np.float32)
+    cell, h_lo, w_lo = st.burn_geometry(H, W, burn_scale)
+    params = ctx.make_params(burn_strength=0.5, burn_cell=cell, burn_d_ref=1.2)
+    D = to_planes(dens)
+    sums = ctx.stage_burn_sums(D, params, y0=0, y1=H, H_global=H)
+    assert tuple(sums.shape) == (h_lo, w_lo)
+    np.testing.assert_allclose(sums.cpu().numpy(), st.resize_area(dens[..., 1], h_lo, w_lo), rtol=2e-6, atol=0)
+    # row shards' partial sums add up to the whole
+    a = ctx.stage_burn_sums(D, params, y0=0, y1=H // 3, H_global=H)
+    b = ctx.stage_burn_sums(D, params, y0=H // 3, y1=H, H_global=H)
+    np.testing.assert_allclose((a + b).cpu().numpy(), sums.cpu().numpy(), rtol=2e-6, atol=0)
+    bmap = ctx.stage_burn_map(sums, params, W=W, H_global=H)
+    np.testing.assert_allclose(bmap.cpu().numpy(), st.burn_map(dens[..., 1], 1.2, burn_scale), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("grain", [2, 0])
+def test_full_pipeline_with_highlight_burn(ctx, grain):
+    neg, prt, _ = stocks()
+    H, W = 180, 260
+    p = oracle_inputs(neg, prt, 150.0, grain=grain)
+    p.highlight_burn, p.burn_scale, p.d_ref = 0.7, 50.0, float(neg.d_ref[1])
+    img = synthetic_frame(H, W, seed=70)
+    img[40:90, 60:140] *= 12.0  # a bright region so that the map is not flat
+    ref = st.render(img, p, keep_stages=True)
+    assert np.abs(p.stages["burn"] - p.stages["grain" if grain else "mtf"]).max() > 0.05
+    params = setup_ctx(ctx, p)
+    params.flags |= 32
+    params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 50.0)[0], 0.7, float(neg.d_ref[1])
+    out, _ = ctx.render(dev(img), params)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "pipeline with burn")

@@ -102,3 +102,18 @@ def test_uploads_happen_only_on_change(proc):
     assert proc.uploads == n
     proc.process(img, neg, 6, 0.4, **{**kw, "halation_size": 1.5})
     assert proc.uploads == n + 1
+
+
+def test_highlight_burn_through_the_processor(proc):
+    neg, prt, _ = stocks()
+    H, W, fw = 120, 180, 1.5
+    img = _xyz(H, W, seed=46)
+    img[30:70, 50:120] *= 10.0
+    kw = dict(print_film=prt, frame_width=fw, frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000,
+              color_masking=1.0, seed=SEED)
+    plain = proc.process(img, neg, 6, 0.4, **kw)
+    burnt = proc.process(img, neg, 6, 0.4, highlight_burn=0.8, burn_scale=30, **kw)
+    p = oracle_inputs(neg, prt, max(H, W) / fw, matrix=False)
+    p.highlight_burn, p.burn_scale, p.d_ref = 0.8, 30.0, float(neg.d_ref[1])
+    assert _u8_close(burnt, st.to_uint8(st.render(img, p)))
+    assert np.abs(burnt.astype(int) - plain.astype(int)).max() > 5

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _render(rank, world, H, W, fw):
+def _render(rank, world, H, W, fw, burn=0.0):
     from raw2film_amd import HipProcessor, stencils
     from raw2film_amd.hip_processor import REC709_TO_XYZ
     from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
@@ -30,27 +30,30 @@ def _render(rank, world, H, W, fw):
     neg, prt, _ = stocks()
     proc = HipProcessor(device=0)
     params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
-                          frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
+                          frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0,
+                          highlight_burn=burn, burn_scale=20)
     scale = max(H, W) / fw
     hal = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
     mtf = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
     be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
-    rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=rank, world=world)
-    img = torch.from_numpy(synthetic_frame(H, W, seed=31)).cuda()
+    rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, burn=bool(burn), rank=rank, world=world)
+    frame = synthetic_frame(H, W, seed=31)
+    frame[60:150, 40:200] *= 8.0
+    img = torch.from_numpy(frame).cuda()
     out = torch.empty((rr.plan.rows, W, 3), dtype=torch.float32, device="cuda")
     rr.render(img[rr.plan.r0:rr.plan.r1].contiguous(), out_f32=out)
     torch.cuda.synchronize()
     return out.cpu().numpy(), proc, params, img
 
 
-def _worker(rank, world, port, H, W, fw, path):
+def _worker(rank, world, port, H, W, fw, path, burn=0.0):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out, _, _, _ = _render(rank, world, H, W, fw)
+        out, _, _, _ = _render(rank, world, H, W, fw, burn)
         np.save(f"{path}.{rank}.npy", out)
     finally:
         dist.destroy_process_group()
@@ -67,3 +70,19 @@ def test_two_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
     np.testing.assert_array_equal(sharded, whole)
     ref, _ = proc.ctx.render(img, params)
     np.testing.assert_array_equal(whole, ref.cpu().numpy())
+
+
+def test_two_rank_hip_row_shards_with_highlight_burn(tmp_path):
+    """S7 adds one all-reduce of the low-res cell sums; partial sums are added in a different order than on one
+    GPU, so the result agrees to rounding instead of bit for bit."""
+    import torch.multiprocessing as mp
+
+    H, W, fw = 210, 256, 1.0
+    path = str(tmp_path / "shard")
+    mp.spawn(_worker, args=(2, _free_port(), H, W, fw, path, 0.8), nprocs=2, join=True)
+    sharded = np.concatenate([np.load(f"{path}.{r}.npy") for r in range(2)])
+    whole, proc, params, img = _render(0, 1, H, W, fw, 0.8)
+    assert params.flags & 32
+    np.testing.assert_allclose(sharded, whole, rtol=0, atol=2e-6)
+    ref, _ = proc.ctx.render(img, params)
+    np.testing.assert_allclose(whole, ref.cpu().numpy(), rtol=0, atol=1e-6)

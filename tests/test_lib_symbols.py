@@ -29,17 +29,19 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_the_header():
-    # r2f_params: 2 x u32, 2 x f32, 2 x i32 ; r2f_planes: ptr, i64, 2 x i32
-    assert ctypes.sizeof(_lib.Params) == 24
+    # r2f_params: 2 x u32, 2 x f32, 2 x i32, 2 x f32 ; r2f_planes: ptr, i64, 2 x i32
+    assert ctypes.sizeof(_lib.Params) == 32
     assert ctypes.sizeof(_lib.Planes) == 24
     assert _lib.Planes.plane_stride.offset == 8 and _lib.Planes.gy0.offset == 16
 
 
 def test_workspace_bytes_needs_no_gpu():
     lib = _lib.load()
-    p = _lib.Params(_lib.F_HALATION | _lib.F_MTF | _lib.F_GRAIN, 1, 1e-6, 0.25, 0, 0)
+    p = _lib.Params(_lib.F_HALATION | _lib.F_MTF | _lib.F_GRAIN, 1, 1e-6, 0.25, 0, 0, 0.0, 0.0)
     assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 2 * 3 * 100 * 200 * 4
     p.flags = _lib.F_GRAIN
     assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 3 * 100 * 200 * 4
     p.flags = 0
     assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 0
+    p.flags, p.burn_cell = _lib.F_GRAIN | _lib.F_BURN, 10  # grain -> planes, burn map 10 x 20 (x4 floats of scratch)
+    assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 2 * 3 * 100 * 200 * 4 + 4 * 10 * 20 * 4

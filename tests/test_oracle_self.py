@@ -146,3 +146,27 @@ def test_config1_plumbing_negative_only(size):
     assert out.shape == (H, W, 3) and out.dtype == np.float32
     assert 0.0 <= out.min() and out.max() <= 1.0 and 0.2 < out.mean() < 0.8
     assert ok.compute_halation_kernel(max(H, W) / 36.0).shape == (5, 5, 3)
+
+
+def test_area_resize_is_a_block_mean_for_integer_factors_and_conserves_mass():
+    rng = np.random.default_rng(5)
+    a = rng.uniform(0, 3, (120, 180)).astype(np.float32)
+    np.testing.assert_allclose(st.resize_area(a, 40, 60), a.reshape(40, 3, 60, 3).mean(axis=(1, 3)), rtol=1e-6)
+    for out in ((7, 11), (49, 74), (1, 1)):
+        d = st.resize_area(a, *out)
+        assert d.shape == out and abs(float(d.mean()) - float(a.mean())) < 1e-3 * float(a.mean()) + 1e-3
+    t = st.area_table(100, 7)
+    np.testing.assert_allclose(t.sum(axis=1), 1.0, atol=1e-12)  # every destination sample is a weighted mean
+
+
+def test_burn_only_touches_highlights_and_uses_green():
+    dens = np.full((60, 90, 3), 0.8, np.float32)
+    out = st.burn(dens, d_ref=1.2, highlight_burn=0.9, burn_scale=10.0)
+    np.testing.assert_array_equal(out, dens)  # nothing above d_ref -> map is zero
+    dens[20:40, 30:60, 1] = 3.0  # only the green layer is dense
+    out = st.burn(dens, 1.2, 0.9, 10.0)
+    delta = dens - out
+    assert delta.max() > 0.3 and np.allclose(delta[..., 0], delta[..., 2]) and delta.min() >= 0
+    assert (out >= 0).all()
+    cell, h_lo, w_lo = st.burn_geometry(60, 90, 10.0)
+    assert (cell, h_lo, w_lo) == (6, 10, 15)

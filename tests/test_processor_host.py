@@ -99,6 +99,19 @@ def test_bw_stock_sets_equal_halation_factors(proc, monkeypatch):
     assert seen["bw"] is True
 
 
+def test_highlight_burn_gate_and_parameters(proc):
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    on = proc.prepare(neg, 6, 0.4, (600, 400), print_film=prt, highlight_burn=0.5, burn_scale=50)
+    assert on["burn_strength"] == 0.5 and on["burn_cell"] == 8 and on["burn_d_ref"] == neg.d_ref[1]
+    off = proc.prepare(neg, 6, 0.4, (600, 400), print_film=prt, highlight_burn=0.0)
+    assert "burn_strength" not in off
+    # cpu_processor.py:399-402: without a print stock only status_m / bw negatives burn
+    odd = filmstock.SyntheticStock("odd", density_measure="status_a")
+    assert "burn_strength" not in proc.prepare(odd, 6, 0.4, (600, 400), print_film=None, highlight_burn=0.5)
+    assert "burn_strength" in proc.prepare(neg, 6, 0.4, (600, 400), print_film=None, highlight_burn=0.5)
+
+
 def test_random_seed_when_not_given(proc):
     neg = filmstock.builtin_stocks()["Kodak Portra 400"]
     seeds = {proc.prepare(neg, 6, 0.4, (60, 40))["seed"] for _ in range(4)}
@@ -114,8 +127,6 @@ def test_out_of_scope_requests_raise(proc):
         proc.extract_image_data_cpu(img, rotation=3.0)
     with pytest.raises(NotImplementedError):
         proc.extract_image_data_cpu(img, frame_width=0.1, frame_height=0.07)  # finer than max_scale
-    with pytest.raises(NotImplementedError):
-        proc.prepare(neg, 6, 0.4, (60, 40), highlight_burn=0.5)
     with pytest.raises(NotImplementedError):
         proc.process(img, neg, 6, 0.4, dst_texture=object())
 

@@ -73,13 +73,39 @@ class OracleStageBackend:
         x = self._stencil(D, d_gy0, self.p.mtf_kernel, y0, y1, H)
         D2[:, y0 - d2_gy0:y1 - d2_gy0, :] = torch.from_numpy(np.transpose(x, (2, 0, 1)).copy())
 
-    def tail(self, D, d_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
+    def _grained(self, D, d_gy0, y0, y1, H):
         x = np.transpose(D.numpy()[:, y0 - d_gy0:y1 - d_gy0, :], (1, 2, 0))
         if self.p.grain_lut is not None:
             gk = self.p.grain_kernel if self.p.grain_kernel is not None else np.ones((1, 1), np.float32)
             x = st.apply_grain(x, self.p.grain_lut, gk, self.p.seed, self.p.grain_mono, row0=y0, H_global=H)
+        return x
+
+    def tail(self, D, d_gy0, out_f32, out_u8, out_gy0, y0, y1, H, burn_map=None):
+        if burn_map is None:
+            x = self._grained(D, d_gy0, y0, y1, H)
+        else:  # grain already applied by grain()
+            x = np.transpose(D.numpy()[:, y0 - d_gy0:y1 - d_gy0, :], (1, 2, 0))
+            cell = st.burn_geometry(H, x.shape[1], self.p.burn_scale)[0]
+            x = st.burn_apply(x, burn_map.numpy(), cell, self.p.highlight_burn, row0=y0, H_global=H)
         x = st.apply_lut_tetrahedral(x, self.p.lut_3d, 0.25)
         out_f32[y0 - out_gy0:y1 - out_gy0] = torch.from_numpy(x)
+
+    def grain(self, D, d_gy0, G, g_gy0, y0, y1, H):
+        x = self._grained(D, d_gy0, y0, y1, H)
+        G[:, y0 - g_gy0:y1 - g_gy0, :] = torch.from_numpy(np.transpose(x, (2, 0, 1)).copy())
+
+    def burn_sums(self, D, d_gy0, y0, y1, H):
+        green = D.numpy()[1, y0 - d_gy0:y1 - d_gy0, :].astype(np.float64)
+        W = green.shape[1]
+        _, h_lo, w_lo = st.burn_geometry(H, W, self.p.burn_scale)
+        wy, wx = st.area_table(H, h_lo)[:, y0:y1], st.area_table(W, w_lo)
+        return torch.from_numpy((wy @ green @ wx.T).astype(np.float32))
+
+    def burn_map(self, sums, W, H):
+        from scipy import ndimage
+
+        down = np.clip(sums.numpy() - np.float32(self.p.d_ref), 0, None)
+        return torch.from_numpy(ndimage.gaussian_filter(down, sigma=3, truncate=2))
 
     def front_to_output(self, image_rows, in_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
         x = self._front(image_rows, in_gy0, 1, y0, y1)
@@ -94,9 +120,14 @@ def _free_port():
     return port
 
 
-def _inputs(H, W, scale, **kw):
+def _inputs(H, W, scale, burn=0.0, **kw):
     neg, prt, _ = stocks()
-    return oracle_inputs(neg, prt, scale, seed=SEED, **kw), synthetic_frame(H, W, seed=5)
+    p = oracle_inputs(neg, prt, scale, seed=SEED, **kw)
+    img = synthetic_frame(H, W, seed=5)
+    if burn:
+        p.highlight_burn, p.burn_scale, p.d_ref = burn, 10.0, float(neg.d_ref[1])
+        img[10:30, 8:40] *= 10.0
+    return p, img
 
 
 def _worker(rank, world, port, H, W, scale, flags, result_path):
@@ -107,7 +138,7 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
         p, img = _inputs(H, W, scale, **flags)
         be = OracleStageBackend(p)
         rr = sharding.RowShardedRenderer(be, H, W, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None,
-                                         grain=p.grain_lut is not None)
+                                         grain=p.grain_lut is not None, burn=bool(p.highlight_burn))
         r0, r1 = rr.plan.r0, rr.plan.r1
         out = torch.zeros((r1 - r0, W, 3), dtype=torch.float32)
         rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
@@ -136,6 +167,8 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
         (64, 48, 160.0, dict(halation=False, grain=0)),
         (40, 32, 60.0, dict(halation=False, mtf=False)),
         (40, 32, 60.0, dict(halation=False, mtf=False, grain=0)),  # LUTs only: fused pointwise pass
+        (97, 64, 120.0, dict(burn=0.7)),  # S7 on top of everything: all-reduce of the low-res cell sums
+        (64, 48, 100.0, dict(burn=0.7, halation=False, mtf=False, grain=0)),
     ],
 )
 def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
