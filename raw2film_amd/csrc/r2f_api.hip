@@ -78,7 +78,11 @@ int fail(r2f_ctx* ctx, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, R2F_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Tables change only when a render parameter changes (the reference's caching rule), so the upload path
+// is allowed to be slow: wait for every render still in flight on any stream before overwriting a table
+// that those kernels may be reading, then copy synchronously.
 int upload(r2f_ctx* ctx, DeviceBuf& buf, const void* host, size_t bytes) {
+    R2F_HIP(ctx, hipDeviceSynchronize());
     if (buf.bytes < bytes) {
         buf.release();
         R2F_HIP(ctx, hipMalloc(&buf.p, bytes));
