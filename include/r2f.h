@@ -141,6 +141,16 @@ int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* den
  * `scratch` holds 2 x the map size. */
 int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums, float* burn_map, float* scratch, int W,
                        int H_global, void* stream);
+/* Pre-path chroma noise reduction, effects.chroma_nr_filter (effects.py:547-561): XYZ -> xyY, a separable
+ * (2*size+1)-tap Gaussian on the two chromaticity planes only (coordinates clamped to the frame), back to XYZ.
+ * Pass 1 (rows independent): `in` -> planes {x blurred horizontally, y blurred horizontally, Y}.
+ * Pass 2 (needs size rows above/below, clamped at the global edges): those planes -> XYZ planes, which
+ * r2f_stage_front / r2f_render accept as R2F_LAYOUT_CHW input. */
+int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy0, int in_rows, const r2f_planes* dst,
+                          int size, int y0, int y1, int W, void* stream);
+int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes* dst, int size, int y0, int y1, int W,
+                          int H_global, void* stream);
+
 /* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
  * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,

@@ -29,6 +29,57 @@ LOG_EPS = 1e-6  # lut_1d.wgsl:24
 LUT3D_SCALE = 0.25  # cpu_processor.py:405, lut_3d.wgsl:1
 
 
+# ------------------------------------------------------------------ pre-path: chroma NR
+def chroma_kernel_1d(size: int) -> np.ndarray:
+    """effects.py:554-556 + gaussian_kernel_1d :421-435: 2*size+1 taps, sigma = 0.3*((taps-1)/2 - 1) + 0.8,
+    exp in double, stored and normalised in float32.  PINNED bit-exact (tests/golden/chroma_nr.npz)."""
+    taps = int(size) * 2 + 1
+    sigma = 0.3 * ((taps - 1) * 0.5 - 1) + 0.8
+    x = np.arange(taps) - taps // 2
+    k = np.exp(-(x * x) / (2.0 * sigma * sigma)).astype(F32)
+    k /= k.sum()
+    return k
+
+
+def xyz_to_xyY(image: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """effects.py:496-518: x = X/(X+Y+Z), y = Y/(X+Y+Z) (0 when the sum <= eps), third channel Y.  float32."""
+    image = np.asarray(image, dtype=F32)
+    X, Y, Z = image[..., 0], image[..., 1], image[..., 2]
+    denom = (X + Y) + Z
+    ok = denom > F32(eps)
+    safe = np.where(ok, denom, F32(1))
+    return np.stack([np.where(ok, X / safe, F32(0)), np.where(ok, Y / safe, F32(0)), Y], axis=-1).astype(F32)
+
+
+def xyY_to_xyz(image: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """effects.py:521-544: inv = Y/y; X = x*inv, Z = (1 - x - y)*inv; all 0 when y <= eps.  float32."""
+    image = np.asarray(image, dtype=F32)
+    cx, cy, Y = image[..., 0], image[..., 1], image[..., 2]
+    ok = cy > F32(eps)
+    inv = Y / np.where(ok, cy, F32(1))
+    out = np.stack([cx * inv, Y, ((F32(1.0) - cx) - cy) * inv], axis=-1)
+    out[~ok] = 0
+    return out.astype(F32)
+
+
+def chroma_nr_filter(image: np.ndarray, size: int) -> np.ndarray:
+    """effects.chroma_nr_filter, effects.py:547-561: XYZ -> xyY, separable Gaussian on the x and y planes only
+    (horizontal then vertical, coordinates clamped to the frame, float64 accumulator under numba, float32 stored
+    between the passes), back to XYZ.  Pinned to 1e-6 against the reference's own code run by CPython (which
+    accumulates in float32, see tools/make_golden.py)."""
+    xyY = xyz_to_xyY(image)
+    k = chroma_kernel_1d(size).astype(np.float64)
+    r = len(k) // 2
+    out = xyY.copy()
+    for ch in (0, 1):
+        plane = xyY[..., ch].astype(np.float64)
+        pad = np.pad(plane, ((0, 0), (r, r)), mode="edge")
+        h = sum(k[i] * pad[:, i:i + plane.shape[1]] for i in range(len(k))).astype(F32).astype(np.float64)
+        pad = np.pad(h, ((r, r), (0, 0)), mode="edge")
+        out[..., ch] = sum(k[i] * pad[i:i + plane.shape[0], :] for i in range(len(k))).astype(F32)
+    return xyY_to_xyz(out)
+
+
 # --------------------------------------------------------------------------- S0
 def apply_matrix3x3(image: np.ndarray, m: np.ndarray) -> np.ndarray:
     """S0 camera->scene 3x3: out = M . in per pixel, fp32.

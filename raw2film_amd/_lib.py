@@ -91,6 +91,14 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, _P(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     ),
+    "r2f_stage_chroma_nr_h": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_stage_chroma_nr_v": (
+        C.c_int,
+        [C.c_void_p, _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
     "r2f_stage_noise": (
         C.c_int,
         [C.c_void_p, _P(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],

@@ -255,6 +255,32 @@ class HipContext:
                                                  H_global, self._stream()))
         return out
 
+    def stage_chroma_nr_h(self, image, dst, size, *, in_gy0=0, dst_gy0=0, y0=None, y1=None):
+        """Pre-path chroma NR pass 1: image rows -> planes (x blurred horizontally, y blurred horizontally, Y)."""
+        self._check_image(image)
+        layout, rows, W = self.layout_of(image)
+        y0 = in_gy0 if y0 is None else y0
+        y1 = in_gy0 + rows if y1 is None else y1
+        pd = self.planes(dst, dst_gy0)
+        self._check(self._lib.r2f_stage_chroma_nr_h(self._h, image.data_ptr(), layout, in_gy0, rows, C.byref(pd), int(size), y0, y1,
+                                                    W, self._stream()))
+
+    def stage_chroma_nr_v(self, src, dst, size, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
+        """Pre-path chroma NR pass 2: vertical blur + xyY -> XYZ planes (CHW input for the front stage)."""
+        ps, pd = self.planes(src, src_gy0), self.planes(dst, dst_gy0)
+        self._check(self._lib.r2f_stage_chroma_nr_v(self._h, C.byref(ps), C.byref(pd), int(size), y0, y1, int(src.shape[2]),
+                                                    H_global, self._stream()))
+
+    def chroma_nr(self, image, size):
+        """effects.chroma_nr_filter on a whole frame: (H, W, 3|4) or (3, H, W) in -> (3, H, W) XYZ planes out."""
+        torch = self._torch
+        _, H, W = self.layout_of(image)
+        tmp = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+        out = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+        self.stage_chroma_nr_h(image, tmp, size)
+        self.stage_chroma_nr_v(tmp, out, size, y0=0, y1=H, H_global=H)
+        return out
+
     def stage_noise(self, params, y0, y1, W, want_hash=True, want_noise=True):
         torch = self._torch
         rows = y1 - y0

@@ -728,6 +728,84 @@ int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums
     return R2F_OK;
 }
 
+static int chroma_weights(r2f_ctx* ctx, int size, ChromaArgs& a) {
+    // gaussian_kernel_1d(2*size+1, 0.3*((taps-1)/2 - 1) + 0.8), effects.py:421-435,554-556: exp in double, float32 taps
+    // normalised by their float32 sum
+    if (size < 1 || 2 * size + 1 > kChromaMaxTaps) return fail(ctx, R2F_EINVAL, "chroma_nr size must be in [1, %d]", (kChromaMaxTaps - 1) / 2);
+    const int taps = 2 * size + 1;
+    const double sigma = 0.3 * ((taps - 1) * 0.5 - 1) + 0.8, s2 = 2.0 * sigma * sigma;
+    float sum = 0.f;
+    for (int i = 0; i < taps; ++i) {
+        const double x = i - size;
+        a.w[i] = (float)exp(-(x * x) / s2);
+    }
+    // numpy's float32 .sum() is pairwise; for <= 63 elements it reduces to 8 interleaved partial sums -- restate that order
+    {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = 0;
+        if (taps >= 8) {
+            for (int j = 0; j < 8; ++j) acc[j] = a.w[j];
+            for (i = 8; i + 8 <= taps; i += 8)
+                for (int j = 0; j < 8; ++j) acc[j] += a.w[i + j];
+            sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
+        for (; i < taps; ++i) sum += a.w[i];
+    }
+    for (int i = 0; i < taps; ++i) a.w[i] /= sum;
+    a.radius = size;
+    return R2F_OK;
+}
+
+int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy0, int in_rows, const r2f_planes* dst, int size,
+                          int y0, int y1, int W, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (y1 <= y0) return R2F_OK;
+    if (!in || W <= 0 || y0 < in_gy0 || y1 > in_gy0 + in_rows || in_layout < 0 || in_layout > 2)
+        return fail(ctx, R2F_EINVAL, "chroma_nr: bad input geometry");
+    ChromaArgs a;
+    memset(&a, 0, sizeof a);
+    int rc = chroma_weights(ctx, size, a);
+    if (rc) return rc;
+    rc = check_rows(ctx, "chroma_nr dst", dst, y0, y1);
+    if (rc) return rc;
+    a.in = in;
+    a.in_layout = in_layout;
+    a.in_gy0 = in_gy0;
+    a.in_rows = in_rows;
+    a.dst = to_dev(dst);
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.H_global = in_gy0 + in_rows;
+    a.vec = planes_vec_ok(dst, W) ? 1 : 0;
+    R2F_HIP(ctx, launch_chroma_h(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes* dst, int size, int y0, int y1, int W,
+                          int H_global, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (y1 <= y0) return R2F_OK;
+    if (W <= 0 || y0 < 0 || y1 > H_global) return fail(ctx, R2F_EINVAL, "chroma_nr: bad geometry");
+    ChromaArgs a;
+    memset(&a, 0, sizeof a);
+    int rc = chroma_weights(ctx, size, a);
+    if (rc) return rc;
+    rc = check_rows(ctx, "chroma_nr dst", dst, y0, y1);
+    if (rc) return rc;
+    rc = check_rows(ctx, "chroma_nr src", src, std::max(y0 - size, 0), std::min(y1 + size, H_global));
+    if (rc) return rc;
+    a.src = to_dev(src);
+    a.dst = to_dev(dst);
+    a.y0 = y0;
+    a.y1 = y1;
+    a.W = W;
+    a.H_global = H_global;
+    a.vec = (planes_vec_ok(src, W) && planes_vec_ok(dst, W)) ? 1 : 0;
+    R2F_HIP(ctx, launch_chroma_v(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1, int W,
                     void* stream) {
     if (!ctx || !p) return R2F_EINVAL;

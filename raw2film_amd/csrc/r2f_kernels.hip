@@ -514,6 +514,116 @@ __global__ __launch_bounds__(256) void burn_map_kernel(const BurnMapArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------ chroma NR (pre-path)
+__device__ __forceinline__ void load_input1(const void* in_, int layout, int in_gy0, int in_rows, int W, int gy, int x,
+                                            float& X, float& Y, float& Z) {
+    const float* in = static_cast<const float*>(in_);
+    const long long row = gy - in_gy0;
+    if (layout == R2F_LAYOUT_CHW) {
+        const long long plane = (long long)in_rows * W, o = row * W + x;
+        X = in[o];
+        Y = in[plane + o];
+        Z = in[2 * plane + o];
+    } else {
+        const int nc = layout == R2F_LAYOUT_HWC4 ? 4 : 3;
+        const float* p = in + (row * W + x) * nc;
+        X = p[0];
+        Y = p[1];
+        Z = p[2];
+    }
+}
+
+// effects.XYZ_to_xyY, effects.py:496-518
+__device__ __forceinline__ void xyz_to_xy(float X, float Y, float Z, float& cx, float& cy) {
+    const float denom = (X + Y) + Z;
+    if (denom > 1e-8f) {
+        cx = X / denom;
+        cy = Y / denom;
+    } else {
+        cx = 0.f;
+        cy = 0.f;
+    }
+}
+
+// Pass 1: one workgroup = one row segment of 1024 pixels.  Chromaticities of the segment plus `radius` clamped
+// neighbours on each side are staged in LDS (the one truly separable blur near this path), then every lane blurs its
+// 4 pixels horizontally.  Output planes: x', y', Y.
+constexpr int kChromaSeg = 1024;
+__global__ __launch_bounds__(256) void chroma_h_kernel(const ChromaArgs a) {
+    __shared__ float sx[kChromaSeg + 2 * 31], sy[kChromaSeg + 2 * 31];
+    const int gy = a.y0 + blockIdx.y;
+    const int seg0 = blockIdx.x * kChromaSeg;
+    const int r = a.radius;
+    const int n = kChromaSeg + 2 * r;
+    float Yown[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int gx = clampi(seg0 - r + i, 0, a.W - 1);  // ix = min(max(x + i, 0), w - 1), effects.py:452
+        float X, Y, Z;
+        load_input1(a.in, a.in_layout, a.in_gy0, a.in_rows, a.W, gy, gx, X, Y, Z);
+        xyz_to_xy(X, Y, Z, sx[i], sy[i]);
+    }
+    __syncthreads();
+    const int x0 = seg0 + 4 * threadIdx.x;
+    if (x0 >= a.W) return;
+    const int nv = min(4, a.W - x0);
+    float bx[4], by[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float accx = 0.f, accy = 0.f;
+        const int c = 4 * threadIdx.x + p;  // window [c, c + 2r] in LDS
+        for (int t = 0; t <= 2 * r; ++t) {
+            accx = fmaf(sx[c + t], a.w[t], accx);
+            accy = fmaf(sy[c + t], a.w[t], accy);
+        }
+        bx[p] = accx;
+        by[p] = accy;
+        if (p < nv) {
+            float X, Y, Z;
+            load_input1(a.in, a.in_layout, a.in_gy0, a.in_rows, a.W, gy, x0 + p, X, Y, Z);
+            Yown[p] = Y;
+        }
+    }
+    store_planes4(a.dst, gy, x0, a.W, nv, a.vec != 0, bx, by, Yown);
+}
+
+// Pass 2: vertical blur of x', y' (rows clamped to the frame) and effects.xyY_to_XYZ (effects.py:521-544).
+__global__ __launch_bounds__(256) void chroma_v_kernel(const ChromaArgs a) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int gy = a.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.W || gy >= a.y1) return;
+    const int nv = min(4, a.W - x);
+    const bool vec = a.vec != 0;
+    const int r = a.radius;
+    float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
+    float Yc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t <= 2 * r; ++t) {
+        const int sy = clampi(gy - r + t, 0, a.H_global - 1);  // iy = min(max(y + i, 0), h - 1), effects.py:476
+        float px[4], py[4], pY[4];
+        load_planes4(a.src, sy, x, a.W, nv, vec, px, py, pY);
+        const float w = a.w[t];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ax[p] = fmaf(px[p], w, ax[p]);
+            ay[p] = fmaf(py[p], w, ay[p]);
+            if (t == r) Yc[p] = pY[p];
+        }
+    }
+    float X[4], Z[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (ay[p] > 1e-8f) {
+            const float inv = Yc[p] / ay[p];
+            X[p] = ax[p] * inv;
+            Z[p] = ((1.0f - ax[p]) - ay[p]) * inv;
+        } else {
+            X[p] = 0.f;
+            Yc[p] = 0.f;
+            Z[p] = 0.f;
+        }
+    }
+    store_planes4(a.dst, gy, x, a.W, nv, vec, X, Yc, Z);
+}
+
 // ------------------------------------------------------------------------------ noise (test)
 __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -639,6 +749,19 @@ hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s) {
 
 hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(burn_map_kernel, dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_chroma_h(const ChromaArgs& a, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    hipLaunchKernelGGL(chroma_h_kernel, dim3((a.W + kChromaSeg - 1) / kChromaSeg, a.y1 - a.y0), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    const int quads = (a.W + 3) / 4;
+    hipLaunchKernelGGL(chroma_v_kernel, dim3((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 

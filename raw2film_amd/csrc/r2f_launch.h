@@ -84,6 +84,18 @@ struct TailArgs {
     int vec;
 };
 
+constexpr int kChromaMaxTaps = 63;
+struct ChromaArgs {
+    const void* in;  // pass 1 input image
+    int in_layout, in_gy0, in_rows;
+    DevPlanes src;  // pass 2 input planes
+    DevPlanes dst;
+    int y0, y1, W, H_global;
+    int radius;  // taps = 2*radius + 1
+    int vec;
+    float w[kChromaMaxTaps];
+};
+
 struct NoiseArgs {
     uint32_t* hash;
     float* noise;
@@ -114,5 +126,7 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s);
 hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s);
+hipError_t launch_chroma_h(const ChromaArgs& a, hipStream_t s);
+hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s);
 
 }  // namespace r2f

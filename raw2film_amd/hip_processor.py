@@ -6,8 +6,8 @@ keyword names and defaults, unknown keywords swallowed, LUTs / stencils rebuilt 
 re-uploaded only when their parameter dict changes (cpu_processor.py:104-105,157-158,...).
 
 Scope: the post-decode per-pixel path, plus the index-only geometry around it (aspect crop, zoom,
-quarter turns before; canvas after) and the highlight burn (S7).  RAW decoding, lens correction, free
-rotation, chroma NR and the `max_scale` resize belong to the rows SURVEY.md section 8f lists as "next";
+quarter turns before; canvas after), the pre-path chroma NR and the highlight burn (S7).  RAW decoding, lens
+correction, free rotation and the `max_scale` resize belong to the rows SURVEY.md section 8f lists as "next";
 asking for them raises NotImplementedError instead of silently rendering something else.
 
 `src` is therefore a decoded frame: a float32 (H, W, 3|4) array / CUDA tensor in linear CIE XYZ
@@ -161,8 +161,6 @@ class HipProcessor:
             raise NotImplementedError(
                 "free rotation (effects.rotate -> cv.warpAffine) is outside the accelerated path (SURVEY.md section 8f)"
             )
-        if chroma_nr:
-            raise NotImplementedError("chroma NR is outside the accelerated path (SURVEY.md section 8f)")
         # aspect crop / zoom / quarter turns: index arithmetic of raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72)
         image = geometry.crop_to_frame(image, frame_width, frame_height, zoom, rotate_times, flip)
         h, w = image.shape[:2]
@@ -185,6 +183,8 @@ class HipProcessor:
             "output_resolution": (w, h),
             "canvas_resolution": canvas_res,
             "pipeline_resolution": (w, h),
+            # upstream filters on the host here (gpu_processor.py:750-751); this backend filters on the device in phase 2
+            "chroma_nr": int(chroma_nr),
         }
 
     @staticmethod
@@ -246,6 +246,8 @@ class HipProcessor:
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
         image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
+        if cpu_payload.get("chroma_nr"):  # pre-path chroma NR (effects.py:547-561): XYZ planes out, CHW into the pipeline
+            image = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"])
         _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,
                                            **settings)
         # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic

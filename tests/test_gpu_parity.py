@@ -462,3 +462,44 @@ def test_full_pipeline_with_highlight_burn(ctx, grain):
     params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 50.0)[0], 0.7, float(neg.d_ref[1])
     out, _ = ctx.render(dev(img), params)
     assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "pipeline with burn")
+
+
+# ------------------------------------------------------------------------------- pre-path chroma NR
+@pytest.mark.parametrize("layout", ["hwc3", "hwc4", "chw"])
+@pytest.mark.parametrize("shape,size", [((28, 36), 2), ((70, 1100), 5), ((33, 50), 10), ((1, 9), 3)])
+def test_chroma_nr_against_oracle(ctx, layout, shape, size):
+    H, W = shape
+    xyz = st.apply_matrix3x3(synthetic_frame(H, W, seed=80 + size), st.REC709_TO_XYZ)
+    xyz[0, :2] = 0.0
+    ref = st.chroma_nr_filter(xyz, size)
+    if layout == "hwc3":
+        t = dev(xyz)
+    elif layout == "hwc4":
+        t = dev(np.concatenate([xyz, np.ones((H, W, 1), np.float32)], axis=-1))
+    else:
+        t = to_planes(xyz)
+    out = from_planes(ctx.chroma_nr(t, size))
+    assert_close(out, ref, 5e-6, 1e-4, f"chroma nr {shape} size {size}")
+
+
+def test_chroma_nr_against_reference_golden(ctx, golden_dir):
+    import os
+
+    nr = np.load(os.path.join(golden_dir, "chroma_nr.npz"))
+    for i, size in enumerate(nr["sizes"][:4]):
+        out = from_planes(ctx.chroma_nr(dev(nr["xyz"]), int(size)))
+        np.testing.assert_allclose(out, nr[f"out_{i}"], rtol=4e-6, atol=1e-9)
+
+
+def test_chroma_nr_row_shards_bitwise(ctx):
+    H, W, size = 60, 80, 4
+    xyz = st.apply_matrix3x3(synthetic_frame(H, W, seed=90), st.REC709_TO_XYZ)
+    t = dev(xyz)
+    whole = ctx.chroma_nr(t, size)
+    tmp = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_chroma_nr_h(t, tmp, size)
+    out = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    for a, b in ((0, 17), (17, 41), (41, 60)):
+        lo, hi = max(a - size, 0), min(b + size, H)
+        ctx.stage_chroma_nr_v(tmp[:, lo:hi].contiguous(), out, size, src_gy0=lo, y0=a, y1=b, H_global=H)
+    np.testing.assert_array_equal(out.cpu().numpy(), whole.cpu().numpy())

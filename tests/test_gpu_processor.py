@@ -117,3 +117,15 @@ def test_highlight_burn_through_the_processor(proc):
     p.highlight_burn, p.burn_scale, p.d_ref = 0.8, 30.0, float(neg.d_ref[1])
     assert _u8_close(burnt, st.to_uint8(st.render(img, p)))
     assert np.abs(burnt.astype(int) - plain.astype(int)).max() > 5
+
+
+def test_chroma_nr_through_the_processor(proc):
+    neg, prt, _ = stocks()
+    H, W = 80, 120
+    img = _xyz(H, W, seed=47)
+    kw = dict(print_film=prt, halation=False, sharpness=False, grain=0, exp_kelvin=6000, color_masking=1.0)
+    out = proc.process(img, neg, 6, 0.4, chroma_nr=3, **kw)
+    p = oracle_inputs(neg, prt, max(H, W) / 36, halation=False, mtf=False, grain=0, matrix=False)
+    ref = st.to_uint8(st.render(st.chroma_nr_filter(img, 3), p))
+    assert _u8_close(out, ref)
+    assert np.abs(out.astype(int) - proc.process(img, neg, 6, 0.4, **kw).astype(int)).max() > 3

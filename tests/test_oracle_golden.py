@@ -96,3 +96,26 @@ def test_compute_kernel_from_function_bit_exact(mtf):
     for j, (size_mm, px_mm) in enumerate(mtf["ckf_args"]):
         k = ok.compute_kernel_from_function(lambda f: np.exp(-((f / 40.0) ** 2)), float(size_mm), float(px_mm))
         np.testing.assert_array_equal(k, mtf[f"ckf_{j}"])
+
+
+@pytest.fixture(scope="module")
+def nr(golden_dir):
+    return np.load(os.path.join(golden_dir, "chroma_nr.npz"))
+
+
+def test_chroma_nr_kernel_bit_exact(nr):
+    for i, size in enumerate(nr["sizes"]):
+        np.testing.assert_array_equal(st.chroma_kernel_1d(int(size)), nr[f"kernel_{i}"])
+
+
+def test_chroma_nr_colour_space_round_trip_bit_exact(nr):
+    np.testing.assert_array_equal(st.xyz_to_xyY(nr["xyz"]), nr["xyY"])
+
+
+def test_chroma_nr_filter_matches_reference(nr):
+    for i, size in enumerate(nr["sizes"][:4]):
+        out = st.chroma_nr_filter(nr["xyz"], int(size))
+        ref = nr[f"out_{i}"]
+        assert out.dtype == np.float32
+        np.testing.assert_allclose(out, ref, rtol=2e-6, atol=1e-9)
+        np.testing.assert_array_equal(out[..., 1], nr["xyz"][..., 1] * (nr["xyY"][..., 1] > 1e-8))  # Y passes through

@@ -147,7 +147,8 @@ def test_extract_image_data_cpu_payload(proc):
     assert payload["image_array"].shape == (40, 60, 4) and payload["image_array"].dtype == np.float32
     assert payload["image_array"][..., :3].max() == 65504.0 and np.all(payload["image_array"][..., 3] == 1.0)
     assert payload["output_resolution"] == (60, 40) and payload["pipeline_resolution"] == (60, 40)
-    assert payload["canvas_resolution"] is None
+    assert payload["canvas_resolution"] is None and payload["chroma_nr"] == 0
+    assert proc.extract_image_data_cpu(img, chroma_nr=3)["chroma_nr"] == 3
 
 
 def test_settings_merge_and_preview_gating():

@@ -12,6 +12,7 @@ What is executed (imported from /root/reference/src, nothing is copied):
   raw2film.effects.compute_kernel_from_function   effects.py:123-143
   raw2film.effects.mtf_kernel_layer / mtf_kernel  effects.py:159-185
   raw2film.effects.crop_image / get_canvas_data   effects.py:77-111, 290-333
+  raw2film.effects.chroma_nr_filter (+ helpers)   effects.py:421-561
 
 Third-party modules that are absent from this image are replaced by inert stubs
 (SURVEY.md appendix A).  The only stub with a body is `numba.njit` (identity
@@ -240,7 +241,26 @@ def main():
     geo["canvas_out"] = np.array(canvas_out)
     np.savez_compressed(os.path.join(OUT_DIR, "geometry.npz"), **geo)
 
-    for name in ("tetrahedral", "halation_kernels", "mtf_kernels", "geometry"):
+    # ---- 5. chroma noise reduction (effects.py:421-561): the separable masked Gaussian in xyY ----
+    # CPython runs the numba loops with a float32 accumulator (`acc = 0.0` is a weak Python float, NEP 50) where numba
+    # keeps float64; the fixture therefore pins the oracle to ~1e-6, not bit for bit.
+    nr = {}
+    sizes = [1, 2, 3, 5, 10]
+    nr["sizes"] = np.array(sizes)
+    for i, size in enumerate(sizes):
+        taps = int(size) * 2 + 1
+        sigma = 0.3 * ((taps - 1) * 0.5 - 1) + 0.8
+        nr[f"kernel_{i}"] = ref_effects.gaussian_kernel_1d(taps, sigma)
+    xyz = (0.18 * 2.0 ** rng.normal(0, 1.5, (28, 36, 1)) * rng.uniform(0.6, 1.4, (28, 36, 3))).astype(np.float32)
+    xyz[3, 4] = 0.0  # denom <= eps branch
+    xyz[5, 6] = (1e-9, 0.0, 2e-9)
+    nr["xyz"] = xyz
+    nr["xyY"] = ref_effects.XYZ_to_xyY(xyz)
+    for i, size in enumerate(sizes[:4]):
+        nr[f"out_{i}"] = ref_effects.chroma_nr_filter(xyz, size)
+    np.savez_compressed(os.path.join(OUT_DIR, "chroma_nr.npz"), **nr)
+
+    for name in ("tetrahedral", "halation_kernels", "mtf_kernels", "geometry", "chroma_nr"):
         p = os.path.join(OUT_DIR, name + ".npz")
         print(f"{p}: {os.path.getsize(p) / 1024:.0f} KiB")
 
