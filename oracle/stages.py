@@ -273,21 +273,24 @@ def gaussian_noise(xs: np.ndarray, ys: np.ndarray, seed: int, mono: bool = False
 
 
 def grain_field(
-    H: int, W: int, seed: int, grain_kernel: np.ndarray, mono: bool = False, row0: int = 0, H_global: int | None = None
+    H: int, W: int, seed: int, grain_kernel: np.ndarray, mono: bool = False, row0: int = 0, H_global: int | None = None,
+    col0: int = 0, W_global: int | None = None,
 ) -> np.ndarray:
     """S6b G = K_g (*) N with the noise texture clamped at the image border
     (grain.wgsl:48-75: start = p - k//2, taps in row-major order, `clamp(coord, 0, dims-1)`).
-    Rows [row0, row0+H) of a frame that is H_global rows tall (row shards evaluate the hash
-    at true global coordinates, so the field is identical for any sharding)."""
+    Rows [row0, row0+H) x columns [col0, col0+W) of a frame of H_global x W_global pixels (row shards and
+    test windows evaluate the hash at true global coordinates, so the field is identical for any sharding)."""
     if H_global is None:
         H_global = row0 + H
+    if W_global is None:
+        W_global = col0 + W
     k = np.asarray(grain_kernel, dtype=np.float64)
     if k.ndim == 2:
         k = k[..., None]
     kh, kw = k.shape[:2]
     ay, ax = kh // 2, kw // 2
     ys = np.clip(np.arange(row0 - ay, row0 + H + kh - 1 - ay), 0, H_global - 1)
-    xs = np.clip(np.arange(-ax, W + kw - 1 - ax), 0, W - 1)
+    xs = np.clip(np.arange(col0 - ax, col0 + W + kw - 1 - ax), 0, W_global - 1)
     noise = gaussian_noise(xs[None, :], ys[:, None], seed, mono).astype(np.float64)
     out = np.zeros((H, W, 3), dtype=np.float64)
     for c in range(3):
@@ -307,6 +310,8 @@ def apply_grain(
     mono: bool = False,
     row0: int = 0,
     H_global: int | None = None,
+    col0: int = 0,
+    W_global: int | None = None,
 ) -> np.ndarray:
     """S6 = effects.py:220-236 + the clip at cpu_processor.py:397.  PARITY UNPINNED
     (sfl.generate_grain / FilmSpectral.grain_transform); restates grain.wgsl:78-89:
@@ -314,7 +319,7 @@ def apply_grain(
     then max(out, 0)."""
     density = np.asarray(density, dtype=F32)
     H, W = density.shape[:2]
-    G = grain_field(H, W, seed, grain_kernel, mono, row0, H_global)
+    G = grain_field(H, W, seed, grain_kernel, mono, row0, H_global, col0, W_global)
     factor = multi_channel_interp(density, grain_lut)
     return np.maximum(density + G * factor, F32(0.0)).astype(F32)
 

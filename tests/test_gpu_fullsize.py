@@ -1,0 +1,86 @@
+"""Parity at BASELINE.json's full frame size (12288 x 8192, 87 / 35 / 9-tap stencils), where a whole-frame oracle run
+would take minutes: (1) windows of the GPU result against the oracle evaluated on window + halo, with the grain hash at
+global coordinates, (2) row shards against the whole frame, bit for bit, (3) a constant frame stays constant."""
+
+import numpy as np
+import pytest
+
+from oracle import stages as st
+
+from helpers import SEED, oracle_inputs, stocks
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+W_FULL, H_FULL = 12288, 8192
+SCALE = W_FULL / 36.0
+
+
+@pytest.fixture(scope="module")
+def full():
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame_device
+    from test_gpu_parity import setup_ctx
+
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, SCALE, seed=SEED)
+    ctx = HipContext(0)
+    params = setup_ctx(ctx, p)
+    frame = synthetic_frame_device(H_FULL, W_FULL, seed=7)
+    out, _ = ctx.render(frame, params)
+    torch.cuda.synchronize()
+    yield ctx, params, p, frame, out
+    ctx.close()
+
+
+@pytest.mark.parametrize("y0,x0", [(0, 0), (4000, 6000), (H_FULL - 96, W_FULL - 96), (63, 12288 - 200)])
+def test_windows_of_the_100mp_render_match_the_oracle(full, y0, x0):
+    ctx, params, p, frame, out = full
+    n = 96  # window side; the oracle runs on window + halo
+    halo = 42 + 17 + 4  # halation + MTF + grain reach
+    ya, yb = max(y0 - halo, 0), min(y0 + n + halo, H_FULL)
+    xa, xb = max(x0 - halo, 0), min(x0 + n + halo, W_FULL)
+    # a crop in the interior has no real border; reflect-101 inside the oracle only touches the discarded halo.  At the
+    # frame's own edges the crop edge IS the frame edge, so the reflection is the real one.
+    crop = frame[ya:yb, xa:xb].cpu().numpy()
+    x = st.apply_2d_lut(st.apply_matrix3x3(crop, p.matrix), p.lut_2d)
+    x = st.halation(x, p.halation_kernel)
+    x = st.multi_channel_interp(st.log_clip(x), p.lut_1d)
+    x = st.film_sharpness(x, p.mtf_kernel)
+    x = st.apply_grain(x, p.grain_lut, p.grain_kernel, p.seed, False, row0=ya, H_global=H_FULL, col0=xa, W_global=W_FULL)
+    ref = st.apply_lut_tetrahedral(x, p.lut_3d, 0.25)[y0 - ya:y0 - ya + n, x0 - xa:x0 - xa + n]
+    got = out[y0:y0 + n, x0:x0 + n].cpu().numpy()
+    err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 0.1))
+    assert err <= 1e-5, err
+
+
+def test_row_shards_of_the_100mp_frame_are_bit_identical(full):
+    ctx, params, p, frame, out = full
+    rh, rm = p.halation_kernel.shape[0] // 2, p.mtf_kernel.shape[0] // 2
+    bounds = [0, 1000, 4096, 5121, H_FULL]  # uneven shards, each at least a halo tall
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        d_lo, d_hi = max(a - rm, 0), min(b + rm, H_FULL)
+        e_lo, e_hi = max(d_lo - rh, 0), min(d_hi + rh, H_FULL)
+        E = torch.empty((3, e_hi - e_lo, W_FULL), dtype=torch.float32, device="cuda")
+        ctx.stage_front(frame[e_lo:e_hi], params, 0, in_gy0=e_lo, dst=E, dst_gy0=e_lo, H_global=H_FULL)
+        D = torch.empty((3, d_hi - d_lo, W_FULL), dtype=torch.float32, device="cuda")
+        ctx.stage_halation(E, D, params, src_gy0=e_lo, dst_gy0=d_lo, y0=d_lo, y1=d_hi, H_global=H_FULL)
+        D2 = torch.empty((3, b - a, W_FULL), dtype=torch.float32, device="cuda")
+        ctx.stage_mtf(D, D2, params, src_gy0=d_lo, dst_gy0=a, y0=a, y1=b, H_global=H_FULL)
+        part = torch.empty((b - a, W_FULL, 3), dtype=torch.float32, device="cuda")
+        ctx.stage_tail(D2, params, src_gy0=a, out_f32=part, out_gy0=a, y0=a, y1=b, H_global=H_FULL)
+        assert torch.equal(part, out[a:b]), (a, b)
+        del E, D, D2, part
+
+
+def test_a_constant_100mp_frame_stays_constant(full):
+    """Every stencil sums to 1, so with grain off a flat frame must come out flat, at the value the pointwise chain gives."""
+    ctx, params, p, frame, out = full
+    flat = torch.full((H_FULL, W_FULL, 3), 0.18, dtype=torch.float32, device="cuda")
+    q = ctx.make_params(matrix=True, halation=True, mtf=True, grain=False)
+    res, _ = ctx.render(flat, q)
+    p2 = oracle_inputs(*stocks()[:2], SCALE, grain=0, halation=False, mtf=False)
+    expect = st.render(np.full((2, 2, 3), 0.18, np.float32), p2)[0, 0]
+    lo, hi = res.amin(dim=(0, 1)).cpu().numpy(), res.amax(dim=(0, 1)).cpu().numpy()
+    assert np.all(hi - lo <= 2e-6), (lo, hi)
+    np.testing.assert_allclose(lo, expect, rtol=0, atol=3e-6)
