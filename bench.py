@@ -96,19 +96,11 @@ def main():
     frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}")
     out = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device=frame.device)
 
-    # time the dominant kernel with events on the launch stream, inside the timed steps
-    hal_events = []
-    if effects:
-        real_halation = backend.halation
+    # time every stage with events on the launch stream, inside the timed steps (the dominant one feeds `roofline`)
+    from raw2film_amd.tracing import TimedBackend
 
-        def timed_halation(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            real_halation(*a, **k)
-            e1.record()
-            hal_events.append((e0, e1))
-
-        backend.halation = timed_halation
+    timed = TimedBackend(backend)
+    renderer.backend = timed
 
     def barrier():
         torch.cuda.synchronize()
@@ -123,7 +115,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    hal_events.clear()
+    timed.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -163,8 +155,10 @@ def main():
         },
     }
 
-    if effects and hal_events:
-        hal_ms = float(np.mean([a.elapsed_time(b) for a, b in hal_events]))
+    stage_ms = timed.summary()
+    result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+    if effects and "halation" in stage_ms:
+        hal_ms = float(stage_ms["halation"])
         px = (r1 - r0) * W
         nnz = [int(np.count_nonzero(hal_k[..., c])) for c in range(3)]
         flops_nnz = 2.0 * sum(nnz) * px  # one FMA per non-zero tap per pixel

@@ -86,3 +86,24 @@ def test_two_rank_hip_row_shards_with_highlight_burn(tmp_path):
     np.testing.assert_allclose(sharded, whole, rtol=0, atol=2e-6)
     ref, _ = proc.ctx.render(img, params)
     np.testing.assert_allclose(whole, ref.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_timed_backend_reports_every_stage():
+    from raw2film_amd import HipProcessor, stencils
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+    from raw2film_amd.tracing import TimedBackend
+
+    neg, prt, _ = stocks()
+    H, W = 128, 192
+    proc = HipProcessor(device=0)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=2.0,
+                          frame_height=2.0 * H / W, highlight_burn=0.5)
+    be = TimedBackend(HipStageBackend(proc.ctx, params, (23, 23), (9, 9)))
+    rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, burn=True, rank=0, world=1)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    rr.render(torch.from_numpy(synthetic_frame(H, W, seed=3)).cuda(), out_f32=out)
+    ms = be.summary()
+    assert set(ms) == {"front", "halation", "mtf", "grain", "burn_sums", "burn_map", "tail"}
+    assert all(v > 0 for v in ms.values())
+    proc.close()
