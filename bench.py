@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before HIP initialises
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -64,7 +65,6 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
     batch = args.config == "cfg5_batch"  # BASELINE config 5: 64 x 24 MP frames, full pipeline, frame-per-GPU, no collectives
