@@ -1,0 +1,75 @@
+"""Randomised configurations of the whole path against the oracle (fixed seeds, so failures reproduce)."""
+
+import numpy as np
+import pytest
+
+from oracle import stages as st
+
+from helpers import assert_close, oracle_inputs, stocks, synthetic_frame
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _cases(n=24):
+    rng = np.random.default_rng(20261002)
+    out = []
+    for i in range(n):
+        H, W = int(rng.integers(1, 220)), int(rng.integers(1, 300))
+        out.append(dict(
+            H=H, W=W, scale=float(rng.choice([14.22, 40.0, 97.3, 166.67, 260.0, 341.33, 400.0])),
+            halation=bool(rng.integers(0, 2)), mtf=bool(rng.integers(0, 2)), grain=int(rng.integers(0, 3)),
+            bw=bool(rng.integers(0, 4) == 0), green=float(rng.choice([0.0, 0.3, 0.4, 1.0])),
+            hal_size=float(rng.choice([0.5, 1.0, 1.7])), strength=float(rng.choice([0.0, 0.0, 0.6])),
+            grain_size=float(rng.choice([2.0, 6.0, 12.0])), layout=str(rng.choice(["hwc3", "hwc4", "chw"])),
+            burn=float(rng.choice([0.0, 0.0, 0.5])), nr=int(rng.choice([0, 0, 2])), seed=int(rng.integers(0, 2**31)),
+        ))
+    return out
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from raw2film_amd.context import HipContext
+
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("c", _cases(), ids=lambda c: f"{c['H']}x{c['W']}-s{c['scale']:.0f}-h{int(c['halation'])}m{int(c['mtf'])}g{c['grain']}")
+def test_random_configuration(ctx, c):
+    from test_gpu_parity import dev, setup_ctx, to_planes
+
+    neg, prt, bw = stocks()
+    stock = bw if c["bw"] else neg
+    p = oracle_inputs(stock, prt, c["scale"], halation=c["halation"], mtf=c["mtf"], grain=c["grain"], seed=c["seed"],
+                      halation_green_factor=c["green"], halation_size=c["hal_size"], sharpening_strength=c["strength"],
+                      grain_size=c["grain_size"])
+    H, W = c["H"], c["W"]
+    img = synthetic_frame(H, W, seed=c["seed"] % 1000)
+    src = img
+    if c["nr"]:
+        p.matrix = None  # chroma NR works on XYZ: apply S0 up front
+        src = st.apply_matrix3x3(img, st.REC709_TO_XYZ)
+        img_o = st.chroma_nr_filter(src, c["nr"])
+    else:
+        img_o = img
+    if c["burn"]:
+        p.highlight_burn, p.burn_scale, p.d_ref = c["burn"], 20.0, float(stock.d_ref[1])
+    ref = st.render(img_o, p)
+    params = setup_ctx(ctx, p)
+    if c["burn"]:
+        params.flags |= 32
+        params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 20.0)[0], c["burn"], float(stock.d_ref[1])
+    if c["layout"] == "hwc3":
+        t = dev(src)
+    elif c["layout"] == "hwc4":
+        t = dev(np.concatenate([src, np.ones((H, W, 1), np.float32)], axis=-1))
+    else:
+        t = to_planes(src)
+    if c["nr"]:
+        t = ctx.chroma_nr(t, c["nr"])
+    out, u8 = ctx.render(t, params, want_f32=True, want_u8=True)
+    # chroma NR divides by the (blurred) y chromaticity: a 2e-6 difference there is amplified in X and Z
+    assert_close(out.cpu().numpy(), ref, 3e-5 if c["nr"] else 1e-5, 1e-1, str(c))
+    assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1
