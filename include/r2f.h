@@ -151,6 +151,12 @@ int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy
 int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes* dst, int size, int y0, int y1, int W,
                           int H_global, void* stream);
 
+/* Pre-path down-scale to the preview / pipeline resolution: cv.resize(..., interpolation=cv.INTER_AREA) as
+ * utils.resolution_scaling applies it when the target is smaller than the frame (utils.py:226-236, called at
+ * cpu_processor.py:134).  `in` is a whole H x W frame (any in_layout); `dst` receives out_h x out_w planes. */
+int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
+                    void* stream);
+
 /* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
  * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,

@@ -99,6 +99,10 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
+    "r2f_resize_area": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(Planes), C.c_int, C.c_int, C.c_void_p],
+    ),
     "r2f_stage_noise": (
         C.c_int,
         [C.c_void_p, _P(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],

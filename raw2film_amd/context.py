@@ -281,6 +281,17 @@ class HipContext:
         self.stage_chroma_nr_v(tmp, out, size, y0=0, y1=H, H_global=H)
         return out
 
+    def resize_area(self, image, out_h, out_w):
+        """Pre-path INTER_AREA down-scale of a whole frame -> (3, out_h, out_w) planes."""
+        torch = self._torch
+        self._check_image(image)
+        layout, H, W = self.layout_of(image)
+        out = torch.empty((3, int(out_h), int(out_w)), dtype=torch.float32, device=self.device)
+        pd = self.planes(out, 0)
+        self._check(self._lib.r2f_resize_area(self._h, image.data_ptr(), layout, H, W, C.byref(pd), int(out_h), int(out_w),
+                                              self._stream()))
+        return out
+
     def stage_noise(self, params, y0, y1, W, want_hash=True, want_noise=True):
         torch = self._torch
         rows = y1 - y0

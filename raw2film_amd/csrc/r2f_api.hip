@@ -728,6 +728,25 @@ int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums
     return R2F_OK;
 }
 
+int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
+                    void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (!in || in_layout < 0 || in_layout > 2 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || out_h > H || out_w > W)
+        return fail(ctx, R2F_EINVAL, "resize_area: the target must be a non-empty frame no larger than the source");
+    int rc = check_rows(ctx, "resize dst", dst, 0, out_h);
+    if (rc) return rc;
+    ResizeArgs a;
+    a.in = in;
+    a.in_layout = in_layout;
+    a.H = H;
+    a.W = W;
+    a.dst = to_dev(dst);
+    a.out_h = out_h;
+    a.out_w = out_w;
+    R2F_HIP(ctx, launch_resize_area(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
 static int chroma_weights(r2f_ctx* ctx, int size, ChromaArgs& a) {
     // gaussian_kernel_1d(2*size+1, 0.3*((taps-1)/2 - 1) + 0.8), effects.py:421-435,554-556: exp in double, float32 taps
     // normalised by their float32 sum

@@ -624,6 +624,39 @@ __global__ __launch_bounds__(256) void chroma_v_kernel(const ChromaArgs a) {
     store_planes4(a.dst, gy, x, a.W, nv, vec, X, Yc, Z);
 }
 
+// ------------------------------------------------------------------------------ area down-scale (pre-path)
+// One lane per destination pixel: weighted mean over its source footprint with the INTER_AREA weights of
+// area_cell() above, all three channels at once.  Pre-path and run once per preview; no tuning beyond coalesced x.
+__global__ __launch_bounds__(256) void resize_area_kernel(const ResizeArgs a) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= a.out_w || dy >= a.out_h) return;
+    int ry0, ry1, rs1, rs2, cx0, cx1, cs1, cs2;
+    double wyf, wy, wyl, wxf, wx, wxl;
+    area_cell(dy, (double)a.H / a.out_h, a.H, ry0, ry1, rs1, rs2, wyf, wy, wyl);
+    area_cell(dx, (double)a.W / a.out_w, a.W, cx0, cx1, cs1, cs2, wxf, wx, wxl);
+    float accX = 0.f, accY = 0.f, accZ = 0.f;
+    for (int y = ry0; y <= ry1; ++y) {
+        const float wv = area_weight(y, rs1, rs2, wyf, wy, wyl);
+        if (wv == 0.f) continue;
+        float rX = 0.f, rY = 0.f, rZ = 0.f;
+        for (int x = cx0; x <= cx1; ++x) {
+            const float wh = area_weight(x, cs1, cs2, wxf, wx, wxl);
+            float X, Y, Z;
+            load_input1(a.in, a.in_layout, 0, a.H, a.W, y, x, X, Y, Z);
+            rX = fmaf(wh, X, rX);
+            rY = fmaf(wh, Y, rY);
+            rZ = fmaf(wh, Z, rZ);
+        }
+        accX = fmaf(wv, rX, accX);
+        accY = fmaf(wv, rY, accY);
+        accZ = fmaf(wv, rZ, accZ);
+    }
+    float* p0 = a.dst.data + (long long)(dy - a.dst.gy0) * a.out_w + dx;
+    p0[0] = accX;
+    p0[a.dst.plane_stride] = accY;
+    p0[2 * a.dst.plane_stride] = accZ;
+}
+
 // ------------------------------------------------------------------------------ noise (test)
 __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -762,6 +795,12 @@ hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     const int quads = (a.W + 3) / 4;
     hipLaunchKernelGGL(chroma_v_kernel, dim3((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4), dim3(64, 4), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_area(const ResizeArgs& a, hipStream_t s) {
+    if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(resize_area_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 

@@ -96,6 +96,13 @@ struct ChromaArgs {
     float w[kChromaMaxTaps];
 };
 
+struct ResizeArgs {
+    const void* in;
+    int in_layout, H, W;
+    DevPlanes dst;
+    int out_h, out_w;
+};
+
 struct NoiseArgs {
     uint32_t* hash;
     float* noise;
@@ -128,5 +135,6 @@ hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s);
 hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s);
 hipError_t launch_chroma_h(const ChromaArgs& a, hipStream_t s);
 hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s);
+hipError_t launch_resize_area(const ResizeArgs& a, hipStream_t s);
 
 }  // namespace r2f

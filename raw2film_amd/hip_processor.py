@@ -164,13 +164,21 @@ class HipProcessor:
         # aspect crop / zoom / quarter turns: index arithmetic of raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72)
         image = geometry.crop_to_frame(image, frame_width, frame_height, zoom, rotate_times, flip)
         h, w = image.shape[:2]
-        if resolution is not None and tuple(resolution) != (h, w):
-            raise NotImplementedError("pre-path resolution scaling is outside the accelerated path (SURVEY.md section 8f)")
-        if max_scale is not None and max(h, w) / max(frame_width, frame_height) > max_scale:
+        if max_scale is not None and max(h, w) / max(frame_width, frame_height) > max_scale and resolution is None:
             raise NotImplementedError(
-                f"frame is finer than max_scale={max_scale} px/mm; the reference down-scales first "
-                "(cpu_processor.py:128-134), which is outside the accelerated path"
+                f"frame is finer than max_scale={max_scale} px/mm; the reference down-scales before and LANCZOS4-up-scales "
+                "after the path (cpu_processor.py:128-134, 411-412), which is outside the accelerated path"
             )
+        resize_to = None
+        if resolution is not None:  # preview: utils.resolution_scaling (utils.py:226-244), applied on the device in phase 2
+            if max_scale is not None and max(resolution) / max(frame_width, frame_height) > max_scale:
+                raise NotImplementedError("max_scale clamping of the preview resolution is outside the accelerated path")
+            factor = min(resolution[0] / h, resolution[1] / w)
+            if factor > 1:
+                raise NotImplementedError("up-scaling (cv.INTER_LANCZOS4, utils.py:237-242) is outside the accelerated path")
+            if factor < 1:
+                resize_to = (round(h * factor), round(w * factor))  # cv.resize(dsize=(round(w f), round(h f)), INTER_AREA)
+                h, w = resize_to
         canvas_res = None
         if canvas_mode != "No":  # gpu_processor.py:767-771
             res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
@@ -185,6 +193,7 @@ class HipProcessor:
             "pipeline_resolution": (w, h),
             # upstream filters on the host here (gpu_processor.py:750-751); this backend filters on the device in phase 2
             "chroma_nr": int(chroma_nr),
+            "resize_to": resize_to,  # (rows, cols) of the INTER_AREA down-scale still to be applied, or None
         }
 
     @staticmethod
@@ -248,6 +257,8 @@ class HipProcessor:
         image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         if cpu_payload.get("chroma_nr"):  # pre-path chroma NR (effects.py:547-561): XYZ planes out, CHW into the pipeline
             image = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"])
+        if cpu_payload.get("resize_to"):  # preview down-scale (cv.INTER_AREA), after the NR like cpu_processor.py:119-134
+            image = self.ctx.resize_area(image.contiguous(), *cpu_payload["resize_to"])
         _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,
                                            **settings)
         # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic

@@ -503,3 +503,15 @@ def test_chroma_nr_row_shards_bitwise(ctx):
         lo, hi = max(a - size, 0), min(b + size, H)
         ctx.stage_chroma_nr_v(tmp[:, lo:hi].contiguous(), out, size, src_gy0=lo, y0=a, y1=b, H_global=H)
     np.testing.assert_array_equal(out.cpu().numpy(), whole.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------- pre-path area down-scale
+@pytest.mark.parametrize("layout", ["hwc3", "chw"])
+@pytest.mark.parametrize("shape,out", [((120, 180), (40, 60)), ((133, 217), (37, 61)), ((64, 64), (64, 64)), ((50, 70), (1, 1)), ((90, 30), (7, 29))])
+def test_resize_area_against_oracle(ctx, layout, shape, out):
+    H, W = shape
+    img = synthetic_frame(H, W, seed=95)
+    ref = np.stack([st.resize_area(img[..., c], out[0], out[1]) for c in range(3)], axis=-1)
+    t = dev(img) if layout == "hwc3" else to_planes(img)
+    got = from_planes(ctx.resize_area(t, out[0], out[1]))
+    assert_close(got, ref, 2e-6, 1e-6, f"area resize {shape}->{out}")

@@ -129,3 +129,14 @@ def test_chroma_nr_through_the_processor(proc):
     ref = st.to_uint8(st.render(st.chroma_nr_filter(img, 3), p))
     assert _u8_close(out, ref)
     assert np.abs(out.astype(int) - proc.process(img, neg, 6, 0.4, **kw).astype(int)).max() > 3
+
+
+def test_preview_resolution_downscale(proc):
+    neg, prt, _ = stocks()
+    img = _xyz(200, 300, seed=48)
+    kw = dict(print_film=prt, exp_kelvin=6000, color_masking=1.0, seed=SEED, halation_green_factor=0.3)
+    out = proc.process(img, neg, 6, 0.4, resolution=(80, 150), **kw)
+    assert out.shape == (80, 120, 3)
+    small = np.stack([st.resize_area(img[..., c], 80, 120) for c in range(3)], axis=-1)
+    p = oracle_inputs(neg, prt, 120 / 36, matrix=False)
+    assert _u8_close(out, st.to_uint8(st.render(small, p)))

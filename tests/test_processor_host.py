@@ -128,6 +128,8 @@ def test_out_of_scope_requests_raise(proc):
     with pytest.raises(NotImplementedError):
         proc.extract_image_data_cpu(img, frame_width=0.1, frame_height=0.07)  # finer than max_scale
     with pytest.raises(NotImplementedError):
+        proc.extract_image_data_cpu(img, resolution=(80, 120))  # up-scaling needs LANCZOS4
+    with pytest.raises(NotImplementedError):
         proc.process(img, neg, 6, 0.4, dst_texture=object())
 
 
@@ -139,6 +141,14 @@ def test_extract_crops_zooms_turns_and_reports_canvas(proc):
     assert p["image_array"].shape[0] > p["image_array"].shape[1]  # quarter turn of a landscape crop
     w, h = p["pipeline_resolution"]
     assert p["canvas_resolution"] == (w + int(max(h, w) * 0.1), h + int(max(h, w) * 0.1)) or p["canvas_resolution"][0] > w
+
+
+def test_preview_resolution_becomes_an_area_downscale(proc):
+    img = np.zeros((400, 600, 3), np.float32)
+    p = proc.extract_image_data_cpu(img, resolution=(100, 200))  # widget 100 x 200: limited by the height factor 0.25
+    assert p["resize_to"] == (100, 150) and p["pipeline_resolution"] == (150, 100) and p["output_resolution"] == (150, 100)
+    assert p["image_array"].shape == (400, 600, 4)  # the frame itself is resized on the device in phase 2
+    assert proc.extract_image_data_cpu(img, resolution=(400, 600))["resize_to"] is None
 
 
 def test_extract_image_data_cpu_payload(proc):
