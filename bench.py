@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--config", default="cfg4_100mp", choices=["cfg4_100mp", "cfg3_45mp", "cfg2_24mp", "cfg5_batch"])
     ap.add_argument("--frames", type=int, default=64, help="cfg5_batch: frames per step, dealt round-robin to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the measured configuration); gloo + --same-device validates the N > 1 code path on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="validation only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -62,10 +65,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     batch = args.config == "cfg5_batch"  # BASELINE config 5: 64 x 24 MP frames, full pipeline, frame-per-GPU, no collectives
     W, H = CONFIGS["cfg2_24mp" if batch else args.config]
@@ -122,7 +130,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=frame.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=frame.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
