@@ -248,8 +248,10 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
         bool sym = allow_sym && channel_symmetric(c);
         if (sym && common_box)  // shared geometry (grain): pair taps only if every channel allows it
             sym = channel_symmetric(0) && channel_symmetric(1) && channel_symmetric(2);
-        // virtual stencil: the cropped box, widened by one zero column per side when sym needs an even r
-        const int pad = (sym && ((bw - 1) / 2) % 2 == 1) ? 1 : 0;
+        // virtual stencil: the cropped box widened by zero columns on both sides until r = 2 (mod 4).  Even r keeps the
+        // mirrored block 16-byte aligned; r + 1 = 3 (mod 4) puts the one padded column of the left half next to the
+        // centre and the slack at the OUTER edge, where whole chunks are empty on most rows and get skipped.
+        const int pad = sym ? ((2 - ((bw - 1) / 2) % 4) + 4) % 4 : 0;
         const int vkw = bw + 2 * pad, vkh = bh;
         auto tap = [&](int i, int j) -> float {
             j -= pad;

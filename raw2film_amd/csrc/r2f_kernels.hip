@@ -1,11 +1,14 @@
 // r2f_kernels.hip -- gfx950 kernels of the film-emulation render path and their launchers.
 //
 // Kernel inventory (pass graph mirrors gpu_processor.py:1763-1862, fused where it is free):
-//   front_kernel    S0 3x3 + S1 2-D LUT [+ S3 log + S4 curve [+ S8 3-D LUT + S9 u8]]   HBM-bound
-//   stencil_kernel  S2 halation (+S3+S4 epilogue) / S5 MTF: LDS-tiled direct stencil    fp32-VALU-bound
-//   tail_kernel     S6 hash noise -> LDS, grain stencil, grain LUT, clip, S8, S9        VALU/LDS
-//   lut3d_kernel    S8 + S9 from density planes (grain off)                              HBM-bound
-//   noise_kernel    S6a test entry (hash + Gaussian field)
+//   front_kernel      S0 3x3 + S1 2-D LUT [+ S3 log + S4 curve [+ S8 3-D LUT + S9 u8]]        HBM-bound
+//   stencil_kernel    S2 halation (+S3+S4 epilogue) / S5 MTF: LDS-tiled direct stencil         fp32-VALU-bound
+//   tail_kernel       S6 hash noise -> LDS, grain stencil, grain LUT, clip [, S8, S9]          VALU/LDS
+//   lut3d_kernel      [S7 burn subtract +] S8 + S9 from density planes                         HBM-bound
+//   burn_sums/_map    S7: INTER_AREA cell sums of the green density; clip + Gaussian on the map
+//   chroma_h/_v       pre-path chroma NR: xyY + separable Gaussian on the chromaticity planes  HBM-bound
+//   resize_area       pre-path INTER_AREA down-scale to the preview resolution
+//   noise_kernel      S6a test entry (hash + Gaussian field)
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
