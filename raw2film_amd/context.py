@@ -133,10 +133,19 @@ class HipContext:
 
     # ------------------------------------------------------------------ whole frame
     @staticmethod
-    def layout_of(t) -> tuple[int, int, int]:
-        """(layout, H, W) of an image tensor: (H, W, 3) / (H, W, 4) interleaved or (3, H, W) planar."""
+    def layout_of(t, layout=None) -> tuple[int, int, int]:
+        """(layout, H, W) of an image tensor: (H, W, 3) / (H, W, 4) interleaved or (3, H, W) planar.
+
+        A (3, H, 3) or (3, H, 4) tensor is ambiguous; interleaved wins (the reference only knows (H, W, C) frames),
+        so pass ``layout="chw"`` for a planar frame that is 3 or 4 pixels wide."""
         if t.dim() != 3:
             raise ValueError("image must be 3-D")
+        if layout is not None:
+            want = {"hwc3": (_lib.LAYOUT_HWC3, 2, 3), "hwc4": (_lib.LAYOUT_HWC4, 2, 4), "chw": (_lib.LAYOUT_CHW, 0, 3)}.get(layout)
+            if want is None or t.shape[want[1]] != want[2]:
+                raise ValueError(f"layout {layout!r} does not fit image shape {tuple(t.shape)}")
+            hw = (t.shape[1], t.shape[2]) if layout == "chw" else (t.shape[0], t.shape[1])
+            return want[0], int(hw[0]), int(hw[1])
         if t.shape[2] == 3:
             return _lib.LAYOUT_HWC3, int(t.shape[0]), int(t.shape[1])
         if t.shape[2] == 4:
@@ -162,11 +171,11 @@ class HipContext:
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def render(self, image, params, out_f32=None, out_u8=None, want_f32=True, want_u8=False):
+    def render(self, image, params, out_f32=None, out_u8=None, want_f32=True, want_u8=False, layout=None):
         """Full pipeline on one frame: S0..S8 (+S9).  Returns (out_f32, out_u8) device tensors (H, W, 3)."""
         torch = self._torch
         self._check_image(image)
-        layout, H, W = self.layout_of(image)
+        layout, H, W = self.layout_of(image, layout)
         if out_f32 is None and want_f32:
             out_f32 = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
         if out_u8 is None and want_u8:
@@ -184,9 +193,9 @@ class HipContext:
 
     # ------------------------------------------------------------------ stages (row-shard aware)
     def stage_front(self, image, params, upto, *, in_gy0=0, dst=None, dst_gy0=0, out_f32=None, out_u8=None,
-                    out_gy0=0, y0=None, y1=None, H_global=None):
+                    out_gy0=0, y0=None, y1=None, H_global=None, layout=None):
         self._check_image(image)
-        layout, rows, W = self.layout_of(image)
+        layout, rows, W = self.layout_of(image, layout)
         y0 = in_gy0 if y0 is None else y0
         y1 = in_gy0 + rows if y1 is None else y1
         H_global = in_gy0 + rows if H_global is None else H_global
@@ -255,10 +264,10 @@ class HipContext:
                                                  H_global, self._stream()))
         return out
 
-    def stage_chroma_nr_h(self, image, dst, size, *, in_gy0=0, dst_gy0=0, y0=None, y1=None):
+    def stage_chroma_nr_h(self, image, dst, size, *, in_gy0=0, dst_gy0=0, y0=None, y1=None, layout=None):
         """Pre-path chroma NR pass 1: image rows -> planes (x blurred horizontally, y blurred horizontally, Y)."""
         self._check_image(image)
-        layout, rows, W = self.layout_of(image)
+        layout, rows, W = self.layout_of(image, layout)
         y0 = in_gy0 if y0 is None else y0
         y1 = in_gy0 + rows if y1 is None else y1
         pd = self.planes(dst, dst_gy0)
@@ -271,21 +280,21 @@ class HipContext:
         self._check(self._lib.r2f_stage_chroma_nr_v(self._h, C.byref(ps), C.byref(pd), int(size), y0, y1, int(src.shape[2]),
                                                     H_global, self._stream()))
 
-    def chroma_nr(self, image, size):
+    def chroma_nr(self, image, size, layout=None):
         """effects.chroma_nr_filter on a whole frame: (H, W, 3|4) or (3, H, W) in -> (3, H, W) XYZ planes out."""
         torch = self._torch
-        _, H, W = self.layout_of(image)
+        _, H, W = self.layout_of(image, layout)
         tmp = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
         out = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
-        self.stage_chroma_nr_h(image, tmp, size)
+        self.stage_chroma_nr_h(image, tmp, size, layout=layout)
         self.stage_chroma_nr_v(tmp, out, size, y0=0, y1=H, H_global=H)
         return out
 
-    def resize_area(self, image, out_h, out_w):
+    def resize_area(self, image, out_h, out_w, layout=None):
         """Pre-path INTER_AREA down-scale of a whole frame -> (3, out_h, out_w) planes."""
         torch = self._torch
         self._check_image(image)
-        layout, H, W = self.layout_of(image)
+        layout, H, W = self.layout_of(image, layout)
         out = torch.empty((3, int(out_h), int(out_w)), dtype=torch.float32, device=self.device)
         pd = self.planes(out, 0)
         self._check(self._lib.r2f_resize_area(self._h, image.data_ptr(), layout, H, W, C.byref(pd), int(out_h), int(out_w),

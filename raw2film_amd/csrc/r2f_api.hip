@@ -644,8 +644,8 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
             a.burn.w_lo = w_lo;
             a.burn.h_up = h_lo * p->burn_cell;
             a.burn.w_up = w_lo * p->burn_cell;
-            a.burn.ry = a.burn.h_up > 1 ? (float)((double)(h_lo - 1) / (double)(a.burn.h_up - 1)) : 0.f;
-            a.burn.rx = a.burn.w_up > 1 ? (float)((double)(w_lo - 1) / (double)(a.burn.w_up - 1)) : 0.f;
+            a.burn.zy = a.burn.h_up > 1 ? (double)(h_lo - 1) / (double)(a.burn.h_up - 1) : 0.0;
+            a.burn.zx = a.burn.w_up > 1 ? (double)(w_lo - 1) / (double)(a.burn.w_up - 1) : 0.0;
             a.burn.strength = p->burn_strength;
         }
     }

@@ -216,13 +216,17 @@ struct Lut3dArgs {
     BurnUp burn;
 };
 
-// S7: the highlight map at pixel (gy, x): ndimage.zoom(map, cell, order=1) = linear interpolation with the
-// first / last samples pinned to the first / last zoomed pixels, then edge padding (effects.py:381-388).
+// S7: the highlight map at pixel (gy, x): ndimage.zoom(map, cell, order=1) = linear interpolation at the
+// coordinate o * (in - 1) / (out - 1), evaluated in double like SciPy does, then edge padding to the frame
+// (effects.py:381-388).  SciPy's default mode="constant" returns 0 for a coordinate beyond the last sample,
+// and o * ((in-1)/(out-1)) can exceed in-1 by one ulp at o = out-1 (e.g. 223 * (31/223) > 31): the reference's
+// last zoomed column / row is then 0, and so is the edge padding copied from it.  Reproduced here on purpose.
 __device__ __forceinline__ float burn_sample(const BurnUp& bu, int gy, int x) {
-    const float fy = (float)min(gy, bu.h_up - 1) * bu.ry, fx = (float)min(x, bu.w_up - 1) * bu.rx;
-    const int y0 = min((int)fy, bu.h_lo - 1), x0 = min((int)fx, bu.w_lo - 1);
+    const double cy = (double)min(gy, bu.h_up - 1) * bu.zy, cx = (double)min(x, bu.w_up - 1) * bu.zx;
+    if (cy > (double)(bu.h_lo - 1) || cx > (double)(bu.w_lo - 1)) return 0.f;
+    const int y0 = (int)cy, x0 = (int)cx;
     const int y1 = min(y0 + 1, bu.h_lo - 1), x1 = min(x0 + 1, bu.w_lo - 1);
-    const float ty = fy - (float)y0, tx = fx - (float)x0;
+    const float ty = (float)(cy - (double)y0), tx = (float)(cx - (double)x0);
     const float a = bu.map[y0 * bu.w_lo + x0], b = bu.map[y0 * bu.w_lo + x1];
     const float c = bu.map[y1 * bu.w_lo + x0], d = bu.map[y1 * bu.w_lo + x1];
     const float top = a + tx * (b - a), bot = c + tx * (d - c);

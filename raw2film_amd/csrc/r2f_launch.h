@@ -44,7 +44,7 @@ struct BurnUp {
     const float* map;  // h_lo x w_lo, nullptr = burn off
     int h_lo, w_lo;
     int h_up, w_up;    // h_lo * cell, w_lo * cell: extent of the zoomed map; beyond it the edge is repeated
-    float ry, rx;      // (h_lo - 1) / (h_up - 1), (w_lo - 1) / (w_up - 1)
+    double zy, zx;     // (h_lo - 1) / (h_up - 1), (w_lo - 1) / (w_up - 1) in double, like scipy's zoom
     float strength;
 };
 

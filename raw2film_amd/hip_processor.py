@@ -255,12 +255,13 @@ class HipProcessor:
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
         image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
+        layout = None  # the payload is (H, W, C) like the reference's; the device pre-path hands on (3, H, W) planes
         if cpu_payload.get("chroma_nr"):  # pre-path chroma NR (effects.py:547-561): XYZ planes out, CHW into the pipeline
-            image = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"])
+            image, layout = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"]), "chw"
         if cpu_payload.get("resize_to"):  # preview down-scale (cv.INTER_AREA), after the NR like cpu_processor.py:119-134
-            image = self.ctx.resize_area(image.contiguous(), *cpu_payload["resize_to"])
+            image, layout = self.ctx.resize_area(image.contiguous(), *cpu_payload["resize_to"], layout=layout), "chw"
         _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,
-                                           **settings)
+                                           layout=layout, **settings)
         # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic
         out_u8 = geometry.add_canvas(out_u8, settings.get("canvas_mode", "No"), settings.get("canvas_scale", 1.0),
                                      settings.get("canvas_ratio", 1.0))
@@ -329,7 +330,8 @@ class HipProcessor:
                                     grain_mono=grain == 1, seed=seed, lut3d_mode=lut3d_mode,
                                     log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE, **burn_kw)
 
-    def _execute_pipeline(self, image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True, **settings):
-        _, H, W = self.ctx.layout_of(image)
+    def _execute_pipeline(self, image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True, layout=None,
+                          **settings):
+        _, H, W = self.ctx.layout_of(image, layout)
         params = self.prepare(negative_film, grain_size, grain_sigma, (W, H), **settings)
-        return self.ctx.render(image, params, want_f32=want_f32, want_u8=want_u8)
+        return self.ctx.render(image, params, want_f32=want_f32, want_u8=want_u8, layout=layout)

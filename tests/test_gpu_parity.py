@@ -447,6 +447,23 @@ def test_burn_area_sums_and_map(ctx, shape, burn_scale):
     np.testing.assert_allclose(bmap.cpu().numpy(), st.burn_map(dens[..., 1], 1.2, burn_scale), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(139, 229), (140, 228), (133, 224), (61, 97)])
+def test_burn_upsample_edges_like_scipy_zoom(ctx, shape):
+    """Frames that are not a multiple of the shrink factor get an edge-padded map, and SciPy's zoom can turn its last
+    column / row into 0 (coordinate one ulp past the last sample) -- the device path must do exactly the same."""
+    neg, prt, _ = stocks()
+    H, W = shape
+    p = oracle_inputs(neg, prt, 166.67, halation=False, mtf=False, grain=0)
+    p.highlight_burn, p.burn_scale, p.d_ref = 0.5, 20.0, float(neg.d_ref[1])
+    img = synthetic_frame(H, W, seed=77)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    params.flags |= 32
+    params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 20.0)[0], 0.5, float(neg.d_ref[1])
+    out, _ = ctx.render(dev(img), params)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, f"burn edges {shape}")
+
+
 @pytest.mark.parametrize("grain", [2, 0])
 def test_full_pipeline_with_highlight_burn(ctx, grain):
     neg, prt, _ = stocks()
