@@ -126,8 +126,8 @@ int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, i
 // Row steps are grouped into phases of at most `mp` steps; LDS offsets are relative to the phase.
 struct StreamHost {
     std::vector<float> w;
-    std::vector<int> offs, offs_r, rowcnt, phases;
-    int n_phases = 0, n_rowsteps = 0, max_lds_rows = 0;
+    std::vector<int> rowinfo, phases;  // rowinfo: 4 ints per non-empty row step (DevStencil::rowinfo)
+    int n_phases = 0, n_rowsteps = 0, n_entries = 0, max_lds_rows = 0;
 };
 
 // `tap(i, j)` = weight of the (virtual) cropped stencil, 0 outside; kh x kw virtual taps.
@@ -150,8 +150,8 @@ void build_stream(Tap tap, int kh, int kw, bool sym, int Q, int RS, int TH, int 
         const int lds_rows = TH - Q + (m1 - m0);
         out.phases.push_back(m0);
         out.phases.push_back(lds_rows);
-        out.phases.push_back((int)out.rowcnt.size());
-        out.phases.push_back((int)out.offs.size());
+        out.phases.push_back((int)out.rowinfo.size() / 4);
+        out.phases.push_back(out.n_entries);
         out.max_lds_rows = std::max(out.max_lds_rows, lds_rows);
         ++out.n_phases;
         for (int m = m0; m < m1; ++m) {
@@ -170,27 +170,27 @@ void build_stream(Tap tap, int kh, int kw, bool sym, int Q, int RS, int TH, int 
                 }
             }
             if (c_hi < 0) continue;  // no work on this row step
-            out.rowcnt.push_back(c_hi - c_lo + 1);
+            out.rowinfo.push_back(c_hi - c_lo + 1);
+            out.rowinfo.push_back((m - m0) * RS + 4 * c_lo);
+            out.rowinfo.push_back(sym ? (m - m0) * RS + 2 * r - 4 * c_lo - 4 : 0);
+            out.rowinfo.push_back(0);
             for (int c = c_lo; c <= c_hi; ++c) {
-                out.offs.push_back((m - m0) * RS + 4 * c);
-                out.offs_r.push_back((m - m0) * RS + 2 * r - 4 * c - 4);
+                ++out.n_entries;
                 for (int t = 0; t < 4; ++t)
                     for (int q = 0; q < Q; ++q) out.w.push_back(wt(m - q, 4 * c + t));
             }
         }
     }
-    out.n_rowsteps = (int)out.rowcnt.size();
+    out.n_rowsteps = (int)out.rowinfo.size() / 4;
     // terminator phase record: {., ., n_rowsteps, n_entries}
     out.phases.push_back(0);
     out.phases.push_back(0);
     out.phases.push_back(out.n_rowsteps);
-    out.phases.push_back((int)out.offs.size());
-    for (int d = 0; d < 2; ++d) {  // two dummy entries: targets of the last prefetches
-        out.offs.push_back(0);
-        out.offs_r.push_back(0);
+    out.phases.push_back(out.n_entries);
+    for (int d = 0; d < 2; ++d) {  // two dummy entries and row-step records: targets of the last prefetches
+        for (int i = 0; i < 4; ++i) out.rowinfo.push_back(0);
         for (int i = 0; i < 4 * Q; ++i) out.w.push_back(0.f);
     }
-    if (out.rowcnt.empty()) out.rowcnt.push_back(0);
 }
 
 // Build (or reuse) the device form of stencil `which` for a tile TW x TH, Q rows per lane, and an LDS
@@ -283,20 +283,15 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
         d.max_lds_rows = sh.max_lds_rows;
         int rc = upload(ctx, s.wbuf[c], sh.w.data(), sh.w.size() * sizeof(float));
         if (rc) return rc;
-        // offsets, mirrored offsets, row counts and phase records share one allocation
-        std::vector<int> meta(sh.offs);
-        const size_t n_off = meta.size();
-        meta.insert(meta.end(), sh.offs_r.begin(), sh.offs_r.end());
-        meta.insert(meta.end(), sh.rowcnt.begin(), sh.rowcnt.end());
-        const size_t n_rc = sh.rowcnt.size();
+        // row-step records (16-byte aligned: read with s_load_dwordx4) and phase records share one allocation
+        std::vector<int> meta(sh.rowinfo);
+        const size_t n_ri = meta.size();
         meta.insert(meta.end(), sh.phases.begin(), sh.phases.end());
         rc = upload(ctx, s.mbuf[c], meta.data(), meta.size() * sizeof(int));
         if (rc) return rc;
         d.wstream = static_cast<const float*>(s.wbuf[c].p);
-        d.offs = static_cast<const int*>(s.mbuf[c].p);
-        d.offs_r = d.offs + n_off;
-        d.rowcnt = d.offs_r + n_off;
-        d.phases = d.rowcnt + n_rc;
+        d.rowinfo = static_cast<const int*>(s.mbuf[c].p);
+        d.phases = d.rowinfo + n_ri;
     }
     s.built_q = Q;
     s.built_tw = TW;

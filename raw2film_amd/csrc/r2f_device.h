@@ -41,14 +41,15 @@ struct DevLut3D {  // S8: n^3 float4 texels, (r, g, b) at (r*n + g)*n + b
 // one input-row step m x one 4-tap chunk c; the entries of a row step are consecutive.  Row
 // steps are grouped into PHASES: a phase keeps only the input rows its row steps touch in LDS,
 // so the LDS footprint (and with it the number of resident workgroups) is a tuning knob that
-// does not depend on the stencil height.  The list ends with two dummy entries so the loop can
-// always prefetch ahead.
+// does not depend on the stencil height.  The list ends with two dummy entries (and the row-step
+// table with two dummy records) so the loop can always prefetch ahead.
 struct DevStencil {
     const float* wstream;  // per entry: 4*Q floats  w[t][q] = K[m-q][4c+t]  (0 outside the taps)
-    const int* offs;       // per entry: LDS float offset (m - m0(phase))*RS + 4c
-    const int* rowcnt;     // per non-empty row step: number of entries (>= 1)
-    const int* offs_r;     // sym only, per entry: LDS float offset of the mirrored 8-float block (m - m0)*RS + 2r - 4c - 4
-    const int* phases;     // per phase 4 ints: {m0, lds_rows, first row step (index into rowcnt), first entry}
+    const int* rowinfo;    // per non-empty row step 4 ints: {number of entries (>= 1),
+                           //   LDS float offset of its first entry (m - m0(phase))*RS + 4*c_lo,
+                           //   sym only: LDS offset of that entry's mirrored 8-float block (m - m0)*RS + 2r - 4*c_lo - 4, 0};
+                           // the following entries of the row step sit 4 floats further right (mirrored: further left)
+    const int* phases;     // per phase 4 ints: {m0, lds_rows, first row step (index into rowinfo), first entry}
                            // + one terminator {., ., n_rowsteps, n_entries}
     int n_phases;
     int n_rowsteps;        // total non-empty row steps
@@ -339,20 +340,26 @@ __device__ __forceinline__ void wait_operands(const typename WVec<4 * Q>::type& 
 // (Tried and dropped: touching the scalar-cache line of entry e+4 with a one-dword s_load.  Any
 // use of a scalar load forces lgkmcnt(0), which also waits for the touch, so it cannot fly ahead.)
 // One pipeline step: wait for the current entry's operands, request the next entry's
-// (into the other register set), then issue the current entry's FMAs.
+// (into the other register set), then issue the current entry's FMAs.  `noff` = LDS offset of the
+// next entry: plain scalar arithmetic (+4 floats inside a row step, the next row step's first offset
+// at its end) -- a per-entry offset TABLE made the compiler fetch two entries' offsets with one
+// s_load_dwordx2 right before their use, i.e. one exposed scalar-load latency every other entry.
+// The first step of row step r also requests the record of row step r+2 (`info_ptr` -> `info_nn`).
+typedef int __attribute__((ext_vector_type(4))) int4v;
+
 template <int Q, bool FIRST>
-__device__ __forceinline__ void entry_step(const float* lds, const int R2F_CONSTANT* offs,
-                                           const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e, int& off1,
+__device__ __forceinline__ void entry_step(const float* lds, const int noff,
+                                           const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
                                            const typename WVec<4 * Q>::type& cw, const float4v& ca, const float4v& cb, typename WVec<4 * Q>::type& nw, float4v& na, float4v& nb,
-                                           float2v (&part)[Q / 2][4]) {
+                                           float2v (&part)[Q / 2][4], const int4v R2F_CONSTANT* info_ptr = nullptr,
+                                           int4v* info_nn = nullptr) {
     wait_operands<Q>(cw, ca, cb);
-    const int off2 = offs[e + 2];
+    if (FIRST) *info_nn = *info_ptr;
     nw = wstream[(e + 1) * wmul];
-    na = *reinterpret_cast<const float4v*>(lds + off1);
-    nb = *reinterpret_cast<const float4v*>(lds + off1 + 4);
+    na = *reinterpret_cast<const float4v*>(lds + noff);
+    nb = *reinterpret_cast<const float4v*>(lds + noff + 4);
     __builtin_amdgcn_sched_barrier(0);
     entry_fma<Q, FIRST>(cw, ca, cb, part);
-    off1 = off2;
     ++e;
 }
 
@@ -371,9 +378,20 @@ __device__ __forceinline__ void entry_fma_sym(const typename WVec<4 * Q>::type& 
     const float rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        // L index p+t and R index 4+p-t have the same parity, so the sums of two neighbouring pixels come out of one
+        // v_pk_add_f32 on two aligned register pairs whenever p+t is even: (p=0,1), (p=2,3) for even t; (p=1,2) for odd t
+        // (p=0 and p=3 are then single adds).  10 VALU instructions instead of 16, same 16 sums, same rounding.
         float sum[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) sum[p] = lw[p + t] + rw[4 + p - t];
+        if ((t & 1) == 0) {
+            const float2v s01 = float2v{lw[t], lw[t + 1]} + float2v{rw[4 - t], rw[5 - t]};
+            const float2v s23 = float2v{lw[t + 2], lw[t + 3]} + float2v{rw[6 - t], rw[7 - t]};
+            sum[0] = s01.x, sum[1] = s01.y, sum[2] = s23.x, sum[3] = s23.y;
+        } else {
+            const float2v s12 = float2v{lw[t + 1], lw[t + 2]} + float2v{rw[5 - t], rw[6 - t]};
+            sum[0] = lw[t] + rw[4 - t];
+            sum[1] = s12.x, sum[2] = s12.y;
+            sum[3] = lw[t + 3] + rw[7 - t];
+        }
 #pragma unroll
         for (int j = 0; j < Q / 2; ++j) {
             const float2v wv = {w[t * Q + 2 * j], w[t * Q + 2 * j + 1]};
@@ -396,22 +414,48 @@ struct SymOperands {
 };
 
 template <int Q, bool FIRST>
-__device__ __forceinline__ void entry_step_sym(const float* lds, const int R2F_CONSTANT* offs, const int R2F_CONSTANT* offs_r,
+__device__ __forceinline__ void entry_step_sym(const float* lds, const int noff, const int noffr,
                                                const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
-                                               int& off1, int& off1r, const SymOperands<Q>& cur, SymOperands<Q>& nxt,
-                                               float2v (&part)[Q / 2][4]) {
+                                               const SymOperands<Q>& cur, SymOperands<Q>& nxt, float2v (&part)[Q / 2][4],
+                                               const int4v R2F_CONSTANT* info_ptr = nullptr, int4v* info_nn = nullptr) {
     asm volatile("" ::"s"(cur.w[0]), "s"(cur.w[4 * Q - 1]), "v"(cur.la.x), "v"(cur.lb.w), "v"(cur.ra.x), "v"(cur.rb.w));
     __builtin_amdgcn_sched_barrier(0);
-    const int off2 = offs[e + 2], off2r = offs_r[e + 2];
-    nxt.w = wstream[(e + 1) * wmul];
-    nxt.la = *reinterpret_cast<const float4v*>(lds + off1);
-    nxt.lb = *reinterpret_cast<const float4v*>(lds + off1 + 4);
-    nxt.ra = *reinterpret_cast<const float4v*>(lds + off1r);
-    nxt.rb = *reinterpret_cast<const float4v*>(lds + off1r + 4);
+    if (FIRST) *info_nn = *info_ptr;  // see entry_step
+#ifndef R2F_EXP
+#define R2F_EXP 0  // development switch (tools/ablate_stencil.py): bit 0 no LDS reads, 1 no weight loads, 2 no FMAs
+#endif
+    if (R2F_EXP & 2) {
+        asm volatile("" : "=s"(nxt.w));  // "defined" without an instruction: garbage weights
+    } else {
+        nxt.w = wstream[(e + 1) * wmul];
+    }
+    float4v d0, d1, d2, d3;
+    if (R2F_EXP & 8) {  // LDS traffic without consumers: the reads are issued and only waited for after the FMAs
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                     : "v"((unsigned)(size_t)(lds + noff) ), "v"((unsigned)(size_t)(lds + noffr)));
+        asm volatile("" : "=v"(nxt.la), "=v"(nxt.lb), "=v"(nxt.ra), "=v"(nxt.rb));
+    } else if (R2F_EXP & 1) {
+        asm volatile("" : "=v"(nxt.la), "=v"(nxt.lb), "=v"(nxt.ra), "=v"(nxt.rb));
+    } else {
+        nxt.la = *reinterpret_cast<const float4v*>(lds + noff);
+        nxt.lb = *reinterpret_cast<const float4v*>(lds + noff + 4);
+        nxt.ra = *reinterpret_cast<const float4v*>(lds + noffr);
+        nxt.rb = *reinterpret_cast<const float4v*>(lds + noffr + 4);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    entry_fma_sym<Q, FIRST>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part);
-    off1 = off2;
-    off1r = off2r;
+    if (R2F_EXP & 4) {
+        if (FIRST)
+            for (int j = 0; j < Q / 2; ++j)
+                for (int p = 0; p < 4; ++p) part[j][p] = float2v{cur.w[j], cur.la.x + cur.ra.y};
+        else
+            part[0][0] += float2v{cur.w[0] + cur.w[4 * Q - 1], cur.la.x + cur.lb.w + cur.ra.x + cur.rb.w};
+    } else
+        entry_fma_sym<Q, FIRST>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part);
+    if (R2F_EXP & 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
+    }
     ++e;
 }
 
@@ -419,40 +463,50 @@ template <int Q>
 __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const DevStencil& st, int row_begin, int row_end,
                                                        int e0, float2v (&acc)[Q / 2][4]) {
     typedef typename WVec<4 * Q>::type wvec;
-    const int R2F_CONSTANT* offs = (const int R2F_CONSTANT*)st.offs;
-    const int R2F_CONSTANT* offs_r = (const int R2F_CONSTANT*)st.offs_r;
-    const int R2F_CONSTANT* rowcnt = (const int R2F_CONSTANT*)st.rowcnt;
+    const int4v R2F_CONSTANT* info = (const int4v R2F_CONSTANT*)st.rowinfo;
     const wvec R2F_CONSTANT* wstream = (const wvec R2F_CONSTANT*)st.wstream;
     const int wmul = st.wmul;
     float2v part[Q / 2][4];
     int e = e0;
-    int off1 = offs[e0 + 1], off1r = offs_r[e0 + 1];
+    int4v ri = info[row_begin], ri_n = info[row_begin + 1], ri_nn;  // this row step, the next, the one after
     SymOperands<Q> A, B;
     A.w = wstream[e0 * wmul];
-    {
-        const int o = offs[e0], orr = offs_r[e0];
-        A.la = *reinterpret_cast<const float4v*>(lds + o);
-        A.lb = *reinterpret_cast<const float4v*>(lds + o + 4);
-        A.ra = *reinterpret_cast<const float4v*>(lds + orr);
-        A.rb = *reinterpret_cast<const float4v*>(lds + orr + 4);
-    }
+    A.la = *reinterpret_cast<const float4v*>(lds + ri.y);
+    A.lb = *reinterpret_cast<const float4v*>(lds + ri.y + 4);
+    A.ra = *reinterpret_cast<const float4v*>(lds + ri.z);
+    A.rb = *reinterpret_cast<const float4v*>(lds + ri.z + 4);
     for (int r = row_begin; r < row_end; ++r) {
-        const int cnt = rowcnt[r];
-        entry_step_sym<Q, true>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, A, B, part);
+        const int cnt = ri.x;
+        int off = ri.y + 4, offr = ri.z - 4;  // LDS offsets of the entry after the current one, if it is in this row step
+#define R2F_NEXT_OFFS(i) const bool last = (i) + 1 >= cnt; const int no = last ? ri_n.y : off, nor = last ? ri_n.z : offr; off += 4; offr -= 4;
+        {
+            R2F_NEXT_OFFS(0)
+            entry_step_sym<Q, true>(lds, no, nor, wstream, wmul, e, A, B, part, info + r + 2, &ri_nn);
+        }
         int i = 1;
         for (; i + 1 < cnt; i += 2) {
-            entry_step_sym<Q, false>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, B, A, part);
-            entry_step_sym<Q, false>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, A, B, part);
+            {
+                const int no = off, nor = offr;  // entry i+1 is in this row step
+                off += 4, offr -= 4;
+                entry_step_sym<Q, false>(lds, no, nor, wstream, wmul, e, B, A, part);
+            }
+            {
+                R2F_NEXT_OFFS(i + 1)
+                entry_step_sym<Q, false>(lds, no, nor, wstream, wmul, e, A, B, part);
+            }
         }
-        if (i < cnt) {
-            entry_step_sym<Q, false>(lds, offs, offs_r, wstream, wmul, e, off1, off1r, B, A, part);
+        if (i < cnt) {  // entry i = cnt - 1 is the last of the row step
+            entry_step_sym<Q, false>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part);
         } else {
             A = B;
         }
+#undef R2F_NEXT_OFFS
 #pragma unroll
         for (int j = 0; j < Q / 2; ++j)
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[j][p] += part[j][p];
+        ri = ri_n;
+        ri_n = ri_nn;
     }
 }
 
@@ -462,33 +516,42 @@ __device__ __forceinline__ void stencil_accumulate(const float* lds, const DevSt
                                                    int e0, float2v (&acc)[Q / 2][4]) {
     static_assert(Q == 2 || Q == 4, "Q must be 2 or 4");
     typedef typename WVec<4 * Q>::type wvec;
-    const int R2F_CONSTANT* offs = (const int R2F_CONSTANT*)st.offs;
-    const int R2F_CONSTANT* rowcnt = (const int R2F_CONSTANT*)st.rowcnt;
+    const int4v R2F_CONSTANT* info = (const int4v R2F_CONSTANT*)st.rowinfo;
     const wvec R2F_CONSTANT* wstream = (const wvec R2F_CONSTANT*)st.wstream;
     const int wmul = st.wmul;
     float2v part[Q / 2][4];
 
-    int e = e0;               // flat entry index
-    int off1 = offs[e0 + 1];  // LDS offset of entry e+1
+    int e = e0;  // flat entry index
+    int4v ri = info[row_begin], ri_n = info[row_begin + 1], ri_nn;
     // two operand sets: A holds the current entry at the top of every row step
     wvec wA = wstream[e0 * wmul], wB;
     float4v aA, bA, aB, bB;
-    {
-        const int off0 = offs[e0];
-        aA = *reinterpret_cast<const float4v*>(lds + off0);
-        bA = *reinterpret_cast<const float4v*>(lds + off0 + 4);
-    }
+    aA = *reinterpret_cast<const float4v*>(lds + ri.y);
+    bA = *reinterpret_cast<const float4v*>(lds + ri.y + 4);
     for (int r = row_begin; r < row_end; ++r) {
-        const int cnt = rowcnt[r];
+        const int cnt = ri.x;
+        int off = ri.y + 4;
         // first entry of the row step starts the row partial (multiply instead of fma)
-        entry_step<Q, true>(lds, offs, wstream, wmul, e, off1, wA, aA, bA, wB, aB, bB, part);
+        {
+            const int no = cnt <= 1 ? ri_n.y : off;
+            off += 4;
+            entry_step<Q, true>(lds, no, wstream, wmul, e, wA, aA, bA, wB, aB, bB, part, info + r + 2, &ri_nn);
+        }
         int i = 1;
         for (; i + 1 < cnt; i += 2) {
-            entry_step<Q, false>(lds, offs, wstream, wmul, e, off1, wB, aB, bB, wA, aA, bA, part);
-            entry_step<Q, false>(lds, offs, wstream, wmul, e, off1, wA, aA, bA, wB, aB, bB, part);
+            {
+                const int no = off;
+                off += 4;
+                entry_step<Q, false>(lds, no, wstream, wmul, e, wB, aB, bB, wA, aA, bA, part);
+            }
+            {
+                const int no = i + 2 >= cnt ? ri_n.y : off;
+                off += 4;
+                entry_step<Q, false>(lds, no, wstream, wmul, e, wA, aA, bA, wB, aB, bB, part);
+            }
         }
         if (i < cnt) {
-            entry_step<Q, false>(lds, offs, wstream, wmul, e, off1, wB, aB, bB, wA, aA, bA, part);
+            entry_step<Q, false>(lds, ri_n.y, wstream, wmul, e, wB, aB, bB, wA, aA, bA, part);
         } else {  // an odd number of steps was taken: the current entry sits in set B
             wA = wB;
             aA = aB;
@@ -498,6 +561,8 @@ __device__ __forceinline__ void stencil_accumulate(const float* lds, const DevSt
         for (int j = 0; j < Q / 2; ++j)
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[j][p] += part[j][p];
+        ri = ri_n;
+        ri_n = ri_nn;
     }
 }
 

@@ -1,0 +1,47 @@
+"""Time the halation / MTF stencils with a development build of the library (tools/ablate/lib_expN.so, built with
+-DR2F_EXP=N: bit 0 no LDS reads, bit 1 no weight loads, bit 2 no FMAs in the symmetric inner loop).  Results are wrong by
+construction; only the timings mean anything.   usage: python tools/ablate_stencil.py <path/to/lib.so>"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw2film_amd import _lib  # noqa: E402
+
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from raw2film_amd import HipProcessor, filmstock  # noqa: E402
+from raw2film_amd.hip_processor import REC709_TO_XYZ  # noqa: E402
+from raw2film_amd.synthetic import synthetic_frame_device  # noqa: E402
+
+H, W = 8192, 12288
+stocks = filmstock.builtin_stocks()
+neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+proc = HipProcessor(device=0)
+ctx = proc.ctx
+img = synthetic_frame_device(H, W)
+params = proc.prepare(neg, 6, 0.4, (W, H), seed=1, print_film=prt, matrix=REC709_TO_XYZ, halation_green_factor=0.3)
+E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+D = torch.empty_like(E)
+D2 = torch.empty_like(E)
+ctx.stage_front(img, params, 1, dst=E)
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return best
+
+
+th = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
+tm = timeit(lambda: ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H))
+print(f"{os.path.basename(_lib.LIB_PATH):>16}: halation {th:7.3f} ms   mtf {tm:7.3f} ms")
