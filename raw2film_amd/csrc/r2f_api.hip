@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/r2f.h"
@@ -53,8 +54,15 @@ struct r2f_ctx {
     DevCurve curve{};
     DevCurve grain_lut{};
     StencilSet stencil[3];
+    // tile-order tables of the stencil launches (xcd_remap = 2), keyed by the tile grid
+    struct TileOrder {
+        int gx = 0, gy = 0;
+        DeviceBuf buf;
+    } tile_order[4];
+    int tile_order_next = 0;
+    int opt_xcd_band = 0;  // tile columns per band of the xcd_remap = 2 order; 0 = auto
     int opt_variant = -1;  // -1 auto
-    int opt_xcd_remap = 1;
+    int opt_xcd_remap = 2;  // 0 = launch order, 1 = one contiguous row-major run of tiles per XCD, 2 = that run walked in column bands
     int opt_ablate = 0;
     int opt_sym = 1;      // use the mirror-symmetric entry form when a channel's taps allow it
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
@@ -337,6 +345,43 @@ int check_stencil_source(r2f_ctx* ctx, const char* what, const r2f_planes* src, 
     return check_rows(ctx, what, src, need_lo, need_hi + 1);
 }
 
+// Tile order for a gx x gy grid of stencil workgroups.  Linear workgroup ids are dealt round-robin to the 8 XCDs (each
+// with its own 4 MB L2), so XCD x runs ids x, x+8, ...  Give each XCD one contiguous row-major run of tiles (balanced to
+// one tile), and let it walk that run in bands of `b` tile columns, top to bottom: the ~64 tiles an XCD has in flight
+// then form a compact block whose halo rows AND columns are re-read from that L2 instead of from HBM.
+int ensure_tile_order(r2f_ctx* ctx, int gx, int gy, const int** out) {
+    for (auto& t : ctx->tile_order)
+        if (t.gx == gx && t.gy == gy && t.buf.p) {
+            *out = static_cast<const int*>(t.buf.p);
+            return R2F_OK;
+        }
+    const int nwg = gx * gy, q = nwg / 8, r = nwg % 8;
+    std::vector<int> order((size_t)nwg);
+    std::vector<int> tiles;
+    for (int x = 0; x < 8; ++x) {
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, len = q + (x < r ? 1 : 0);
+        if (len == 0) continue;
+        const int rows = (start + len - 1) / gx - start / gx + 1;
+        int b = std::max(1, std::min(gx, (64 + rows / 2) / rows));  // 32 CUs x 2 workgroups in flight per XCD
+        if (ctx->opt_xcd_band > 0) b = std::min(gx, ctx->opt_xcd_band);
+        tiles.resize((size_t)len);
+        for (int i = 0; i < len; ++i) tiles[(size_t)i] = start + i;
+        std::stable_sort(tiles.begin(), tiles.end(), [&](int a, int c) {
+            const int ba = (a % gx) / b, bc = (c % gx) / b;
+            return ba != bc ? ba < bc : a < c;  // band, then row-major inside the band
+        });
+        for (int i = 0; i < len; ++i) order[(size_t)i * 8 + x] = tiles[(size_t)i];
+    }
+    r2f_ctx::TileOrder& slot = ctx->tile_order[ctx->tile_order_next];
+    ctx->tile_order_next = (ctx->tile_order_next + 1) % 4;
+    int rc = upload(ctx, slot.buf, order.data(), order.size() * sizeof(int));
+    if (rc) return rc;
+    slot.gx = gx;
+    slot.gy = gy;
+    *out = static_cast<const int*>(slot.buf.p);
+    return R2F_OK;
+}
+
 int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
                 int epilogue, float log_eps, hipStream_t s) {
     if (y1 <= y0) return R2F_OK;
@@ -386,6 +431,12 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     a.nchan = 3;
     a.vec = planes_vec_ok(dst, W) ? 1 : 0;
     a.xcd_remap = ctx->opt_xcd_remap;
+    a.order = nullptr;
+    if (a.xcd_remap == 2) {
+        const StencilVariant& sv = kStencilVariants[variant];
+        rc = ensure_tile_order(ctx, (W + sv.TW() - 1) / sv.TW(), (y1 - y0 + sv.TH() - 1) / sv.TH(), &a.order);
+        if (rc) return rc;
+    }
     a.ablate = ctx->opt_ablate;
     R2F_HIP(ctx, launch_stencil(a, variant, s));
     return R2F_OK;
@@ -423,6 +474,7 @@ void r2f_destroy(r2f_ctx* ctx) {
             s.wbuf[c].release();
             s.mbuf[c].release();
         }
+    for (auto& t : ctx->tile_order) t.buf.release();
     delete ctx;
 }
 
@@ -448,8 +500,15 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         ctx->opt_ablate = value;
         return R2F_OK;
     }
+    if (!strcmp(name, "xcd_band")) {
+        if (value < 0) return fail(ctx, R2F_EINVAL, "xcd_band must be >= 0");
+        ctx->opt_xcd_band = value;
+        for (auto& t : ctx->tile_order) t.gx = t.gy = 0;  // rebuild the tables
+        return R2F_OK;
+    }
     if (!strcmp(name, "xcd_remap")) {
-        ctx->opt_xcd_remap = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, R2F_EINVAL, "xcd_remap must be 0, 1 or 2");
+        ctx->opt_xcd_remap = value;
         return R2F_OK;
     }
     return fail(ctx, R2F_EINVAL, "unknown option %s", name);

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
     if (a.xcd_remap) {
         // remap inside the channel's own 2-D tile grid: channels differ wildly in cost (the blue
         // halation plane is the identity), so a remap across channels would unbalance the XCDs
-        const int nwg = gridDim.x * gridDim.y;
-        const int id = xcd_remap(bx + gridDim.x * by, nwg);
+        const int nwg = gridDim.x * gridDim.y, lin = bx + gridDim.x * by;
+        const int id = a.xcd_remap == 2 ? a.order[lin] : xcd_remap(lin, nwg);
         bx = id % gridDim.x;
         by = id / gridDim.x;
     }

@@ -35,7 +35,8 @@ struct StencilArgs {
     float log_eps;
     int nchan;
     int vec;
-    int xcd_remap;
+    int xcd_remap;     // 0 none, 1 arithmetic (contiguous run per XCD), 2 table `order`
+    const int* order;  // xcd_remap == 2: tile index (bx + gx * by) of every linear workgroup id of one channel
     int ablate;  // profiling aid: 1 = skip the tile fill, 2 = skip the accumulation (results invalid)
 };
 

@@ -24,7 +24,7 @@ img = synthetic_frame_device(H, W)
 params = proc.prepare(neg, 6, 0.4, (W, H), seed=20260630, print_film=prt, halation_green_factor=0.3, exp_kelvin=6000,
                       color_masking=1.0, matrix=REC709_TO_XYZ, frame_width=fw, frame_height=fw * H / W)
 ctx.set_option("stencil_variant", variant)
-ctx.set_option("xcd_remap", int(os.environ.get("XCD", "0")))
+ctx.set_option("xcd_remap", int(os.environ.get("XCD", "2")))
 E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
 D = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
 D2 = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
