@@ -157,6 +157,12 @@ int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes*
 int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
                     void* stream);
 
+/* Caller-side RGB histogram of the rendered bitmap: the counting loop of utils.generate_histogram (utils.py:160-165; GPU twin
+ * histogram.wgsl pass1_accumulate, dispatched at gpu_processor.py:1149).  image_hwc: uint8 (H, W, 3) on the device, 16-byte
+ * aligned; counts: 3 x 256 uint32 on the device (R bins, G bins, B bins), overwritten.  The 768-value post-processing
+ * (log1p, 3-bin smoothing, bar image) is host work: raw2film_amd/histogram.py. */
+int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint32_t* counts, void* stream);
+
 /* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
  * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,

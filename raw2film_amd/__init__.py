@@ -6,7 +6,7 @@ Importing the package does not need a GPU; constructing `HipProcessor` / `HipCon
 and raises if the HIP library or the GPU is missing (there is no CPU fallback).
 """
 
-from . import filmstock, settings, stencils  # noqa: F401
+from . import filmstock, histogram, settings, stencils  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -301,6 +301,17 @@ class HipContext:
                                               self._stream()))
         return out
 
+    def histogram_counts(self, image_u8):
+        """Per-channel bin counts of a uint8 (H, W, 3) device image -> int32 (3, 256) device tensor (utils.py:160-165)."""
+        torch = self._torch
+        if not (image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.is_contiguous() and image_u8.dim() == 3
+                and image_u8.shape[2] == 3):
+            raise ValueError("histogram_counts needs a contiguous uint8 (H, W, 3) CUDA tensor")
+        counts = torch.empty((3, 256), dtype=torch.int32, device=self.device)
+        self._check(self._lib.r2f_histogram_u8(self._h, image_u8.data_ptr(), int(image_u8.shape[0]), int(image_u8.shape[1]),
+                                               counts.data_ptr(), self._stream()))
+        return counts
+
     def stage_noise(self, params, y0, y1, W, want_hash=True, want_noise=True):
         torch = self._torch
         rows = y1 - y0

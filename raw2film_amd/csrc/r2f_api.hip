@@ -896,6 +896,14 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
     return R2F_OK;
 }
 
+int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint32_t* counts, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (!counts || H < 0 || W < 0 || (!image_hwc && H > 0 && W > 0)) return fail(ctx, R2F_EINVAL, "histogram: bad arguments");
+    if (!aligned16(image_hwc)) return fail(ctx, R2F_EINVAL, "histogram: image must be 16-byte aligned");
+    R2F_HIP(ctx, launch_histogram_u8(image_hwc, (long long)H * W * 3, counts, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
 // ------------------------------------------------------------------------------- whole frame
 static size_t plane_set_floats(int H, int W) { return ((size_t)H * W + 3) / 4 * 4 * 3; }
 

@@ -9,6 +9,7 @@
 //   chroma_h/_v       pre-path chroma NR: xyY + separable Gaussian on the chromaticity planes  HBM-bound
 //   resize_area       pre-path INTER_AREA down-scale to the preview resolution
 //   noise_kernel      S6a test entry (hash + Gaussian field)
+//   histogram_u8      caller-side RGB histogram counts of the uint8 output (utils.generate_histogram, histogram.wgsl pass 1)
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
@@ -688,6 +689,51 @@ __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------ histogram
+// utils.generate_histogram's counting loop (utils.py:160-165) / histogram.wgsl pass1_accumulate on the uint8 (H, W, 3)
+// output: 3 x 256 counts.  HBM-bound (3 B/px); the byte stream is read 16 B per lane, channel = byte index mod 3.  Flat
+// images put most pixels into a few bins, so every group of 8 lanes owns a private copy of the table in LDS (same-address
+// LDS atomics serialise) and the copies are folded into global memory once per workgroup.
+constexpr int kHistCopies = 8, kHistThreads = 256, kHistBytesPerLane = 16, kHistIters = 16;
+
+__global__ __launch_bounds__(kHistThreads) void histogram_u8_kernel(const uint8_t* __restrict__ image, long long n_bytes,
+                                                                    uint32_t* __restrict__ counts) {
+    __shared__ uint32_t h[kHistCopies][768];
+    for (int i = threadIdx.x; i < kHistCopies * 768; i += kHistThreads) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t* mine = h[threadIdx.x & (kHistCopies - 1)];
+    const long long chunk = (long long)kHistThreads * kHistBytesPerLane;
+    long long base = (long long)blockIdx.x * chunk * kHistIters;
+    for (int it = 0; it < kHistIters; ++it, base += chunk) {
+        const long long o = base + (long long)threadIdx.x * kHistBytesPerLane;
+        if (o >= n_bytes) break;
+        int ch = (int)(o % 3);
+        if (o + kHistBytesPerLane <= n_bytes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(image + o);  // hipMalloc'ed images are 16-byte aligned
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    atomicAdd(&mine[ch * 256 + ((w[k] >> (8 * b)) & 255u)], 1u);
+                    ch = ch == 2 ? 0 : ch + 1;
+                }
+        } else {
+            for (long long i = o; i < n_bytes; ++i) {
+                atomicAdd(&mine[ch * 256 + image[i]], 1u);
+                ch = ch == 2 ? 0 : ch + 1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += kHistThreads) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int c = 0; c < kHistCopies; ++c) s += h[c][i];
+        if (s) atomicAdd(&counts[i], s);
+    }
+}
+
 // ------------------------------------------------------------------------------ launchers
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan) {
     size_t best = 0;
@@ -815,6 +861,15 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     dim3 block(256), grid((a.W + 255) / 256, a.y1 - a.y0);
     hipLaunchKernelGGL(noise_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(counts, 0, 768 * sizeof(uint32_t), s);
+    if (e != hipSuccess || n_bytes <= 0) return e;
+    const long long per_block = (long long)kHistThreads * kHistBytesPerLane * kHistIters;
+    hipLaunchKernelGGL(histogram_u8_kernel, dim3((unsigned)((n_bytes + per_block - 1) / per_block)), dim3(kHistThreads), 0, s,
+                       image, n_bytes, counts);
     return hipGetLastError();
 }
 

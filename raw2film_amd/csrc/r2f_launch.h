@@ -1,6 +1,7 @@
 // r2f_launch.h -- host-callable launchers implemented in r2f_kernels.hip.
 #pragma once
 
+#include <cstdint>
 #include "r2f_device.h"
 
 namespace r2f {
@@ -132,6 +133,9 @@ hipError_t launch_front(const FrontArgs& a, hipStream_t s);
 hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s);
 hipError_t launch_tail(const TailArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
+
+// Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
+hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s);
 hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s);
 hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s);
 hipError_t launch_chroma_h(const ChromaArgs& a, hipStream_t s);

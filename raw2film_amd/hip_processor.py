@@ -51,6 +51,7 @@ class HipProcessor:
         self.grain_lut_param_dict = None
         self.matrix_key = None
         self.uploads = 0  # number of table uploads, for the caching tests
+        self.last_output = None  # device uint8 (H, W, 3) of the last process()/process_preloaded(): histogram source
 
     def close(self):
         self.ctx.close()
@@ -265,7 +266,21 @@ class HipProcessor:
         # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic
         out_u8 = geometry.add_canvas(out_u8, settings.get("canvas_mode", "No"), settings.get("canvas_scale", 1.0),
                                      settings.get("canvas_ratio", 1.0))
+        self.last_output = out_u8
         return out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def generate_histogram(self, image=None, mix_table=None, height=100):
+        """utils.generate_histogram (utils.py:145-223) of `image` (uint8 (H, W, 3), NumPy or device) -- or, with no image,
+        of the frame the last process() call rendered, counted on the device before it ever left it (the GUI calls this
+        right after process(), gui.py:2225).  Returns the (height, 256, 4) uint8 bar image."""
+        from . import histogram
+
+        if image is None:
+            image = self.last_output
+            if image is None:
+                raise ValueError("generate_histogram(): no frame has been rendered yet")
+        return histogram.generate_histogram(image, histogram.MIX_TABLE if mix_table is None else mix_table, height,
+                                            ctx=self.ctx)
 
     def process_array(self, image, negative_film, grain_size=6, grain_sigma=0.4, *, colorspace="XYZ", seed=None,
                       return_float=False, output="host", **settings):
