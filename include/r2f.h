@@ -157,6 +157,13 @@ int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes*
 int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
                     void* stream);
 
+/* Pre-path free rotation: cv.warpAffine(rgb, rot_mat, same size, flags=cv.INTER_LINEAR) of effects.rotate (effects.py:46-52;
+ * constant border 0), restricted to the window [oy, oy + out_h) x [ox, ox + out_w) that rotate()'s centred crop keeps
+ * (effects.py:54-74).  m_dst_to_src: the INVERSE of cv.getRotationMatrix2D(...), 2 x 3 row-major doubles (host memory).
+ * `in` is a whole H x W frame (any in_layout); `dst` receives out_h x out_w planes. */
+int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const double* m_dst_to_src, const r2f_planes* dst,
+                    int out_h, int out_w, int oy, int ox, void* stream);
+
 /* Caller-side RGB histogram of the rendered bitmap: the counting loop of utils.generate_histogram (utils.py:160-165; GPU twin
  * histogram.wgsl pass1_accumulate, dispatched at gpu_processor.py:1149).  image_hwc: uint8 (H, W, 3) on the device, 16-byte
  * aligned; counts: 3 x 256 uint32 on the device (R bins, G bins, B bins), overwritten.  The 768-value post-processing

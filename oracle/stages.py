@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+import math
+
 import numpy as np
 from scipy import fft as sfft
 from scipy import ndimage
@@ -547,3 +549,70 @@ def render(image: np.ndarray, p: RenderInputs, method: str = "fft", keep_stages:
     else:
         x = apply_lut_trilinear(x, p.lut_3d, LUT3D_SCALE)
     return x
+
+
+# ---------------------------------------------------------------------------------------------- free rotation (pre-path)
+def rotation_matrix_2d(center, angle_deg, scale=1.0):
+    """cv.getRotationMatrix2D: [[a, b, (1-a) cx - b cy], [-b, a, b cx + (1-a) cy]], a = s cos, b = s sin (documented form)."""
+    ang = angle_deg * np.pi / 180.0
+    a, b = np.cos(ang) * scale, np.sin(ang) * scale
+    cx, cy = center
+    return np.array([[a, b, (1 - a) * cx - b * cy], [-b, a, b * cx + (1 - a) * cy]], dtype=np.float64)
+
+
+def invert_affine(m):
+    """cv.invertAffineTransform (what warpAffine applies when WARP_INVERSE_MAP is not set)."""
+    d = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22, a12, a21 = m[1, 1] * d, m[0, 0] * d, -m[0, 1] * d, -m[1, 0] * d
+    return np.array([[a11, a12, -a11 * m[0, 2] - a12 * m[1, 2]], [a21, a22, -a21 * m[0, 2] - a22 * m[1, 2]]])
+
+
+def warp_affine_linear(img, m_dst_to_src, out_shape=None, offset=(0, 0)):
+    """cv.warpAffine(img, M, dsize, flags=INTER_LINEAR), BORDER_CONSTANT 0, restated from the documented definition
+    dst(x, y) = src(M^-1 (x, y, 1)) with bilinear interpolation: float32 source coordinates and a two-step float32 lerp
+    (the shape of OpenCV >= 4.11's linear warp kernels).  PARITY UNPINNED: OpenCV is not installed here and its SIMD/scalar
+    paths differ in FMA use, so only tolerance-level agreement is meaningful anyway."""
+    img = np.asarray(img, dtype=np.float32)
+    H, W = img.shape[:2]
+    oh, ow = (H, W) if out_shape is None else out_shape
+    m = np.asarray(m_dst_to_src, dtype=np.float64).astype(np.float32)
+    xf = (np.arange(ow) + offset[1]).astype(np.float32)[None, :]
+    yf = (np.arange(oh) + offset[0]).astype(np.float32)[:, None]
+    sx = (xf * m[0, 0] + yf * m[0, 1]) + m[0, 2]
+    sy = (xf * m[1, 0] + yf * m[1, 1]) + m[1, 2]
+    x0f, y0f = np.floor(sx), np.floor(sy)
+    ax, ay = (sx - x0f)[..., None], (sy - y0f)[..., None]
+    x0 = np.clip(x0f, -2, W + 1).astype(np.int64)
+    y0 = np.clip(y0f, -2, H + 1).astype(np.int64)
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        v = img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1), :3]
+        return np.where(ok[..., None], v, np.float32(0))
+
+    t00, t01, t10, t11 = tap(y0, x0), tap(y0, x0 + 1), tap(y0 + 1, x0), tap(y0 + 1, x0 + 1)
+    top = t00 + ax * (t01 - t00)
+    bot = t10 + ax * (t11 - t10)
+    return (top + ay * (bot - top)).astype(np.float32)
+
+
+def rotate(img, degrees):
+    """effects.rotate, effects.py:46-75: warp about the frame centre by -degrees, then the centred crop."""
+    if not degrees:
+        return img
+    H, W = img.shape[:2]
+    rot = rotation_matrix_2d((W / 2, H / 2), -degrees, 1.0)  # :50-51
+    out = warp_affine_linear(img, invert_affine(rot))  # :52
+    aspect = H / W
+    angle = math.fabs(degrees) * math.pi / 180  # :54
+    if aspect < 1:  # :56-62
+        total_height, aspect, switch = H, 1 / aspect, True
+    else:
+        switch, total_height = False, W
+    w = total_height / (aspect * math.sin(angle) + math.cos(angle))  # :64
+    h = w * aspect
+    if switch:
+        w, h = h, w
+    ch, cw = int((H - h) // 2), int((W - w) // 2)  # :68-69
+    return out[ch:H - ch, cw:W - cw]

@@ -301,6 +301,22 @@ class HipContext:
                                               self._stream()))
         return out
 
+    def warp_affine(self, image, m_dst_to_src, window=None, layout=None):
+        """cv.warpAffine(image, M, same size, INTER_LINEAR) restricted to `window` = (row0, col0, rows, cols) -> (3, rows, cols)
+        planes.  m_dst_to_src: inverse of M, 2 x 3 (geometry.rotation_plan)."""
+        torch = self._torch
+        self._check_image(image)
+        layout, H, W = self.layout_of(image, layout)
+        r0, c0, nr, nc = (0, 0, H, W) if window is None else [int(v) for v in window]
+        out = torch.empty((3, nr, nc), dtype=torch.float32, device=self.device)
+        if nr == 0 or nc == 0:
+            return out
+        m = np.ascontiguousarray(np.asarray(m_dst_to_src, dtype=np.float64).reshape(6))
+        pd = self.planes(out, 0)
+        self._check(self._lib.r2f_warp_affine(self._h, image.data_ptr(), layout, H, W, m.ctypes.data, C.byref(pd), nr, nc, r0, c0,
+                                              self._stream()))
+        return out
+
     def histogram_counts(self, image_u8):
         """Per-channel bin counts of a uint8 (H, W, 3) device image -> int32 (3, 256) device tensor (utils.py:160-165)."""
         torch = self._torch

@@ -803,6 +803,28 @@ int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, c
     return R2F_OK;
 }
 
+int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const double* m_dst_to_src, const r2f_planes* dst,
+                    int out_h, int out_w, int oy, int ox, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (!in || !m_dst_to_src || in_layout < 0 || in_layout > 2 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
+        return fail(ctx, R2F_EINVAL, "warp_affine: bad arguments");
+    int rc = check_rows(ctx, "warp dst", dst, 0, out_h);
+    if (rc) return rc;
+    WarpArgs a;
+    a.in = in;
+    a.in_layout = in_layout;
+    a.H = H;
+    a.W = W;
+    a.dst = to_dev(dst);
+    a.out_h = out_h;
+    a.out_w = out_w;
+    a.oy = oy;
+    a.ox = ox;
+    for (int i = 0; i < 6; ++i) a.m[i] = (float)m_dst_to_src[i];
+    R2F_HIP(ctx, launch_warp_affine(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
 static int chroma_weights(r2f_ctx* ctx, int size, ChromaArgs& a) {
     // gaussian_kernel_1d(2*size+1, 0.3*((taps-1)/2 - 1) + 0.8), effects.py:421-435,554-556: exp in double, float32 taps
     // normalised by their float32 sum

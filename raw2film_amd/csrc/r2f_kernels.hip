@@ -8,6 +8,7 @@
 //   burn_sums/_map    S7: INTER_AREA cell sums of the green density; clip + Gaussian on the map
 //   chroma_h/_v       pre-path chroma NR: xyY + separable Gaussian on the chromaticity planes  HBM-bound
 //   resize_area       pre-path INTER_AREA down-scale to the preview resolution
+//   warp_affine       pre-path free rotation (cv.warpAffine, INTER_LINEAR, zero border)
 //   noise_kernel      S6a test entry (hash + Gaussian field)
 //   histogram_u8      caller-side RGB histogram counts of the uint8 output (utils.generate_histogram, histogram.wgsl pass 1)
 #include "r2f_launch.h"
@@ -665,6 +666,48 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const ResizeArgs a) {
     p0[2 * a.dst.plane_stride] = accZ;
 }
 
+// ------------------------------------------------------------------------------ free rotation (pre-path)
+// effects.rotate (effects.py:46-75): cv.warpAffine(rgb, getRotationMatrix2D(centre, -degrees, 1), same size, INTER_LINEAR)
+// followed by a centred crop; the kernel produces the cropped window only.  One lane per destination pixel, lanes along x.
+// Source coordinates and the two-step lerp are float32, like OpenCV's linear warp kernels (>= 4.11); taps that fall
+// outside the frame read the constant border 0.  HBM/L2-bound gather: neighbouring lanes read neighbouring texels for
+// the small angles a horizon correction uses.
+__global__ __launch_bounds__(256) void warp_affine_kernel(const WarpArgs a) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= a.out_w || dy >= a.out_h) return;
+    const float xf = (float)(dx + a.ox), yf = (float)(dy + a.oy);
+    const float sx = __fadd_rn(__fadd_rn(__fmul_rn(xf, a.m[0]), __fmul_rn(yf, a.m[1])), a.m[2]);
+    const float sy = __fadd_rn(__fadd_rn(__fmul_rn(xf, a.m[3]), __fmul_rn(yf, a.m[4])), a.m[5]);
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float ax = sx - fx0, ay = sy - fy0;
+    float v[3] = {0.f, 0.f, 0.f};
+    // int conversion only for coordinates that can touch the frame (also keeps huge values out of the cast)
+    if (fx0 >= -1.f && fy0 >= -1.f && fx0 < (float)a.W && fy0 < (float)a.H) {
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        float t[2][2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int xx = x0 + i, yy = y0 + j;
+                if (xx >= 0 && xx < a.W && yy >= 0 && yy < a.H)
+                    load_input1(a.in, a.in_layout, 0, a.H, a.W, yy, xx, t[j][i][0], t[j][i][1], t[j][i][2]);
+                else
+                    t[j][i][0] = t[j][i][1] = t[j][i][2] = 0.f;
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = __fadd_rn(t[0][0][c], __fmul_rn(ax, __fsub_rn(t[0][1][c], t[0][0][c])));
+            const float bot = __fadd_rn(t[1][0][c], __fmul_rn(ax, __fsub_rn(t[1][1][c], t[1][0][c])));
+            v[c] = __fadd_rn(top, __fmul_rn(ay, __fsub_rn(bot, top)));
+        }
+    }
+    float* p0 = a.dst.data + (long long)(dy - a.dst.gy0) * a.out_w + dx;
+    p0[0] = v[0];
+    p0[a.dst.plane_stride] = v[1];
+    p0[2 * a.dst.plane_stride] = v[2];
+}
+
 // ------------------------------------------------------------------------------ noise (test)
 __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -854,6 +897,12 @@ hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s) {
 hipError_t launch_resize_area(const ResizeArgs& a, hipStream_t s) {
     if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
     hipLaunchKernelGGL(resize_area_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s) {
+    if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(warp_affine_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 

@@ -105,6 +105,16 @@ struct ResizeArgs {
     int out_h, out_w;
 };
 
+// Pre-path free rotation: dst(y, x) = bilinear sample of `in` at M * (x + ox, y + oy, 1), zero outside (cv.warpAffine,
+// INTER_LINEAR, BORDER_CONSTANT); only the window the rotate() crop keeps is produced.
+struct WarpArgs {
+    const void* in;
+    int in_layout, H, W;
+    DevPlanes dst;
+    int out_h, out_w, oy, ox;
+    float m[6];  // dst -> src, row-major 2 x 3, rounded from double like OpenCV's float kernels
+};
+
 struct NoiseArgs {
     uint32_t* hash;
     float* noise;
@@ -132,6 +142,7 @@ hipError_t init_kernel_attributes();
 hipError_t launch_front(const FrontArgs& a, hipStream_t s);
 hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s);
 hipError_t launch_tail(const TailArgs& a, hipStream_t s);
+hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.

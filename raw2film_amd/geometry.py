@@ -5,8 +5,8 @@ reference's own functions through tests/golden/geometry.npz.
   crop_box / crop_to_frame   <->  effects.crop_image, raw_conversion.crop_rotate_zoom   effects.py:77-111, raw_conversion.py:56-72
   canvas_layout / add_canvas <->  effects.get_canvas_data, effects.add_canvas            effects.py:290-357
 
-Free rotation by an arbitrary angle (effects.rotate -> cv.warpAffine) is NOT provided here: it is an
-interpolating resample that belongs to the pre-path rows SURVEY.md 8f lists as "next".
+  rotation_plan              <->  effects.rotate (matrix handed to cv.warpAffine + the centred crop)  effects.py:46-75
+The interpolating resample of the free rotation itself runs on the device (r2f_warp_affine).
 """
 
 from __future__ import annotations
@@ -54,6 +54,34 @@ def crop_to_frame(image: np.ndarray, frame_width: float = 36, frame_height: floa
     r0, c0, nr, nc = crop_box(image.shape[0], image.shape[1], zoom, aspect, False)
     image = image[r0:r0 + nr, c0:c0 + nc]
     return np.rot90(image, k=rotate_times)
+
+
+def rotation_plan(rows: int, cols: int, degrees: float):
+    """What effects.rotate (effects.py:46-75) does to a rows x cols frame, as data:
+
+    (m_dst_to_src, (row0, col0, out_rows, out_cols)) -- the inverse of cv.getRotationMatrix2D((cols/2, rows/2), -degrees, 1)
+    (what cv.warpAffine samples with; 2 x 3 float64, OpenCV's invertAffineTransform arithmetic) and the centred window
+    kept afterwards: the largest axis-parallel rectangle of the frame's aspect inside the rotated frame."""
+    cx, cy = cols / 2, rows / 2  # tuple(np.array(rgb.shape[1::-1]) / 2)
+    angle = -degrees * math.pi / 180  # getRotationMatrix2D: degrees -> radians, scale 1
+    alpha, beta = math.cos(angle), math.sin(angle)
+    m = np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]])
+    d = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]  # invertAffineTransform
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22, a12, a21 = m[1, 1] * d, m[0, 0] * d, -m[0, 1] * d, -m[1, 0] * d
+    inv = np.array([[a11, a12, -a11 * m[0, 2] - a12 * m[1, 2]], [a21, a22, -a21 * m[0, 2] - a22 * m[1, 2]]])
+    aspect = rows / cols
+    ang = math.fabs(degrees) * math.pi / 180
+    if aspect < 1:
+        total, aspect, switch = rows, 1 / aspect, True
+    else:
+        total, switch = cols, False
+    w = total / (aspect * math.sin(ang) + math.cos(ang))
+    h = w * aspect
+    if switch:
+        w, h = h, w
+    crop_r, crop_c = int((rows - h) // 2), int((cols - w) // 2)
+    return inv, (crop_r, crop_c, max(rows - 2 * crop_r, 0), max(cols - 2 * crop_c, 0))
 
 
 def canvas_layout(shape, canvas_mode: str, canvas_scale: float = 1.0, canvas_ratio: float = 1.0):

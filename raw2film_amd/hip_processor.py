@@ -158,13 +158,24 @@ class HipProcessor:
         """PHASE 1 of the two-phase batch API (gpu_processor.py:715-783): pure host work, touches
         no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32."""
         image = self._load_decoded(src)
+        aspect = frame_width / frame_height
+        warp = None
         if rotation:
-            raise NotImplementedError(
-                "free rotation (effects.rotate -> cv.warpAffine) is outside the accelerated path (SURVEY.md section 8f)"
-            )
-        # aspect crop / zoom / quarter turns: index arithmetic of raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72)
-        image = geometry.crop_to_frame(image, frame_width, frame_height, zoom, rotate_times, flip)
-        h, w = image.shape[:2]
+            # raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72) with the interpolating part deferred to the device:
+            # aspect crop here (a view), then phase 2 warps straight into the window that effects.rotate's centred crop
+            # and the zoom crop keep, and applies the quarter turns
+            r0, c0, nr, nc = geometry.crop_box(image.shape[0], image.shape[1], 1, aspect, flip)
+            image = image[r0:r0 + nr, c0:c0 + nc]
+            m_inv, (wr0, wc0, wnr, wnc) = geometry.rotation_plan(nr, nc, rotation)
+            zr0, zc0, znr, znc = geometry.crop_box(wnr, wnc, zoom, aspect, False)
+            if znr <= 0 or znc <= 0:
+                raise ValueError(f"rotation {rotation} / zoom {zoom} leave an empty frame")
+            warp = {"m_dst_to_src": m_inv, "window": (wr0 + zr0, wc0 + zc0, znr, znc), "rotate_times": int(rotate_times) % 4}
+            h, w = (znc, znr) if warp["rotate_times"] % 2 else (znr, znc)
+        else:
+            # aspect crop / zoom / quarter turns: index arithmetic of raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72)
+            image = geometry.crop_to_frame(image, frame_width, frame_height, zoom, rotate_times, flip)
+            h, w = image.shape[:2]
         if max_scale is not None and max(h, w) / max(frame_width, frame_height) > max_scale and resolution is None:
             raise NotImplementedError(
                 f"frame is finer than max_scale={max_scale} px/mm; the reference down-scales before and LANCZOS4-up-scales "
@@ -195,6 +206,7 @@ class HipProcessor:
             # upstream filters on the host here (gpu_processor.py:750-751); this backend filters on the device in phase 2
             "chroma_nr": int(chroma_nr),
             "resize_to": resize_to,  # (rows, cols) of the INTER_AREA down-scale still to be applied, or None
+            "warp": warp,  # free rotation still to be applied (first of the device pre-path steps), or None
         }
 
     @staticmethod
@@ -257,8 +269,14 @@ class HipProcessor:
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
         image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         layout = None  # the payload is (H, W, C) like the reference's; the device pre-path hands on (3, H, W) planes
+        warp = cpu_payload.get("warp")
+        if warp:  # free rotation (effects.rotate) + the crops behind it + quarter turns (np.rot90 on the planes)
+            image = self.ctx.warp_affine(image.contiguous(), warp["m_dst_to_src"], warp["window"])
+            if warp["rotate_times"]:
+                image = torch.rot90(image, warp["rotate_times"], dims=(1, 2)).contiguous()
+            layout = "chw"
         if cpu_payload.get("chroma_nr"):  # pre-path chroma NR (effects.py:547-561): XYZ planes out, CHW into the pipeline
-            image, layout = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"]), "chw"
+            image, layout = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"], layout=layout), "chw"
         if cpu_payload.get("resize_to"):  # preview down-scale (cv.INTER_AREA), after the NR like cpu_processor.py:119-134
             image, layout = self.ctx.resize_area(image.contiguous(), *cpu_payload["resize_to"], layout=layout), "chw"
         _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,

@@ -46,3 +46,37 @@ def test_crop_to_frame_quarter_turns():
     assert out.shape == (600, 400, 3)
     sq = geometry.crop_to_frame(img, 56, 56)
     assert sq.shape == (400, 400, 3) and sq[0, 0, 0] == img[0, 100, 0]
+
+
+def test_rotation_plan_window_matches_reference():
+    """tests/golden/rotate_crop.npz: the window effects.rotate keeps, and the centre / angle it hands to OpenCV."""
+    import os
+
+    from oracle import stages as st
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rotate_crop.npz"))["cases"]
+    assert len(g) == 81
+    for H, W, deg, oh, ow, r0, c0, cx, cy, angle, scale in g:
+        H, W = int(H), int(W)
+        inv, win = geometry.rotation_plan(H, W, deg)
+        assert win == (r0, c0, oh, ow)
+        assert (cx, cy, angle, scale) == (W / 2, H / 2, -deg, 1.0)
+        # the product's inverse matrix and the oracle's (separate code) agree bit for bit, and invert the forward matrix
+        fwd = st.rotation_matrix_2d((cx, cy), angle, scale)
+        assert np.array_equal(inv, st.invert_affine(fwd))
+        full = np.vstack([fwd, [0, 0, 1]]) @ np.vstack([inv, [0, 0, 1]])
+        assert np.allclose(full, np.eye(3), atol=1e-9)
+        if H <= 600:
+            assert st.rotate(np.zeros((H, W, 3), np.float32), deg).shape[:2] == (oh, ow)
+
+
+def test_oracle_warp_is_the_identity_for_the_identity_matrix_and_zero_outside():
+    from oracle import stages as st
+
+    img = np.random.default_rng(3).random((9, 13, 3)).astype(np.float32)
+    eye = np.array([[1, 0, 0], [0, 1, 0]], float)
+    assert np.array_equal(st.warp_affine_linear(img, eye), img)
+    shifted = st.warp_affine_linear(img, np.array([[1, 0, 0.5], [0, 1, 0]], float))  # samples half a pixel to the right
+    assert np.allclose(shifted[:, :-1], 0.5 * (img[:, :-1] + img[:, 1:]))
+    assert np.allclose(shifted[:, -1], 0.5 * img[:, -1])  # the right neighbour is the constant border 0
+    assert not st.warp_affine_linear(img, np.array([[1, 0, 100.0], [0, 1, 0]], float)).any()

@@ -92,6 +92,47 @@ def test_crop_zoom_turn_and_canvas(proc):
     assert _u8_close(out, ref)
 
 
+@pytest.mark.parametrize("deg,zoom,k,flip", [(2.5, 1.0, 0, False), (-11.0, 1.4, 1, False), (44.0, 1.0, 3, True), (0.3, 1.0, 2, False)])
+def test_free_rotation_through_the_processor(proc, deg, zoom, k, flip):
+    from raw2film_amd import geometry
+
+    neg, prt, _ = stocks()
+    img = _xyz(150, 210, seed=45)
+    kw = dict(print_film=prt, halation=False, sharpness=False, grain=0, exp_kelvin=6000, color_masking=1.0,
+              frame_width=36, frame_height=24, max_scale=None)
+    out = proc.process(img, neg, 6, 0.4, rotation=deg, zoom=zoom, rotate_times=k, flip=flip, **kw)
+    # raw_conversion.crop_rotate_zoom on the oracle side
+    r0, c0, nr, nc = geometry.crop_box(150, 210, 1, 1.5, flip)
+    pre = st.rotate(np.ascontiguousarray(img[r0:r0 + nr, c0:c0 + nc]), deg)
+    z = geometry.crop_box(pre.shape[0], pre.shape[1], zoom, 1.5, False)
+    pre = np.ascontiguousarray(np.rot90(pre[z[0]:z[0] + z[2], z[1]:z[1] + z[3]], k))
+    p = oracle_inputs(neg, prt, max(pre.shape[:2]) / 36, halation=False, mtf=False, grain=0, matrix=False)
+    ref = st.to_uint8(st.render(pre, p))
+    assert out.shape == ref.shape
+    assert _u8_close(out, ref)
+
+
+def test_warp_affine_matches_oracle_on_every_layout(proc):
+    from raw2film_amd import geometry
+
+    rng = np.random.default_rng(8)
+    img = rng.uniform(0, 4, (97, 131, 3)).astype(np.float32)
+    for deg in (5.0, -33.0, 90.0, 180.0):
+        m, win = geometry.rotation_plan(97, 131, deg)
+        ref_full = st.warp_affine_linear(img, m)
+        ref_win = st.warp_affine_linear(img, m, win[2:], win[:2])
+        assert np.array_equal(ref_win, ref_full[win[0]:win[0] + win[2], win[1]:win[1] + win[3]])
+        for layout in ("hwc3", "hwc4", "chw"):
+            a = img if layout == "hwc3" else np.concatenate([img, np.ones((97, 131, 1), np.float32)], -1) if layout == "hwc4" \
+                else np.ascontiguousarray(img.transpose(2, 0, 1))
+            t = torch.from_numpy(a).cuda()
+            got = proc.ctx.warp_affine(t, m, layout=layout).cpu().numpy().transpose(1, 2, 0)
+            # float32 coordinates: a last-bit difference in sx moves the sample by 2^-17 px at x ~ 100 -> ~1e-5 of the local contrast
+            assert np.abs(got - ref_full).max() <= 2e-5 * 4
+            gotw = proc.ctx.warp_affine(t, m, win, layout=layout).cpu().numpy().transpose(1, 2, 0)
+            assert np.array_equal(gotw, got[win[0]:win[0] + win[2], win[1]:win[1] + win[3]])
+
+
 def test_uploads_happen_only_on_change(proc):
     neg, prt, _ = stocks()
     img = _xyz(48, 64, seed=45)

@@ -124,8 +124,6 @@ def test_out_of_scope_requests_raise(proc):
     with pytest.raises(NotImplementedError):
         proc.process("photo.cr3", neg, 6, 0.4)
     with pytest.raises(NotImplementedError):
-        proc.extract_image_data_cpu(img, rotation=3.0)
-    with pytest.raises(NotImplementedError):
         proc.extract_image_data_cpu(img, frame_width=0.1, frame_height=0.07)  # finer than max_scale
     with pytest.raises(NotImplementedError):
         proc.extract_image_data_cpu(img, resolution=(80, 120))  # up-scaling needs LANCZOS4
@@ -141,6 +139,28 @@ def test_extract_crops_zooms_turns_and_reports_canvas(proc):
     assert p["image_array"].shape[0] > p["image_array"].shape[1]  # quarter turn of a landscape crop
     w, h = p["pipeline_resolution"]
     assert p["canvas_resolution"] == (w + int(max(h, w) * 0.1), h + int(max(h, w) * 0.1)) or p["canvas_resolution"][0] > w
+
+
+def test_free_rotation_is_deferred_to_the_device_with_the_reference_window(proc):
+    """Phase 1 only plans the rotation: aspect crop on the host, then a warp into the window effects.rotate + the zoom crop keep."""
+    from oracle import stages as st
+    from raw2film_amd import geometry
+
+    img = np.random.default_rng(2).uniform(0, 1, (420, 600, 3)).astype(np.float32)
+    for deg, zoom, k in ((3.5, 1.0, 0), (-8.0, 1.3, 1), (0.7, 1.0, 2)):
+        p = proc.extract_image_data_cpu(img, rotation=deg, zoom=zoom, rotate_times=k, max_scale=None)
+        # the oracle's whole-frame route: aspect crop -> rotate (warp + crop) -> zoom crop -> quarter turns
+        r0, c0, nr, nc = geometry.crop_box(420, 600, 1, 1.5, False)
+        ref = st.rotate(img[r0:r0 + nr, c0:c0 + nc], deg)
+        z = geometry.crop_box(ref.shape[0], ref.shape[1], zoom, 1.5, False)
+        ref = np.rot90(ref[z[0]:z[0] + z[2], z[1]:z[1] + z[3]], k)
+        assert p["pipeline_resolution"] == (ref.shape[1], ref.shape[0])
+        assert p["image_array"].shape[:2] == (nr, nc) and p["warp"]["rotate_times"] == k
+        # and the planned window reproduces that route when the oracle's warp is evaluated on it
+        w = p["warp"]
+        direct = st.warp_affine_linear(img[r0:r0 + nr, c0:c0 + nc], w["m_dst_to_src"], w["window"][2:], w["window"][:2])
+        assert np.array_equal(np.rot90(direct, k), ref)
+    assert proc.extract_image_data_cpu(img)["warp"] is None
 
 
 def test_preview_resolution_becomes_an_area_downscale(proc):
