@@ -124,6 +124,20 @@ int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, i
     cv.x1 = lut[m - 1];
     const float range = lut[m - 1] - lut[0];
     cv.inv_step = range > 0.f ? (float)(m - 1) / range : 0.f;
+    // `near`: is the device's first guess (same float32 arithmetic) within one cell of the true cell for every x?  Both
+    // are monotone step functions of x, so it is enough to look at each breakpoint and at the float just below it.
+    cv.near = 1;
+    const int last = m - 2;
+    auto guess = [&](float x) {
+        const int g = (int)((x - cv.x0) * cv.inv_step);
+        return g < 0 ? 0 : (g > last ? last : g);
+    };
+    for (int k = 1; k + 1 < m && cv.near; ++k) {
+        if (lut[k] == lut[k - 1] || lut[k] == lut[k + 1]) cv.near = 0;  // repeated abscissae: keep the exact walk
+        const int at = guess(lut[k]), below = guess(std::nextafterf(lut[k], -INFINITY));
+        const int t_at = k > last ? last : k, t_below = k - 1;
+        if (std::abs(at - t_at) > 1 || std::abs(below - t_below) > 1) cv.near = 0;
+    }
     return R2F_OK;
 }
 
@@ -178,10 +192,18 @@ void build_stream(Tap tap, int kh, int kw, bool sym, int Q, int RS, int TH, int 
                 }
             }
             if (c_hi < 0) continue;  // no work on this row step
+            // live tap columns of the first and of the last entry (bit t: some row of column 4c+t is non-zero)
+            auto live = [&](int c) {
+                int bits = 0;
+                for (int t = 0; t < 4; ++t)
+                    for (int q = 0; q < Q; ++q)
+                        if (wt(m - q, 4 * c + t) != 0.f) bits |= 1 << t;
+                return bits;
+            };
             out.rowinfo.push_back(c_hi - c_lo + 1);
             out.rowinfo.push_back((m - m0) * RS + 4 * c_lo);
             out.rowinfo.push_back(sym ? (m - m0) * RS + 2 * r - 4 * c_lo - 4 : 0);
-            out.rowinfo.push_back(0);
+            out.rowinfo.push_back(live(c_lo) | live(c_hi) << 4);
             for (int c = c_lo; c <= c_hi; ++c) {
                 ++out.n_entries;
                 for (int t = 0; t < 4; ++t)

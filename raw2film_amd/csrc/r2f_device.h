@@ -24,6 +24,8 @@ struct DevCurve {
     float x1;        // xp[m-1]
     float inv_step;  // (m-1)/(xp[m-1]-xp[0]): first guess of the cell, corrected against the cell's own bounds
     float f_first[3], f_last[3];  // fp[ch][0], fp[ch][m-1]: the clamped ends of np.interp
+    int near;        // 1: the first guess is never more than one cell off (checked on the host for every breakpoint;
+                     // true for any near-uniform axis) -> one corrective gather instead of a walk
 };
 
 struct DevLut2D {  // S1: n*n float4 texels (rgb + pad), texel (xi, yi) at xi*n + yi
@@ -47,7 +49,8 @@ struct DevStencil {
     const float* wstream;  // per entry: 4*Q floats  w[t][q] = K[m-q][4c+t]  (0 outside the taps)
     const int* rowinfo;    // per non-empty row step 4 ints: {number of entries (>= 1),
                            //   LDS float offset of its first entry (m - m0(phase))*RS + 4*c_lo,
-                           //   sym only: LDS offset of that entry's mirrored 8-float block (m - m0)*RS + 2r - 4*c_lo - 4, 0};
+                           //   sym only: LDS offset of that entry's mirrored 8-float block (m - m0)*RS + 2r - 4*c_lo - 4,
+                           //   live tap columns of the first entry (bits 0-3) and of the last entry (bits 4-7)};
                            // the following entries of the row step sit 4 floats further right (mirrored: further left)
     const int* phases;     // per phase 4 ints: {m0, lds_rows, first row step (index into rowinfo), first entry}
                            // + one terminator {., ., n_rowsteps, n_entries}
@@ -89,15 +92,22 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // non-decreasing xp gives exact np.interp results (uniform grids never take a step).
 template <class CellPtr>
 __device__ __forceinline__ float curve_eval_at(CellPtr cells_base, const DevCurve& cv, int ch, float x) {
-    if (!(x > cv.x0)) return cv.f_first[ch];
-    if (x >= cv.x1) return cv.f_last[ch];
     const int last = cv.m - 2;
     CellPtr cells = cells_base + ch * (cv.m - 1);
     int i = clampi((int)((x - cv.x0) * cv.inv_step), 0, last);
     float4 c = cells[i];
-    while (x < c.x && i > 0) c = cells[--i];
-    while (x >= c.y && i < last) c = cells[++i];
-    return fmaf(c.w, x - c.x, c.z);
+    if (cv.near) {
+        // branch-free: the corrective gather is issued for every pixel (it re-reads the same cell when the guess was
+        // right), so the evaluations of a lane's pixels and channels are independent and their gathers overlap --
+        // a data-dependent walk serialises them into one memory round trip after the other
+        const int adj = (x < c.x && i > 0) ? -1 : ((x >= c.y && i < last) ? 1 : 0);
+        c = cells[i + adj];
+    } else {
+        while (x < c.x && i > 0) c = cells[--i];
+        while (x >= c.y && i < last) c = cells[++i];
+    }
+    const float v = fmaf(c.w, x - c.x, c.z);
+    return !(x > cv.x0) ? cv.f_first[ch] : (x >= cv.x1 ? cv.f_last[ch] : v);
 }
 
 __device__ __forceinline__ float curve_eval(const DevCurve& cv, int ch, float x) {
@@ -371,39 +381,61 @@ __device__ __forceinline__ void entry_step(const float* lds, const int noff,
 // reads two 8-float blocks, L at columns 4c.. and the mirrored R at columns 2r-4c-4.. (r is made even
 // on the host so that R is 16-byte aligned), forms 16 sums s[p][t] = L[p+t] + R[4+p-t], and issues the
 // same 8*Q packed FMAs as a plain entry -- for twice the taps.  1.5x fewer VALU instructions per tap.
-template <int Q, bool FIRST>
+// One tap column t of a symmetric entry: the 4 mirrored sums, then 2*Q packed FMAs.
+// L index p+t and R index 4+p-t have the same parity, so the sums of two neighbouring pixels come out of one
+// v_pk_add_f32 on two aligned register pairs whenever p+t is even: (p=0,1), (p=2,3) for even t; (p=1,2) for odd t
+// (p=0 and p=3 are then single adds).  10 VALU instructions per entry instead of 16, same 16 sums, same rounding.
+template <int Q, int T, bool MUL>
+__device__ __forceinline__ void tap_fma_sym(const typename WVec<4 * Q>::type& w, const float (&lw)[8], const float (&rw)[8],
+                                            float2v (&part)[Q / 2][4]) {
+    float sum[4];
+    if ((T & 1) == 0) {
+        const float2v s01 = float2v{lw[T], lw[T + 1]} + float2v{rw[4 - T], rw[5 - T]};
+        const float2v s23 = float2v{lw[T + 2], lw[T + 3]} + float2v{rw[6 - T], rw[7 - T]};
+        sum[0] = s01.x, sum[1] = s01.y, sum[2] = s23.x, sum[3] = s23.y;
+    } else {
+        const float2v s12 = float2v{lw[T + 1], lw[T + 2]} + float2v{rw[5 - T], rw[6 - T]};
+        sum[0] = lw[T] + rw[4 - T];
+        sum[1] = s12.x, sum[2] = s12.y;
+        sum[3] = lw[T + 3] + rw[7 - T];
+    }
+#pragma unroll
+    for (int j = 0; j < Q / 2; ++j) {
+        const float2v wv = {w[T * Q + 2 * j], w[T * Q + 2 * j + 1]};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float2v px = {sum[p], sum[p]};
+            part[j][p] = MUL ? wv * px : __builtin_elementwise_fma(wv, px, part[j][p]);
+        }
+    }
+}
+
+// FIRST: the entry starts the row partial (multiply instead of fma).  MASKED: only the tap columns whose bit is set in
+// `mask` are evaluated -- the first and last entry of a row step usually hold padding columns or the rim of a disc
+// (all-zero weights); `mask` is wave-uniform (it comes from the row-step record), so each test is a scalar branch.
+template <int Q, bool FIRST, bool MASKED>
 __device__ __forceinline__ void entry_fma_sym(const typename WVec<4 * Q>::type& w, const float4v& la, const float4v& lb,
-                                              const float4v& ra, const float4v& rb, float2v (&part)[Q / 2][4]) {
+                                              const float4v& ra, const float4v& rb, float2v (&part)[Q / 2][4], const int mask) {
     const float lw[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
     const float rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    if (!MASKED) {
+        tap_fma_sym<Q, 0, FIRST>(w, lw, rw, part);
+        tap_fma_sym<Q, 1, false>(w, lw, rw, part);
+        tap_fma_sym<Q, 2, false>(w, lw, rw, part);
+        tap_fma_sym<Q, 3, false>(w, lw, rw, part);
+    } else {
+        // (a single dispatch on the whole mask into straight-line prefix / suffix variants measured slower than these
+        // four scalar branches: 14.7 vs 14.2 ms on the 100 MP halation)
+        if (FIRST) {  // fma(w, x, +0) == w * x: starting from zero gives the same partial as starting with a multiply
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        // L index p+t and R index 4+p-t have the same parity, so the sums of two neighbouring pixels come out of one
-        // v_pk_add_f32 on two aligned register pairs whenever p+t is even: (p=0,1), (p=2,3) for even t; (p=1,2) for odd t
-        // (p=0 and p=3 are then single adds).  10 VALU instructions instead of 16, same 16 sums, same rounding.
-        float sum[4];
-        if ((t & 1) == 0) {
-            const float2v s01 = float2v{lw[t], lw[t + 1]} + float2v{rw[4 - t], rw[5 - t]};
-            const float2v s23 = float2v{lw[t + 2], lw[t + 3]} + float2v{rw[6 - t], rw[7 - t]};
-            sum[0] = s01.x, sum[1] = s01.y, sum[2] = s23.x, sum[3] = s23.y;
-        } else {
-            const float2v s12 = float2v{lw[t + 1], lw[t + 2]} + float2v{rw[5 - t], rw[6 - t]};
-            sum[0] = lw[t] + rw[4 - t];
-            sum[1] = s12.x, sum[2] = s12.y;
-            sum[3] = lw[t + 3] + rw[7 - t];
+            for (int j = 0; j < Q / 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) part[j][p] = float2v{0.f, 0.f};
         }
-#pragma unroll
-        for (int j = 0; j < Q / 2; ++j) {
-            const float2v wv = {w[t * Q + 2 * j], w[t * Q + 2 * j + 1]};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float2v px = {sum[p], sum[p]};
-                if (FIRST && t == 0)
-                    part[j][p] = wv * px;
-                else
-                    part[j][p] = __builtin_elementwise_fma(wv, px, part[j][p]);
-            }
-        }
+        if (mask & 1) tap_fma_sym<Q, 0, false>(w, lw, rw, part);
+        if (mask & 2) tap_fma_sym<Q, 1, false>(w, lw, rw, part);
+        if (mask & 4) tap_fma_sym<Q, 2, false>(w, lw, rw, part);
+        if (mask & 8) tap_fma_sym<Q, 3, false>(w, lw, rw, part);
     }
 }
 
@@ -413,29 +445,25 @@ struct SymOperands {
     float4v la, lb, ra, rb;
 };
 
-template <int Q, bool FIRST>
-__device__ __forceinline__ void entry_step_sym(const float* lds, const int noff, const int noffr,
-                                               const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
-                                               const SymOperands<Q>& cur, SymOperands<Q>& nxt, float2v (&part)[Q / 2][4],
-                                               const int4v R2F_CONSTANT* info_ptr = nullptr, int4v* info_nn = nullptr) {
-    asm volatile("" ::"s"(cur.w[0]), "s"(cur.w[4 * Q - 1]), "v"(cur.la.x), "v"(cur.lb.w), "v"(cur.ra.x), "v"(cur.rb.w));
-    __builtin_amdgcn_sched_barrier(0);
-    if (FIRST) *info_nn = *info_ptr;  // see entry_step
 #ifndef R2F_EXP
 #define R2F_EXP 0  // development switch (tools/ablate_stencil.py): bit 0 no LDS reads, 1 no weight loads, 2 no FMAs
 #endif
+
+template <int Q, bool FIRST, bool MASKED>
+__device__ __forceinline__ void entry_step_sym(const float* lds, const int noff, const int noffr,
+                                               const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
+                                               const SymOperands<Q>& cur, SymOperands<Q>& nxt, float2v (&part)[Q / 2][4],
+                                               const int mask = 15, const int4v R2F_CONSTANT* info_ptr = nullptr,
+                                               int4v* info_nn = nullptr) {
+    asm volatile("" ::"s"(cur.w[0]), "s"(cur.w[4 * Q - 1]), "v"(cur.la.x), "v"(cur.lb.w), "v"(cur.ra.x), "v"(cur.rb.w));
+    __builtin_amdgcn_sched_barrier(0);
+    if (FIRST) *info_nn = *info_ptr;  // see entry_step
     if (R2F_EXP & 2) {
         asm volatile("" : "=s"(nxt.w));  // "defined" without an instruction: garbage weights
     } else {
         nxt.w = wstream[(e + 1) * wmul];
     }
-    float4v d0, d1, d2, d3;
-    if (R2F_EXP & 8) {  // LDS traffic without consumers: the reads are issued and only waited for after the FMAs
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16"
-                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-                     : "v"((unsigned)(size_t)(lds + noff) ), "v"((unsigned)(size_t)(lds + noffr)));
-        asm volatile("" : "=v"(nxt.la), "=v"(nxt.lb), "=v"(nxt.ra), "=v"(nxt.rb));
-    } else if (R2F_EXP & 1) {
+    if (R2F_EXP & 1) {
         asm volatile("" : "=v"(nxt.la), "=v"(nxt.lb), "=v"(nxt.ra), "=v"(nxt.rb));
     } else {
         nxt.la = *reinterpret_cast<const float4v*>(lds + noff);
@@ -451,15 +479,15 @@ __device__ __forceinline__ void entry_step_sym(const float* lds, const int noff,
         else
             part[0][0] += float2v{cur.w[0] + cur.w[4 * Q - 1], cur.la.x + cur.lb.w + cur.ra.x + cur.rb.w};
     } else
-        entry_fma_sym<Q, FIRST>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part);
-    if (R2F_EXP & 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
-    }
+        entry_fma_sym<Q, FIRST, MASKED>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part, mask);
     ++e;
 }
 
-template <int Q>
+// Row step = first entry (masked), middle entries (all four tap columns), last entry (masked).  The two operand sets
+// alternate entry by entry; the current entry sits in set A at the top of every row step.  MASKS = false evaluates every
+// tap column of every entry (the tail kernel's 9x9 grain stencil: two entries per row step, the branches cost more than
+// the padding columns they skip -- 2.0 vs 1.8 ms).
+template <int Q, bool MASKS>
 __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const DevStencil& st, int row_begin, int row_end,
                                                        int e0, float2v (&acc)[Q / 2][4]) {
     typedef typename WVec<4 * Q>::type wvec;
@@ -477,30 +505,29 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
     A.rb = *reinterpret_cast<const float4v*>(lds + ri.z + 4);
     for (int r = row_begin; r < row_end; ++r) {
         const int cnt = ri.x;
+        const int m_first = cnt > 1 ? (ri.w & 15) : (ri.w & (ri.w >> 4) & 15), m_last = (ri.w >> 4) & 15;
         int off = ri.y + 4, offr = ri.z - 4;  // LDS offsets of the entry after the current one, if it is in this row step
-#define R2F_NEXT_OFFS(i) const bool last = (i) + 1 >= cnt; const int no = last ? ri_n.y : off, nor = last ? ri_n.z : offr; off += 4; offr -= 4;
-        {
-            R2F_NEXT_OFFS(0)
-            entry_step_sym<Q, true>(lds, no, nor, wstream, wmul, e, A, B, part, info + r + 2, &ri_nn);
+        {  // entry 0
+            const bool only = cnt <= 1;
+            const int no = only ? ri_n.y : off, nor = only ? ri_n.z : offr;
+            off += 4, offr -= 4;
+            entry_step_sym<Q, true, MASKS>(lds, no, nor, wstream, wmul, e, A, B, part, m_first, info + r + 2, &ri_nn);
         }
         int i = 1;
-        for (; i + 1 < cnt; i += 2) {
-            {
-                const int no = off, nor = offr;  // entry i+1 is in this row step
-                off += 4, offr -= 4;
-                entry_step_sym<Q, false>(lds, no, nor, wstream, wmul, e, B, A, part);
-            }
-            {
-                R2F_NEXT_OFFS(i + 1)
-                entry_step_sym<Q, false>(lds, no, nor, wstream, wmul, e, A, B, part);
-            }
+        for (; i + 2 < cnt; i += 2) {  // two middle entries: i (set B) and i + 1 (set A); entry i + 2 exists in this row step
+            entry_step_sym<Q, false, false>(lds, off, offr, wstream, wmul, e, B, A, part);
+            entry_step_sym<Q, false, false>(lds, off + 4, offr - 4, wstream, wmul, e, A, B, part);
+            off += 8, offr -= 8;
         }
-        if (i < cnt) {  // entry i = cnt - 1 is the last of the row step
-            entry_step_sym<Q, false>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part);
-        } else {
+        if (i + 1 < cnt) {  // two entries left: a middle one (set B), then the last (set A)
+            entry_step_sym<Q, false, false>(lds, off, offr, wstream, wmul, e, B, A, part);
+            entry_step_sym<Q, false, MASKS>(lds, ri_n.y, ri_n.z, wstream, wmul, e, A, B, part, m_last);
+            A = B;
+        } else if (i < cnt) {  // one entry left: the last (set B)
+            entry_step_sym<Q, false, MASKS>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part, m_last);
+        } else {  // cnt == 1
             A = B;
         }
-#undef R2F_NEXT_OFFS
 #pragma unroll
         for (int j = 0; j < Q / 2; ++j)
 #pragma unroll

@@ -305,8 +305,10 @@ __device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, 
     }
 }
 
+// amdgpu_waves_per_eu(4): two 512-thread workgroups per CU (4 waves per SIMD) is the operating point the LDS budget is
+// built around, so the register allocator must stay within 128 VGPRs.
 template <int BX, int BY, int Q, int EPI>
-__global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
+__global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) void stencil_kernel(const StencilArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = BX * BY, TW = 4 * BX, TH = Q * BY;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(BX* BY) void stencil_kernel(const StencilArgs a) {
         __syncthreads();
         if (a.ablate != 2) {
             if (st.sym)  // per channel, wave-uniform
-                stencil_accumulate_sym<Q>(lds_lane, st, row_begin, row_end, e0, acc);
+                stencil_accumulate_sym<Q, true>(lds_lane, st, row_begin, row_end, e0, acc);
             else
                 stencil_accumulate<Q>(lds_lane, st, row_begin, row_end, e0, acc);
         }
@@ -382,9 +384,12 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
     const int plane_sz = rows * RS + 16;  // + slack: the prefetch of the dummy entry reads past the last row
     const int cols_valid = TW + g0.kw - 1;
     const bool mono = a.mono != 0;
+#ifndef R2F_TAIL_EXP
+#define R2F_TAIL_EXP 0  // development switch (tools/ablate_stencil.py): bit 0 no noise generation, 1 no grain stencil, 2 no LUTs
+#endif
     // S6a: hash noise for the tile + halo, straight into LDS.  Coordinates are clamped to the
     // frame like the shader's texture reads (grain.wgsl:63-75); the hash sees GLOBAL coordinates.
-    for (int idx = threadIdx.x; idx < rows * RS; idx += NT) {
+    for (int idx = threadIdx.x; idx < ((R2F_TAIL_EXP & 1) ? 0 : rows * RS); idx += NT) {
         const int r = idx / RS, c = idx - r * RS;
         float nr = 0.f, ng = 0.f, nb = 0.f;
         if (c < cols_valid) {
@@ -409,8 +414,9 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 #pragma unroll
             for (int p = 0; p < 4; ++p) G[c][j][p] = (float2v){0.f, 0.f};
         const float* plane = smem + (mono ? 0 : c * plane_sz);
+        if (R2F_TAIL_EXP & 2) continue;
         if (a.gk[c].sym)
-            stencil_accumulate_sym<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
+            stencil_accumulate_sym<Q, false>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
         else
             stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
     }
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
             r[p] = fmaxf(r[p] + G[0][q / 2][p][q & 1] * curve_eval(a.grain_lut, 0, r[p]), 0.f);
             g[p] = fmaxf(g[p] + G[1][q / 2][p][q & 1] * curve_eval(a.grain_lut, 1, g[p]), 0.f);
             b[p] = fmaxf(b[p] + G[2][q / 2][p][q & 1] * curve_eval(a.grain_lut, 2, b[p]), 0.f);
-            if (!a.to_planes) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
+            if (!a.to_planes && !(R2F_TAIL_EXP & 4)) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
         }
         if (a.to_planes)
             store_planes4(a.dst, gy, gx, a.W, nv, vec, r, g, b);

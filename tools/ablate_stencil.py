@@ -1,5 +1,6 @@
 """Time the halation / MTF stencils with a development build of the library (tools/ablate/lib_expN.so, built with
--DR2F_EXP=N: bit 0 no LDS reads, bit 1 no weight loads, bit 2 no FMAs in the symmetric inner loop).  Results are wrong by
+-DR2F_EXP=N: bit 0 no LDS reads, bit 1 no weight loads, bit 2 no FMAs in the symmetric inner loop; or -DR2F_TAIL_EXP=N:
+bit 0 no noise generation, bit 1 no grain stencil, bit 2 no 3-D LUT in the tail kernel).  Results are wrong by
 construction; only the timings mean anything.   usage: python tools/ablate_stencil.py <path/to/lib.so>"""
 import os
 import sys
@@ -44,4 +45,6 @@ def timeit(fn, iters=5):
 
 th = timeit(lambda: ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H))
 tm = timeit(lambda: ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H))
-print(f"{os.path.basename(_lib.LIB_PATH):>16}: halation {th:7.3f} ms   mtf {tm:7.3f} ms")
+out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+tt = timeit(lambda: ctx.stage_tail(D2, params, out_f32=out, y0=0, y1=H, H_global=H))
+print(f"{os.path.basename(_lib.LIB_PATH):>16}: halation {th:7.3f} ms   mtf {tm:7.3f} ms   tail {tt:7.3f} ms")
