@@ -362,7 +362,8 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         float v[4] = {acc[q / 2][0][q & 1], acc[q / 2][1][q & 1], acc[q / 2][2][q & 1], acc[q / 2][3][q & 1]};
         if (EPI == 1) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) v[p] = log_curve(a.curve, ch, v[p], a.log_eps);
+            for (int p = 0; p < 4; ++p) v[p] = log10_fast(v[p], a.log_eps);
+            curve_eval_batch<4, 1>(a.curve.cells, a.curve, ch, v);
         }
         float* d = dplane + (long long)(gy - a.dst.gy0) * a.W + gx;
         if (a.vec && nv == 4) {
