@@ -178,6 +178,11 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
 int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W,
                       int H_global, void* stream);
 
+/* Introspection for the measurement harness: what the device form of stencil `which` executes.  out: 3 channels x 8 ints
+ * {entries, row steps, LDS phases, mirror-paired (0/1), cropped rows, cropped (padded) columns, rows per lane, 0}.  One entry =
+ * 32 packed FMAs per lane for 16 pixels (x2 taps when mirror-paired). */
+int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
+
 /* Tuning knob for A/B runs: stencil tile variant (0 = auto). */
 int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
 

@@ -115,6 +115,7 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
+    "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -317,6 +317,13 @@ class HipContext:
                                               self._stream()))
         return out
 
+    def stencil_stats(self, which: int):
+        """Per channel: dict(entries, rowsteps, phases, sym, kh, kw, q) of the device form of stencil `which` (bench.py)."""
+        out = (C.c_int * 24)()
+        self._check(self._lib.r2f_stencil_stats(self._h, int(which), out))
+        keys = ("entries", "rowsteps", "phases", "sym", "kh", "kw", "q")
+        return [dict(zip(keys, out[8 * c:8 * c + 7])) for c in range(3)]
+
     def histogram_counts(self, image_u8):
         """Per-channel bin counts of a uint8 (H, W, 3) device image -> int32 (3, 256) device tensor (utils.py:160-165)."""
         torch = self._torch

@@ -310,6 +310,7 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
         build_stream(tap, vkh, vkw, sym, Q, d.RS, TH, mp, sh);
         d.n_phases = sh.n_phases;
         d.n_rowsteps = sh.n_rowsteps;
+        d.n_entries = sh.n_entries;
         d.max_lds_rows = sh.max_lds_rows;
         int rc = upload(ctx, s.wbuf[c], sh.w.data(), sh.w.size() * sizeof(float));
         if (rc) return rc;
@@ -666,6 +667,25 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
     if (!ctx) return R2F_EINVAL;
     if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "stencil: which must be 0..2");
     return run_stencil(ctx, which, src, dst, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
+}
+
+int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
+    if (!ctx || !out) return R2F_EINVAL;
+    if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "stencil: which must be 0..2");
+    StencilSet& set = ctx->stencil[which];
+    if (!set.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
+    if (!set.built_q) {  // not launched yet: build the device form the default launch would use
+        const StencilVariant& sv = kStencilVariants[ctx->opt_variant >= 0 ? ctx->opt_variant : 0];
+        int rc = ensure_stencil(ctx, which, sv.Q, sv.TW(), sv.TH(), (size_t)ctx->opt_lds_kb * 1024, which == 2);
+        if (rc) return rc;
+    }
+    for (int c = 0; c < 3; ++c) {
+        const DevStencil& d = set.dev[c];
+        int* o = out + 8 * c;
+        o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym;
+        o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q, o[7] = 0;
+    }
+    return R2F_OK;
 }
 
 static bool burn_geometry(const r2f_params* p, int H, int W, int* h_lo, int* w_lo) {

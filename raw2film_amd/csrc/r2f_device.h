@@ -56,6 +56,7 @@ struct DevStencil {
                            // + one terminator {., ., n_rowsteps, n_entries}
     int n_phases;
     int n_rowsteps;        // total non-empty row steps
+    int n_entries;         // total entries (without the two dummies)
     int kh, kw;            // cropped taps
     int kw_pad;            // kw rounded up to a multiple of 4
     int ay, ax;            // anchor inside the cropped box

@@ -404,6 +404,11 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
             smem[2 * plane_sz + idx] = nb;
         }
     }
+    // the grain LUT's cells next to the noise planes: 24 gathers per lane hit LDS instead of the vector L1
+    const float4* gcells = a.grain_lut.cells;
+    float4* cells_lds = reinterpret_cast<float4*>(smem + a.cells_off);
+    if (a.cells_in_lds)
+        for (int i = threadIdx.x; i < 3 * (a.grain_lut.m - 1); i += NT) cells_lds[i] = gcells[i];
     __syncthreads();
 
     const int tx = threadIdx.x % kTailBX, ty = threadIdx.x / kTailBX;
@@ -435,9 +440,19 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             // S6c grain.wgsl:78-89 + clip cpu_processor.py:397
-            r[p] = fmaxf(r[p] + G[0][q / 2][p][q & 1] * curve_eval(a.grain_lut, 0, r[p]), 0.f);
-            g[p] = fmaxf(g[p] + G[1][q / 2][p][q & 1] * curve_eval(a.grain_lut, 1, g[p]), 0.f);
-            b[p] = fmaxf(b[p] + G[2][q / 2][p][q & 1] * curve_eval(a.grain_lut, 2, b[p]), 0.f);
+            float ar, ag, ab;
+            if (a.cells_in_lds) {
+                ar = curve_eval_at((const float4*)cells_lds, a.grain_lut, 0, r[p]);
+                ag = curve_eval_at((const float4*)cells_lds, a.grain_lut, 1, g[p]);
+                ab = curve_eval_at((const float4*)cells_lds, a.grain_lut, 2, b[p]);
+            } else {
+                ar = curve_eval(a.grain_lut, 0, r[p]);
+                ag = curve_eval(a.grain_lut, 1, g[p]);
+                ab = curve_eval(a.grain_lut, 2, b[p]);
+            }
+            r[p] = fmaxf(r[p] + G[0][q / 2][p][q & 1] * ar, 0.f);
+            g[p] = fmaxf(g[p] + G[1][q / 2][p][q & 1] * ag, 0.f);
+            b[p] = fmaxf(b[p] + G[2][q / 2][p][q & 1] * ab, 0.f);
             if (!a.to_planes && !(R2F_TAIL_EXP & 4)) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
         }
         if (a.to_planes)
@@ -794,9 +809,13 @@ size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int ncha
     return best;
 }
 
-size_t tail_lds_bytes(const DevStencil* gk, int mono) {
+// noise planes, then (when they fit next to them in half a CU's LDS) the grain LUT's cells
+size_t tail_plane_floats(const DevStencil* gk, int mono) {
     const size_t plane = (size_t)gk[0].RS * (size_t)gk[0].max_lds_rows + 16;
-    return plane * (mono ? 1 : 3) * sizeof(float);
+    return (plane * (mono ? 1 : 3) + 3) / 4 * 4;
+}
+size_t tail_lds_bytes(const DevStencil* gk, int mono, int cells_in_lds, int grain_m) {
+    return tail_plane_floats(gk, mono) * sizeof(float) + (cells_in_lds ? (size_t)3 * (grain_m - 1) * sizeof(float4) : 0);
 }
 
 hipError_t init_kernel_attributes() {
@@ -873,7 +892,10 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     }
     const int TW = 4 * kTailBX, TH = kTailQ * kTailBY;
     dim3 block(kTailBX * kTailBY), grid((a.W + TW - 1) / TW, (a.y1 - a.y0 + TH - 1) / TH);
-    hipLaunchKernelGGL(tail_kernel, grid, block, tail_lds_bytes(a.gk, a.mono), s, a);
+    TailArgs b = a;
+    b.cells_off = (int)tail_plane_floats(a.gk, a.mono);
+    b.cells_in_lds = tail_lds_bytes(a.gk, a.mono, 1, a.grain_lut.m) <= 80 * 1024 ? 1 : 0;  // keep two workgroups per CU
+    hipLaunchKernelGGL(tail_kernel, grid, block, tail_lds_bytes(a.gk, a.mono, b.cells_in_lds, a.grain_lut.m), s, b);
     return hipGetLastError();
 }
 

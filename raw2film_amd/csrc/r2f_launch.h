@@ -84,6 +84,7 @@ struct TailArgs {
     float lut3d_scale;
     int lut3d_mode;
     int vec;
+    int cells_in_lds, cells_off;  // set by the launcher: grain-LUT cells copied to LDS at float offset cells_off
 };
 
 constexpr int kChromaMaxTaps = 63;
@@ -136,7 +137,7 @@ constexpr int kTailBX = 16, kTailBY = 32, kTailQ = 2;  // grain/tail tile 64 x 6
 constexpr size_t kMaxLds = 160 * 1024;
 
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan);
-size_t tail_lds_bytes(const DevStencil* gk, int mono);
+size_t tail_lds_bytes(const DevStencil* gk, int mono, int cells_in_lds = 0, int grain_m = 2);
 
 hipError_t init_kernel_attributes();
 hipError_t launch_front(const FrontArgs& a, hipStream_t s);
