@@ -20,6 +20,7 @@ namespace r2f {
 const StencilVariant kStencilVariants[kNumStencilVariants] = {
     {0, 32, 16, 4},  // 512 threads, tile 128 x 64, 4x4 outputs per lane
     {1, 16, 8, 4},   // 128 threads, tile 64 x 32: fallback for very wide stencils
+    {2, 32, 8, 4},   // 256 threads, tile 128 x 32: never auto-selected first; occupancy experiments (2 waves per SIMD)
 };
 
 // ------------------------------------------------------------------------------ output
@@ -824,6 +825,8 @@ hipError_t init_kernel_attributes() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)kMaxLds);                                                            \
     if (e != hipSuccess) return e;
+    R2F_SET_LDS((stencil_kernel<32, 8, 4, 0>))
+    R2F_SET_LDS((stencil_kernel<32, 8, 4, 1>))
     R2F_SET_LDS((stencil_kernel<32, 16, 4, 0>))
     R2F_SET_LDS((stencil_kernel<32, 16, 4, 1>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
@@ -864,7 +867,9 @@ hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
         case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0>), grid, block, lds, s, a); break;
         case 1: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 1>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 0>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 1>), grid, block, lds, s, a); break;
+        case 3: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 1>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((stencil_kernel<32, 8, 4, 0>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((stencil_kernel<32, 8, 4, 1>), grid, block, lds, s, a); break;
     }
     return hipGetLastError();
 }

@@ -131,7 +131,7 @@ struct StencilVariant {
     int TW() const { return 4 * BX; }
     int TH() const { return Q * BY; }
 };
-constexpr int kNumStencilVariants = 2;
+constexpr int kNumStencilVariants = 3;
 extern const StencilVariant kStencilVariants[kNumStencilVariants];
 constexpr int kTailBX = 16, kTailBY = 32, kTailQ = 2;  // grain/tail tile 64 x 64, 512 threads
 constexpr size_t kMaxLds = 160 * 1024;
