@@ -39,24 +39,51 @@ def _tile(i):
     return float(out[0, 0, 0])
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota if the container has one
+    (an oversubscribed pool of 256 workers on a 32-CPU quota measures the scheduler, not the code)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def time_cpu_baseline(p: st.RenderInputs, tile_hw=(512, 768), target_seconds: float = 15.0, cores: int | None = None,
                       seed: int = 1234) -> dict:
     """Render tiles for about `target_seconds` of wall time; returns the cpu_baseline object of bench.py."""
     if cores is None:
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cores()
     H, W = tile_hw
     ctx = mp.get_context("fork")
     with ctx.Pool(cores, initializer=_init, initargs=(p, tile_hw, seed)) as pool:
         t0 = time.perf_counter()
         pool.map(_tile, range(cores))  # calibration round: one tile per core
         t_round = time.perf_counter() - t0
-        rounds = int(max(1, min(8, round(target_seconds / max(t_round, 1e-3)) - 1)))
+        rounds = int(max(1, min(64, round(target_seconds / max(t_round, 1e-3)) - 1)))
         t0 = time.perf_counter()
         pool.map(_tile, range(cores, cores * (rounds + 1)), chunksize=1)
         dt = time.perf_counter() - t0
     n_tiles = cores * rounds
     mp_done = n_tiles * H * W / 1e6
+    # the same tile on ONE process with the machine otherwise idle (NumPy's element-wise work is single-threaded; SciPy's
+    # FFT pinned to one thread): SURVEY 8d's "(i) single process" figure next to the all-cores one
+    _init(p, tile_hw, seed)
+    t0 = time.perf_counter()
+    _tile(0)
+    t_single = time.perf_counter() - t0
     return {
+        "single_process": {"value": H * W / 1e6 / t_single, "unit": "MP/s", "cores": 1,
+                           "sample": f"one {W}x{H} tile in {t_single:.2f} s"},
         "value": mp_done / dt,
         "unit": "MP/s",
         "cores": cores,
