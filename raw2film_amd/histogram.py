@@ -89,6 +89,17 @@ def histogram_from_counts(counts, mix_table=MIX_TABLE, height: int = 100, numba_
     return render_bars(bar_heights(counts, height, numba_semantics), mix_table, height)
 
 
+def scale_to_canvas(hist, target_h: int, target_w: int) -> np.ndarray:
+    """The GPU path's blit of the bar image onto the widget's canvas (shaders/scale_texture.wgsl:5-29, dispatched at
+    gpu_processor.py:1885): nearest source texel at floor(uv * src_size) with uv = target pixel / target size, float32
+    arithmetic like the shader.  256 x 80 texels -- host work."""
+    hist = np.asarray(hist)
+    sh, sw = hist.shape[:2]
+    ys = ((np.arange(target_h, dtype=np.float32) / np.float32(target_h)) * np.float32(sh)).astype(np.int32)
+    xs = ((np.arange(target_w, dtype=np.float32) / np.float32(target_w)) * np.float32(sw)).astype(np.int32)
+    return hist[np.minimum(ys, sh - 1)[:, None], np.minimum(xs, sw - 1)[None, :]]
+
+
 def generate_histogram(image, mix_table=MIX_TABLE, height: int = 100, *, ctx, numba_semantics: bool = True) -> np.ndarray:
     """``utils.generate_histogram`` for a uint8 (H, W, 3) frame: a device tensor (no copy) or a NumPy array (uploaded).
     ``ctx`` is the HipContext that counts on the device; there is no host counting path."""

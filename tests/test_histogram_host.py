@@ -57,3 +57,17 @@ def test_default_mix_table_shape_and_alpha():
     assert (t[0, 0, 0] == 0).all() and (t.reshape(8, 4)[1:, 3] == 255).all()
     # the three base colours are red-, green- and blue-dominant
     assert t[1, 0, 0, :3].argmax() == 0 and t[0, 1, 0, :3].argmax() == 1 and t[0, 0, 1, :3].argmax() == 2
+
+
+def test_scale_to_canvas_is_the_shaders_nearest_blit():
+    """scale_texture.wgsl: src = vec2<i32>(uv * src_size), uv = id / target_size."""
+    hist = np.arange(80 * 256 * 4, dtype=np.uint32).reshape(80, 256, 4)
+    for th, tw in ((80, 256), (160, 512), (57, 301), (200, 100), (1, 1)):
+        got = ph.scale_to_canvas(hist, th, tw)
+        assert got.shape == (th, tw, 4)
+        for y in (0, th // 3, th - 1):
+            for x in (0, tw // 2, tw - 1):
+                sy = int(np.float32(np.float32(y) / np.float32(th)) * np.float32(80))
+                sx = int(np.float32(np.float32(x) / np.float32(tw)) * np.float32(256))
+                assert np.array_equal(got[y, x], hist[sy, sx])
+    assert np.array_equal(ph.scale_to_canvas(hist, 80, 256), hist)
