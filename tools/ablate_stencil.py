@@ -1,9 +1,27 @@
 """Time the halation / MTF stencils with a development build of the library (tools/ablate/lib_expN.so, built with
 -DR2F_EXP=N: bit 0 no LDS reads, bit 1 no weight loads, bit 2 no FMAs in the symmetric inner loop; or -DR2F_TAIL_EXP=N:
 bit 0 no noise generation, bit 1 no grain stencil, bit 2 no 3-D LUT in the tail kernel).  Results are wrong by
-construction; only the timings mean anything.   usage: python tools/ablate_stencil.py <path/to/lib.so>"""
+construction; only the timings mean anything.
+
+    python tools/ablate_stencil.py --build          # here (hipcc): builds tools/ablate/lib_exp{1,2,3,4}.so, lib_tail{1,2,4,7}.so
+    python tools/ablate_stencil.py <path/to/lib.so>  # on the GPU box (the .so files travel with gpurun)
+"""
 import os
 import sys
+
+if "--build" in sys.argv:
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "tools", "ablate"), exist_ok=True)
+    src = [os.path.join(root, "raw2film_amd", "csrc", f) for f in ("r2f_kernels.hip", "r2f_api.hip")]
+    for macro, values, stem in (("R2F_EXP", (1, 2, 3, 4), "lib_exp"), ("R2F_TAIL_EXP", (1, 2, 4, 7), "lib_tail")):
+        for n in values:
+            out = os.path.join(root, "tools", "ablate", f"{stem}{n}.so")
+            subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", f"-D{macro}={n}", "-o", out] + src,
+                           check=True)
+            print(out)
+    sys.exit(0)
 
 import torch
 
