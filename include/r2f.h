@@ -164,6 +164,14 @@ int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, c
 int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const double* m_dst_to_src, const r2f_planes* dst,
                     int out_h, int out_w, int oy, int ox, void* stream);
 
+/* Post-path up-scale of the rendered uint8 frame: utils.resolution_scaling's cv.resize(image, dsize,
+ * interpolation=cv.INTER_LANCZOS4) branch (utils.py:237-242), the way back from the `max_scale` pipeline resolution to the
+ * requested one (cpu_processor.py:128-134, 411-412).  src/dst: uint8 (H, W, 3) / (out_h, out_w, 3) on the device.
+ * r2f_lanczos4_table is the host-side table cv::resize derives per destination index (source index of tap 3, eight weights
+ * in 11-bit fixed point); exported so the tests can pin it without a GPU. */
+int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
+int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef);
+
 /* Caller-side RGB histogram of the rendered bitmap: the counting loop of utils.generate_histogram (utils.py:160-165; GPU twin
  * histogram.wgsl pass1_accumulate, dispatched at gpu_processor.py:1149).  image_hwc: uint8 (H, W, 3) on the device, 16-byte
  * aligned; counts: 3 x 256 uint32 on the device (R bins, G bins, B bins), overwritten.  The 768-value post-processing

@@ -616,3 +616,67 @@ def rotate(img, degrees):
         w, h = h, w
     ch, cw = int((H - h) // 2), int((W - w) // 2)  # :68-69
     return out[ch:H - ch, cw:W - cw]
+
+
+# ---------------------------------------------------------------------------------------------- LANCZOS4 up-scale (post-path)
+# utils.resolution_scaling (utils.py:237-242) -> cv.resize(uint8 image, dsize, interpolation=cv.INTER_LANCZOS4): the way back
+# from the `max_scale` pipeline resolution to the requested one (cpu_processor.py:128-134, 411-412).  PARITY UNPINNED: OpenCV
+# is not installed here; this restates the generic C++ path of opencv/modules/imgproc/src/resize.cpp for CV_8U (8-tap separable
+# filter, coefficients rounded to 11-bit fixed point, exact integer accumulation, one rounding at the end, replicated border).
+def lanczos4_coeffs(x):
+    """interpolateLanczos4(float x, float* coeffs): the C++ mixes float and double exactly like this."""
+    x = np.float32(x)
+    s45 = 0.70710678118654752440084436210485
+    cs = ((1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45))
+    y0 = -float(np.float32(x + np.float32(3))) * math.pi * 0.25
+    s0, c0 = math.sin(y0), math.cos(y0)
+    coeffs = np.zeros(8, dtype=np.float32)
+    total = np.float32(0)
+    for i in range(8):
+        y0_ = np.float32(np.float32(x + np.float32(3)) - np.float32(i))
+        if abs(y0_) >= np.float32(1e-6):
+            y = -float(y0_) * math.pi * 0.25
+            coeffs[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
+        else:
+            coeffs[i] = np.float32(1e30)
+        total = np.float32(total + coeffs[i])
+    inv = np.float32(np.float32(1) / total)
+    return (coeffs * inv).astype(np.float32)
+
+
+def lanczos4_table(ssize: int, dsize: int):
+    """Per destination index: source index of tap 3 (floor of the source coordinate) and the 8 fixed-point weights."""
+    scale = 1.0 / (float(dsize) / float(ssize))  # scale_x = 1. / inv_scale_x
+    ofs = np.zeros(dsize, dtype=np.int32)
+    coef = np.zeros((dsize, 8), dtype=np.int16)
+    for d in range(dsize):
+        fx = np.float32((d + 0.5) * scale - 0.5)
+        sx = int(math.floor(float(fx)))
+        fx = np.float32(fx - np.float32(sx))
+        ofs[d] = sx
+        c = lanczos4_coeffs(fx) * np.float32(2048)  # INTER_RESIZE_COEF_SCALE
+        coef[d] = np.clip(np.rint(c), -32768, 32767).astype(np.int16)  # saturate_cast<short>: round half to even
+    return ofs, coef
+
+
+def resize_lanczos4_u8(img, out_h: int, out_w: int):
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3
+    H, W = img.shape[:2]
+    xo, xa = lanczos4_table(W, out_w)
+    yo, ya = lanczos4_table(H, out_h)
+    src = img.astype(np.int64)
+    cols = np.clip(xo[:, None] - 3 + np.arange(8)[None, :], 0, W - 1)  # (out_w, 8), replicated border
+    hor = np.einsum("hwkc,wk->hwc", src[:, cols, :], xa.astype(np.int64))  # (H, out_w, C) exact integers
+    rows = np.clip(yo[:, None] - 3 + np.arange(8)[None, :], 0, H - 1)
+    ver = np.einsum("hkwc,hk->hwc", hor[rows], ya.astype(np.int64))
+    return np.clip((ver + (1 << 21)) >> 22, 0, 255).astype(np.uint8)  # FixedPtCast<int, uchar, 22>
+
+
+def resolution_scaling_u8_up(img, resolution):
+    """utils.resolution_scaling's up-scaling branch (utils.py:226-244) on the rendered uint8 frame."""
+    h, w = img.shape[:2]
+    f = min(resolution[0] / h, resolution[1] / w)
+    if f > 1:
+        return resize_lanczos4_u8(img, round(h * f), round(w * f))
+    return img

@@ -115,6 +115,8 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
+    "r2f_resize_lanczos4_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "r2f_lanczos4_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -317,6 +317,17 @@ class HipContext:
                                               self._stream()))
         return out
 
+    def resize_lanczos4_u8(self, image_u8, out_h: int, out_w: int):
+        """cv.resize(uint8 (H, W, 3), (out_w, out_h), interpolation=cv.INTER_LANCZOS4) on the device."""
+        torch = self._torch
+        if not (image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.is_contiguous() and image_u8.dim() == 3
+                and image_u8.shape[2] == 3):
+            raise ValueError("resize_lanczos4_u8 needs a contiguous uint8 (H, W, 3) CUDA tensor")
+        out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.r2f_resize_lanczos4_u8(self._h, image_u8.data_ptr(), int(image_u8.shape[0]), int(image_u8.shape[1]),
+                                                     out.data_ptr(), int(out_h), int(out_w), self._stream()))
+        return out
+
     def stencil_stats(self, which: int):
         """Per channel: dict(entries, rowsteps, phases, sym, kh, kw, q) of the device form of stencil `which` (bench.py)."""
         out = (C.c_int * 24)()

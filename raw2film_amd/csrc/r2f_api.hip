@@ -60,6 +60,8 @@ struct r2f_ctx {
         DeviceBuf buf;
     } tile_order[4];
     int tile_order_next = 0;
+    DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
+    int lanczos_key[4] = {0, 0, 0, 0};
     int opt_xcd_band = 0;  // tile columns per band of the xcd_remap = 2 order; 0 = auto
     int opt_variant = -1;  // -1 auto
     int opt_xcd_remap = 2;  // 0 = launch order, 1 = one contiguous row-major run of tiles per XCD, 2 = that run walked in column bands
@@ -498,6 +500,7 @@ void r2f_destroy(r2f_ctx* ctx) {
             s.mbuf[c].release();
         }
     for (auto& t : ctx->tile_order) t.buf.release();
+    ctx->lanczos_buf.release();
     delete ctx;
 }
 
@@ -864,6 +867,77 @@ int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, c
     a.ox = ox;
     for (int i = 0; i < 6; ++i) a.m[i] = (float)m_dst_to_src[i];
     R2F_HIP(ctx, launch_warp_affine(a, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+// cv::interpolateLanczos4 (imgproc/src/resize.cpp), float / double mixed exactly as there.
+static void lanczos4_coeffs(float x, float* coeffs) {
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    const double kPi = 3.1415926535897932384626433832795;
+    float sum = 0;
+    const double y0 = -(x + 3) * kPi * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const float y0_ = (x + 3 - i);
+        if (std::fabs(y0_) >= 1e-6f) {
+            const double y = -y0_ * kPi * 0.25;
+            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        } else {
+            coeffs[i] = 1e30f;  // x ~ 0 or ~ 1: this tap takes everything after the normalisation
+        }
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+// cv::resize's per-destination tables for INTER_LANCZOS4 on CV_8U: source index of tap 3 and eight weights in 11-bit fixed
+// point (saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE), round half to even).
+int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef) {
+    if (ssize <= 0 || dsize <= 0 || !ofs || !coef) return R2F_EINVAL;
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        const int sx = (int)std::floor(fx);
+        fx -= sx;
+        ofs[d] = sx;
+        float cbuf[8];
+        lanczos4_coeffs(fx, cbuf);
+        for (int k = 0; k < 8; ++k) {
+            const long v = std::lrintf(cbuf[k] * 2048);
+            coef[d * 8 + k] = (short)std::min<long>(std::max<long>(v, -32768), 32767);
+        }
+    }
+    return R2F_OK;
+}
+
+int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    if (!src_hwc || !dst_hwc || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
+        return fail(ctx, R2F_EINVAL, "resize_lanczos4: bad arguments");
+    const size_t n_ofs = (size_t)out_w + out_h, n_coef = 8 * n_ofs;
+    const size_t coef_off = (n_ofs * sizeof(int) + 15) / 16 * 16;
+    const int key[4] = {H, W, out_h, out_w};
+    if (memcmp(key, ctx->lanczos_key, sizeof key) != 0 || !ctx->lanczos_buf.p) {
+        std::vector<unsigned char> host(coef_off + n_coef * sizeof(short));
+        int* ofs = reinterpret_cast<int*>(host.data());
+        short* coef = reinterpret_cast<short*>(host.data() + coef_off);
+        r2f_lanczos4_table(W, out_w, ofs, coef);
+        r2f_lanczos4_table(H, out_h, ofs + out_w, coef + 8 * (size_t)out_w);
+        int rc = upload(ctx, ctx->lanczos_buf, host.data(), host.size());
+        if (rc) return rc;
+        memcpy(ctx->lanczos_key, key, sizeof key);
+    }
+    LanczosArgs a;
+    a.src = src_hwc;
+    a.dst = dst_hwc;
+    a.H = H, a.W = W, a.out_h = out_h, a.out_w = out_w;
+    const unsigned char* base = static_cast<const unsigned char*>(ctx->lanczos_buf.p);
+    a.xofs = reinterpret_cast<const int*>(base);
+    a.yofs = a.xofs + out_w;
+    a.xcoef = reinterpret_cast<const short*>(base + coef_off);
+    a.ycoef = a.xcoef + 8 * (size_t)out_w;
+    R2F_HIP(ctx, launch_lanczos4_u8(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
 

@@ -9,6 +9,7 @@
 //   chroma_h/_v       pre-path chroma NR: xyY + separable Gaussian on the chromaticity planes  HBM-bound
 //   resize_area       pre-path INTER_AREA down-scale to the preview resolution
 //   warp_affine       pre-path free rotation (cv.warpAffine, INTER_LINEAR, zero border)
+//   lanczos4_u8       post-path up-scale of the uint8 result (cv.resize INTER_LANCZOS4): the way back from max_scale
 //   noise_kernel      S6a test entry (hash + Gaussian field)
 //   histogram_u8      caller-side RGB histogram counts of the uint8 output (utils.generate_histogram, histogram.wgsl pass 1)
 #include "r2f_launch.h"
@@ -731,6 +732,38 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const WarpArgs a) {
     p0[2 * a.dst.plane_stride] = v[2];
 }
 
+// ------------------------------------------------------------------------------ LANCZOS4 up-scale (post-path)
+// utils.resolution_scaling -> cv.resize(uint8, INTER_LANCZOS4) (utils.py:237-242): 8 x 8 taps per output pixel with the
+// 11-bit fixed-point weights OpenCV derives per destination column / row (built on the host, r2f_api.hip), exact int32
+// accumulation, one rounding (+2^21 >> 22), replicated border.  One lane per output pixel, all three channels.
+__global__ __launch_bounds__(256) void lanczos4_u8_kernel(const LanczosArgs a) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= a.out_w || dy >= a.out_h) return;
+    const int sx = a.xofs[dx] - 3, sy = a.yofs[dy] - 3;
+    int wx[8], wy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wx[k] = a.xcoef[dx * 8 + k], wy[k] = a.ycoef[dy * 8 + k];
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint8_t* row = a.src + (long long)clampi(sy + k, 0, a.H - 1) * a.W * 3;
+        int h[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint8_t* p = row + clampi(sx + j, 0, a.W - 1) * 3;
+            h[0] += (int)p[0] * wx[j];
+            h[1] += (int)p[1] * wx[j];
+            h[2] += (int)p[2] * wx[j];
+        }
+        acc[0] += h[0] * wy[k];
+        acc[1] += h[1] * wy[k];
+        acc[2] += h[2] * wy[k];
+    }
+    uint8_t* o = a.dst + ((long long)dy * a.out_w + dx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)clampi((acc[c] + (1 << 21)) >> 22, 0, 255);
+}
+
 // ------------------------------------------------------------------------------ noise (test)
 __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -937,6 +970,12 @@ hipError_t launch_resize_area(const ResizeArgs& a, hipStream_t s) {
 hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s) {
     if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
     hipLaunchKernelGGL(warp_affine_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lanczos4_u8(const LanczosArgs& a, hipStream_t s) {
+    if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lanczos4_u8_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 

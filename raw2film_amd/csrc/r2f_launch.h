@@ -116,6 +116,17 @@ struct WarpArgs {
     float m[6];  // dst -> src, row-major 2 x 3, rounded from double like OpenCV's float kernels
 };
 
+// Post-path up-scale of the uint8 result: cv.resize(..., INTER_LANCZOS4) with host-built fixed-point tables.
+struct LanczosArgs {
+    const uint8_t* src;  // (H, W, 3)
+    uint8_t* dst;        // (out_h, out_w, 3)
+    int H, W, out_h, out_w;
+    const int* xofs;     // out_w: source column of tap 3
+    const short* xcoef;  // out_w x 8
+    const int* yofs;     // out_h
+    const short* ycoef;  // out_h x 8
+};
+
 struct NoiseArgs {
     uint32_t* hash;
     float* noise;
@@ -144,6 +155,7 @@ hipError_t launch_front(const FrontArgs& a, hipStream_t s);
 hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s);
 hipError_t launch_tail(const TailArgs& a, hipStream_t s);
 hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s);
+hipError_t launch_lanczos4_u8(const LanczosArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.

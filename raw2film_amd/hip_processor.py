@@ -176,21 +176,32 @@ class HipProcessor:
             # aspect crop / zoom / quarter turns: index arithmetic of raw_conversion.crop_rotate_zoom (raw_conversion.py:56-72)
             image = geometry.crop_to_frame(image, frame_width, frame_height, zoom, rotate_times, flip)
             h, w = image.shape[:2]
-        if max_scale is not None and max(h, w) / max(frame_width, frame_height) > max_scale and resolution is None:
-            raise NotImplementedError(
-                f"frame is finer than max_scale={max_scale} px/mm; the reference down-scales before and LANCZOS4-up-scales "
-                "after the path (cpu_processor.py:128-134, 411-412), which is outside the accelerated path"
-            )
-        resize_to = None
-        if resolution is not None:  # preview: utils.resolution_scaling (utils.py:226-244), applied on the device in phase 2
-            if max_scale is not None and max(resolution) / max(frame_width, frame_height) > max_scale:
-                raise NotImplementedError("max_scale clamping of the preview resolution is outside the accelerated path")
+        # cpu_processor.py:119-134: without a preview resolution the frame's own size is the target; a target finer than
+        # `max_scale` px/mm is rendered at max_scale and scaled back up at the very end (cpu_processor.py:411-412)
+        if resolution is None and max_scale is not None:
+            resolution = (h, w)
+        resize_to, upscale_to = None, None
+        if resolution is not None:
+            resolution = (int(resolution[0]), int(resolution[1]))
+            scale = max(resolution) / max(frame_width, frame_height)
+            if max_scale is not None and scale > max_scale:
+                upscale_to = resolution
+                resolution = tuple(round(x * (max_scale / scale)) for x in resolution)
+            # utils.resolution_scaling (utils.py:226-244), applied on the device in phase 2
             factor = min(resolution[0] / h, resolution[1] / w)
             if factor > 1:
-                raise NotImplementedError("up-scaling (cv.INTER_LANCZOS4, utils.py:237-242) is outside the accelerated path")
+                raise NotImplementedError("up-scaling the float frame before the path (cv.INTER_LANCZOS4 on float32, "
+                                          "utils.py:237-242: a preview larger than the frame) is outside the accelerated path")
             if factor < 1:
                 resize_to = (round(h * factor), round(w * factor))  # cv.resize(dsize=(round(w f), round(h f)), INTER_AREA)
                 h, w = resize_to
+        out_h, out_w = h, w
+        if upscale_to is not None:  # the uint8 result goes back up with LANCZOS4, same rule (fit inside the target)
+            f = min(upscale_to[0] / h, upscale_to[1] / w)
+            if f > 1:
+                out_h, out_w = round(h * f), round(w * f)
+            else:
+                upscale_to = None
         canvas_res = None
         if canvas_mode != "No":  # gpu_processor.py:767-771
             res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
@@ -200,13 +211,14 @@ class HipProcessor:
         image = np.ascontiguousarray(image, dtype=np.float32)
         return {
             "image_array": image,
-            "output_resolution": (w, h),
+            "output_resolution": (out_w, out_h),
             "canvas_resolution": canvas_res,
             "pipeline_resolution": (w, h),
             # upstream filters on the host here (gpu_processor.py:750-751); this backend filters on the device in phase 2
             "chroma_nr": int(chroma_nr),
             "resize_to": resize_to,  # (rows, cols) of the INTER_AREA down-scale still to be applied, or None
             "warp": warp,  # free rotation still to be applied (first of the device pre-path steps), or None
+            "upscale_to": upscale_to,  # (rows, cols) the rendered uint8 frame is LANCZOS4-scaled back into, or None
         }
 
     @staticmethod
@@ -284,6 +296,11 @@ class HipProcessor:
         # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic
         out_u8 = geometry.add_canvas(out_u8, settings.get("canvas_mode", "No"), settings.get("canvas_scale", 1.0),
                                      settings.get("canvas_ratio", 1.0))
+        up = cpu_payload.get("upscale_to")
+        if up:  # cpu_processor.py:411-412 -> utils.resolution_scaling -> cv.resize(INTER_LANCZOS4) on the uint8 frame
+            f = min(up[0] / out_u8.shape[0], up[1] / out_u8.shape[1])
+            if f > 1:
+                out_u8 = self.ctx.resize_lanczos4_u8(out_u8.contiguous(), round(out_u8.shape[0] * f), round(out_u8.shape[1] * f))
         self.last_output = out_u8
         return out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
 

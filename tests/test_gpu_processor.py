@@ -133,6 +133,37 @@ def test_warp_affine_matches_oracle_on_every_layout(proc):
             assert np.array_equal(gotw, got[win[0]:win[0] + win[2], win[1]:win[1] + win[3]])
 
 
+@pytest.mark.parametrize("shape,out", [((20, 30), (50, 75)), ((97, 131), (200, 270)), ((5, 7), (64, 90)), ((40, 60), (41, 61)),
+                                       ((64, 96), (64, 96))])
+def test_lanczos4_upscale_bit_exact(proc, shape, out):
+    img = np.random.default_rng(shape[0]).integers(0, 256, shape + (3,)).astype(np.uint8)
+    got = proc.ctx.resize_lanczos4_u8(torch.from_numpy(img).cuda(), *out).cpu().numpy()
+    assert np.array_equal(got, st.resize_lanczos4_u8(img, *out))
+
+
+def test_max_scale_round_trip_through_the_processor(proc):
+    """A small-gauge frame (finer than max_scale px/mm): INTER_AREA down to max_scale, the path, LANCZOS4 back up."""
+    from raw2film_amd import geometry
+
+    neg, prt, _ = stocks()
+    img = _xyz(160, 240, seed=46)
+    kw = dict(print_film=prt, halation=True, sharpness=True, grain=0, exp_kelvin=6000, color_masking=1.0,
+              frame_width=5.79, frame_height=3.86, max_scale=20.0)
+    out = proc.process(img, neg, 6, 0.4, **kw)
+    pre = geometry.crop_to_frame(img, 5.79, 3.86, 1.0, 0, False)
+    h, w = pre.shape[:2]
+    f = 20.0 / (max(h, w) / 5.79)
+    res = [round(h * f), round(w * f)]
+    g = min(res[0] / h, res[1] / w)
+    small = np.stack([st.resize_area(np.ascontiguousarray(pre[..., c]), round(h * g), round(w * g)) for c in range(3)], axis=-1)
+    p = oracle_inputs(neg, prt, max(small.shape[:2]) / 5.79, halation=True, mtf=True, grain=0, matrix=False,
+                      halation_green_factor=0.4)  # process()'s default (cpu_processor.py:306), not the GUI's 0.3
+    ref = st.resolution_scaling_u8_up(st.to_uint8(st.render(small, p)), (h, w))
+    assert out.shape == ref.shape and out.shape[0] > small.shape[0]
+    d = np.abs(out.astype(int) - ref.astype(int))
+    assert d.max() <= 3 and (d > 0).mean() <= 5e-3  # a 1-LSB truncation flip before the filter spreads over 8 x 8 taps
+
+
 def test_uploads_happen_only_on_change(proc):
     neg, prt, _ = stocks()
     img = _xyz(48, 64, seed=45)

@@ -124,9 +124,7 @@ def test_out_of_scope_requests_raise(proc):
     with pytest.raises(NotImplementedError):
         proc.process("photo.cr3", neg, 6, 0.4)
     with pytest.raises(NotImplementedError):
-        proc.extract_image_data_cpu(img, frame_width=0.1, frame_height=0.07)  # finer than max_scale
-    with pytest.raises(NotImplementedError):
-        proc.extract_image_data_cpu(img, resolution=(80, 120))  # up-scaling needs LANCZOS4
+        proc.extract_image_data_cpu(img, resolution=(80, 120))  # a preview larger than the frame: float32 LANCZOS4 before the path
     with pytest.raises(NotImplementedError):
         proc.process(img, neg, 6, 0.4, dst_texture=object())
 
@@ -161,6 +159,27 @@ def test_free_rotation_is_deferred_to_the_device_with_the_reference_window(proc)
         direct = st.warp_affine_linear(img[r0:r0 + nr, c0:c0 + nc], w["m_dst_to_src"], w["window"][2:], w["window"][:2])
         assert np.array_equal(np.rot90(direct, k), ref)
     assert proc.extract_image_data_cpu(img)["warp"] is None
+
+
+def test_max_scale_round_trip_is_planned_like_the_cpu_processor(proc):
+    """cpu_processor.py:119-134 + 411-412: a frame finer than max_scale px/mm is rendered at max_scale and scaled back."""
+    img = np.zeros((400, 600, 3), np.float32)
+    # super-8 gate: 600 px over 5.79 mm = 103.6 px/mm; with max_scale 40 the pipeline runs at 40 px/mm
+    p = proc.extract_image_data_cpu(img, frame_width=5.79, frame_height=3.86, max_scale=40.0)
+    f = 40.0 / (600 / 5.79)
+    # the clamped target is (154, 232); utils.resolution_scaling then fits the frame INSIDE it with one factor (the smaller)
+    assert (round(400 * f), round(600 * f)) == (154, 232)
+    assert p["resize_to"] == (154, 231) and p["pipeline_resolution"] == (231, 154)
+    assert p["upscale_to"] == (400, 600)
+    g = min(400 / 154, 600 / 231)
+    assert p["output_resolution"] == (round(231 * g), round(154 * g)) == (600, 400)
+    # below the limit nothing happens; max_scale=None switches the clamp off
+    q = proc.extract_image_data_cpu(img, frame_width=36, frame_height=24, max_scale=40.0)
+    assert q["resize_to"] is None and q["upscale_to"] is None and q["output_resolution"] == (600, 400)
+    assert proc.extract_image_data_cpu(img, frame_width=5.79, frame_height=3.86, max_scale=None)["upscale_to"] is None
+    # a preview resolution above the limit is clamped too, and restored at the end
+    r = proc.extract_image_data_cpu(img, frame_width=5.79, frame_height=3.86, max_scale=40.0, resolution=(200, 300))
+    assert r["upscale_to"] == (200, 300) and r["resize_to"] == (154, 231)
 
 
 def test_preview_resolution_becomes_an_area_downscale(proc):
