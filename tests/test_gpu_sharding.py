@@ -107,3 +107,38 @@ def test_timed_backend_reports_every_stage():
     assert set(ms) == {"front", "halation", "mtf", "grain", "burn_sums", "burn_map", "tail"}
     assert all(v > 0 for v in ms.values())
     proc.close()
+
+
+def test_batch_export_through_the_two_phase_api():
+    """Config 5's shape in small: frames dealt to ranks, host phase one frame ahead on a producer thread, a frame whose host
+    phase fails is skipped (gui_objects.py:65-115) -- here with the real HipProcessor on one rank."""
+    from raw2film_amd import HipProcessor, filmstock
+    from raw2film_amd.sharding import BatchSharder
+
+    stocks_ = filmstock.builtin_stocks()
+    neg, prt = stocks_["Kodak Portra 400"], stocks_["Kodak 2383"]
+    proc = HipProcessor(device=0)
+    try:
+        frames = [synthetic_frame(96 + 8 * i, 144 + 12 * i, seed=60 + i) for i in range(5)]
+        tasks = [dict(src=f, seed=100 + i) for i, f in enumerate(frames)]
+        tasks.insert(2, dict(src="missing_frame.cr3", seed=0))  # RAW decoding is not ours: the host phase raises, the frame is skipped
+        kw = dict(print_film=prt, exp_kelvin=6000, color_masking=1.0, chroma_nr=1)
+
+        def prepare(t):
+            return proc.extract_image_data_cpu(t["src"], **kw)
+
+        def execute(t, payload):
+            return proc.process_preloaded(payload, neg, 6, 0.4, seed=t["seed"], **kw)
+
+        results, skipped = BatchSharder(0, 1).run(tasks, prepare, execute)
+        assert skipped == [2] and sorted(results) == [0, 1, 3, 4, 5]
+        for idx, out in results.items():
+            t = tasks[idx]
+            direct = proc.process(t["src"], neg, 6, 0.4, seed=t["seed"], **kw)
+            assert out.dtype == np.uint8 and np.array_equal(out, direct)
+        # two ranks split the same list without overlap
+        mine0 = [i for i, _ in BatchSharder(0, 2).my_tasks(tasks)]
+        mine1 = [i for i, _ in BatchSharder(1, 2).my_tasks(tasks)]
+        assert sorted(mine0 + mine1) == list(range(6)) and not set(mine0) & set(mine1)
+    finally:
+        proc.close()
