@@ -84,3 +84,34 @@ def test_a_constant_100mp_frame_stays_constant(full):
     lo, hi = res.amin(dim=(0, 1)).cpu().numpy(), res.amax(dim=(0, 1)).cpu().numpy()
     assert np.all(hi - lo <= 2e-6), (lo, hi)
     np.testing.assert_allclose(lo, expect, rtol=0, atol=3e-6)
+
+
+def test_bw_stock_with_unsharp_mask_and_mono_grain_at_full_size():
+    """The other branches at 100 MP: halation on all three layers (bw stock: no identity plane), MTF with the unsharp-mask
+    term (negative taps), monochrome grain."""
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame_device
+    from test_gpu_parity import setup_ctx
+
+    _, prt, bw = stocks()
+    p = oracle_inputs(bw, None, SCALE, seed=SEED + 1, grain=1, sharpening_strength=0.6, halation_green_factor=0.4)
+    ctx = HipContext(0)
+    try:
+        params = setup_ctx(ctx, p)
+        frame = synthetic_frame_device(H_FULL, W_FULL, seed=9)
+        out, _ = ctx.render(frame, params)
+        n, y0, x0 = 64, 5000, 9000
+        halo = 42 + 17 + 4
+        ya, yb, xa, xb = y0 - halo, y0 + n + halo, x0 - halo, x0 + n + halo
+        crop = frame[ya:yb, xa:xb].cpu().numpy()
+        x = st.apply_2d_lut(st.apply_matrix3x3(crop, p.matrix), p.lut_2d)
+        x = st.halation(x, p.halation_kernel)
+        x = st.multi_channel_interp(st.log_clip(x), p.lut_1d)
+        x = st.film_sharpness(x, p.mtf_kernel)
+        x = st.apply_grain(x, p.grain_lut, p.grain_kernel, p.seed, True, row0=ya, H_global=H_FULL, col0=xa, W_global=W_FULL)
+        ref = st.apply_lut_tetrahedral(x, p.lut_3d, 0.25)[halo:halo + n, halo:halo + n]
+        got = out[y0:y0 + n, x0:x0 + n].cpu().numpy()
+        err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 0.1))
+        assert err <= 1e-5, err
+    finally:
+        ctx.close()
