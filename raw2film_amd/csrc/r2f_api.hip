@@ -60,6 +60,12 @@ struct r2f_ctx {
         DeviceBuf buf;
     } tile_order[4];
     int tile_order_next = 0;
+    // FFT form of large stencils (r2f_fft.hip): twiddles, per stencil and channel the kernel spectrum, pass scratch
+    DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_s2, fft_kimg;
+    bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
+    int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
+    int opt_fft_min_taps = 2000;  // ... "large enough": cropped box of at least this many taps (and at most 129 x 129)
+    int opt_fft_batch = 1024;    // window pairs per batch (2 MB of scratch each)
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     int lanczos_key[4] = {0, 0, 0, 0};
     int opt_xcd_band = 0;  // tile columns per band of the xcd_remap = 2 order; 0 = auto
@@ -407,6 +413,110 @@ int ensure_tile_order(r2f_ctx* ctx, int gx, int gy, const int** out) {
     return R2F_OK;
 }
 
+int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
+    if (buf.bytes >= bytes) return R2F_OK;
+    R2F_HIP(ctx, hipDeviceSynchronize());
+    buf.release();
+    R2F_HIP(ctx, hipMalloc(&buf.p, bytes));
+    buf.bytes = bytes;
+    return R2F_OK;
+}
+
+// Bounding box of channel c's non-zero taps: {i_lo, i_hi, j_lo, j_hi}; an all-zero plane keeps its centre tap.
+void tap_box(const StencilSet& s, int c, int box[4]) {
+    const int kc = s.kc == 1 ? 0 : c;
+    int i_lo = s.kh, i_hi = -1, j_lo = s.kw, j_hi = -1;
+    for (int i = 0; i < s.kh; ++i)
+        for (int j = 0; j < s.kw; ++j)
+            if (s.host[((size_t)i * s.kw + j) * s.kc + kc] != 0.f) {
+                i_lo = std::min(i_lo, i), i_hi = std::max(i_hi, i);
+                j_lo = std::min(j_lo, j), j_hi = std::max(j_hi, j);
+            }
+    if (i_hi < 0) i_lo = i_hi = s.kh / 2, j_lo = j_hi = s.kw / 2;
+    box[0] = i_lo, box[1] = i_hi, box[2] = j_lo, box[3] = j_hi;
+}
+
+// Does channel c of stencil `which` take the overlap-save FFT form?
+bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
+    if (!ctx->opt_fft) return false;
+    int b[4];
+    tap_box(s, c, b);
+    const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
+    return bh <= kFftN / 2 + 1 && bw <= kFftN / 2 + 1 && bh * bw >= ctx->opt_fft_min_taps;
+}
+
+// One channel of a stencil as an fp64 overlap-save FFT correlation (r2f_fft.hip).
+int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
+                    int epilogue, float log_eps, hipStream_t s) {
+    StencilSet& set = ctx->stencil[which];
+    int b[4];
+    tap_box(set, c, b);
+    const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
+    const size_t img = (size_t)kFftN * kFftN;
+    if (!ctx->fft_tw.p) {
+        std::vector<double> tw(2 * kFftN);
+        for (int k = 0; k < kFftN; ++k) {
+            const double ang = -2.0 * 3.14159265358979323846264338327950288 * k / kFftN;
+            tw[2 * k] = std::cos(ang), tw[2 * k + 1] = std::sin(ang);
+        }
+        int rc = upload(ctx, ctx->fft_tw, tw.data(), tw.size() * sizeof(double));
+        if (rc) return rc;
+    }
+    FftConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.tw = static_cast<const double2*>(ctx->fft_tw.p);
+    a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
+    a.ax = set.kw / 2 - b[2];
+    a.vy = kFftN - bh + 1;
+    a.vx = kFftN - bw + 1;
+    int rc = ensure_bytes(ctx, ctx->fft_s1, img * sizeof(double2));
+    if (rc) return rc;
+    if (!ctx->fft_kf_valid[which][c]) {  // the kernel's spectrum: the same two forward passes on its zero-padded image
+        std::vector<float> kimg(img, 0.f);
+        const int kc = set.kc == 1 ? 0 : c;
+        for (int i = 0; i < bh; ++i)
+            for (int j = 0; j < bw; ++j) kimg[(size_t)i * kFftN + j] = set.host[((size_t)(b[0] + i) * set.kw + b[2] + j) * set.kc + kc];
+        rc = upload(ctx, ctx->fft_kimg, kimg.data(), img * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_bytes(ctx, ctx->fft_kf[which][c], img * sizeof(double2));
+        if (rc) return rc;
+        FftConvArgs k = a;
+        k.src.data = static_cast<float*>(ctx->fft_kimg.p);
+        k.raw = 1;
+        k.ntiles = 1, k.gx = 1, k.npairs = 1, k.pair0 = 0;
+        k.s1 = static_cast<double2*>(ctx->fft_s1.p);
+        k.kf_out = static_cast<double2*>(ctx->fft_kf[which][c].p);
+        R2F_HIP(ctx, launch_fft_rows_fwd(k, s));
+        R2F_HIP(ctx, launch_fft_cols(k, 1, s));
+        ctx->fft_kf_valid[which][c] = true;
+    }
+    a.src = to_dev(src);
+    a.dst = to_dev(dst);
+    a.ch = c;
+    a.y0 = y0, a.y1 = y1, a.W = W, a.H_global = H;
+    a.gx = (W + a.vx - 1) / a.vx;
+    a.ntiles = a.gx * ((y1 - y0 + a.vy - 1) / a.vy);
+    a.kf = static_cast<const double2*>(ctx->fft_kf[which][c].p);
+    a.epilogue = epilogue;
+    a.curve = ctx->curve;
+    a.log_eps = log_eps;
+    const int pairs = (a.ntiles + 1) / 2, batch = std::min(pairs, ctx->opt_fft_batch);
+    rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * img * sizeof(double2));
+    if (rc) return rc;
+    rc = ensure_bytes(ctx, ctx->fft_s2, (size_t)batch * img * sizeof(double2));
+    if (rc) return rc;
+    a.s1 = static_cast<double2*>(ctx->fft_s1.p);
+    a.s2 = static_cast<double2*>(ctx->fft_s2.p);
+    for (int p0 = 0; p0 < pairs; p0 += batch) {
+        a.pair0 = p0;
+        a.npairs = std::min(batch, pairs - p0);
+        R2F_HIP(ctx, launch_fft_rows_fwd(a, s));
+        R2F_HIP(ctx, launch_fft_cols(a, 0, s));
+        R2F_HIP(ctx, launch_fft_rows_inv(a, s));
+    }
+    return R2F_OK;
+}
+
 int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
                 int epilogue, float log_eps, hipStream_t s) {
     if (y1 <= y0) return R2F_OK;
@@ -453,7 +563,17 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     a.epilogue = epilogue;
     a.curve = ctx->curve;
     a.log_eps = log_eps;
-    a.nchan = 3;
+    // large kernels take the fp64 FFT form channel by channel; the direct kernel runs the rest
+    a.nchan = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (fft_eligible(ctx, set, c)) {
+            rc = run_stencil_fft(ctx, which, c, src, dst, y0, y1, W, H, epilogue, log_eps, s);
+            if (rc) return rc;
+        } else {
+            a.chan[a.nchan++] = c;
+        }
+    }
+    if (a.nchan == 0) return R2F_OK;
     a.vec = planes_vec_ok(dst, W) ? 1 : 0;
     a.xcd_remap = ctx->opt_xcd_remap;
     a.order = nullptr;
@@ -480,7 +600,7 @@ int r2f_create(int device, r2f_ctx** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return R2F_EHIP;
     if (hipSetDevice(device) != hipSuccess) return R2F_EHIP;
-    if (init_kernel_attributes() != hipSuccess) return R2F_EHIP;
+    if (init_kernel_attributes() != hipSuccess || fft_init_attributes() != hipSuccess) return R2F_EHIP;
     r2f_ctx* ctx = new r2f_ctx();
     ctx->device = device;
     *out = ctx;
@@ -501,6 +621,12 @@ void r2f_destroy(r2f_ctx* ctx) {
         }
     for (auto& t : ctx->tile_order) t.buf.release();
     ctx->lanczos_buf.release();
+    ctx->fft_tw.release();
+    ctx->fft_s1.release();
+    ctx->fft_s2.release();
+    ctx->fft_kimg.release();
+    for (auto& row : ctx->fft_kf)
+        for (auto& b : row) b.release();
     delete ctx;
 }
 
@@ -524,6 +650,19 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "stencil_ablate")) {
         ctx->opt_ablate = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft")) {
+        ctx->opt_fft = value ? 1 : 0;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_min_taps")) {
+        ctx->opt_fft_min_taps = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_batch")) {
+        if (value < 1) return fail(ctx, R2F_EINVAL, "stencil_fft_batch must be >= 1");
+        ctx->opt_fft_batch = value;
         return R2F_OK;
     }
     if (!strcmp(name, "xcd_band")) {
@@ -597,6 +736,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.kc = kc;
     s.host.assign(k, k + (size_t)kh * kw * kc);
     s.built_q = 0;
+    for (int c = 0; c < 3; ++c) ctx->fft_kf_valid[which][c] = false;
     return R2F_OK;
 }
 

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = BX * BY, TW = 4 * BX, TH = Q * BY;
     int bx = blockIdx.x, by = blockIdx.y;
-    const int ch = blockIdx.z;
+    const int ch = a.chan[blockIdx.z];
     if (a.xcd_remap) {
         // remap inside the channel's own 2-D tile grid: channels differ wildly in cost (the blue
         // halation plane is the identity), so a remap across channels would unbalance the XCDs
@@ -893,7 +893,7 @@ hipError_t launch_front(const FrontArgs& a, hipStream_t s) {
 hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     const StencilVariant& v = kStencilVariants[variant];
-    const size_t lds = stencil_lds_bytes(v, a.st, a.nchan);
+    const size_t lds = stencil_lds_bytes(v, a.st, 3);  // any subset of the channels may be in a.chan
     dim3 block(v.BX * v.BY), grid((a.W + v.TW() - 1) / v.TW(), (a.y1 - a.y0 + v.TH() - 1) / v.TH(), a.nchan);
     const int key = variant * 2 + (a.epilogue == 1 ? 1 : 0);
     switch (key) {

@@ -36,6 +36,7 @@ struct StencilArgs {
     float log_eps;
     int nchan;
     int vec;
+    int chan[3];       // blockIdx.z -> channel (a launch may cover a subset: the others take the FFT form)
     int xcd_remap;     // 0 none, 1 arithmetic (contiguous run per XCD), 2 table `order`
     const int* order;  // xcd_remap == 2: tile index (bx + gx * by) of every linear workgroup id of one channel
     int ablate;  // profiling aid: 1 = skip the tile fill, 2 = skip the accumulation (results invalid)
@@ -126,6 +127,31 @@ struct LanczosArgs {
     const int* yofs;     // out_h
     const short* ycoef;  // out_h x 8
 };
+
+// Overlap-save FFT form of a large stencil (r2f_fft.hip): one channel, windows [pair0*2, (pair0+npairs)*2) of the launch.
+constexpr int kFftN = 256;
+struct FftConvArgs {
+    DevPlanes src, dst;
+    int ch;                   // plane of src / dst, channel of the curve
+    int y0, y1, W, H_global;  // output rows [y0, y1) of the global frame
+    int ay, ax;               // anchor inside the cropped kernel box
+    int vy, vx;               // valid outputs per window: 256 - kh + 1, 256 - kw + 1
+    int gx, ntiles;           // windows per row of windows, windows in total
+    int pair0, npairs;
+    int raw;                  // 1: src is the zero-padded 256 x 256 kernel image itself (kernel-spectrum build)
+    const double2* tw;        // exp(-2 pi i k / 256), k < 256
+    const double2* kf;        // conj of the kernel spectrum, [k'][r'] (digit-reversed both ways)
+    double2* kf_out;          // pass 2, mode 1
+    double2* s1;              // pass 1 -> 2, npairs x 256 x 256, transposed
+    double2* s2;              // pass 2 -> 3, npairs x 256 x 256, row-major
+    int epilogue;
+    DevCurve curve;
+    float log_eps;
+};
+hipError_t fft_init_attributes();
+hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s);
+hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s);
+hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s);
 
 struct NoiseArgs {
     uint32_t* hash;

@@ -210,6 +210,7 @@ def test_mirror_symmetric_fast_path(ctx):
     H, W = 100, 150
     img = rng.uniform(0.0, 2.0, (H, W, 3)).astype(np.float32)
     src = to_planes(img)
+    ctx.set_option("stencil_fft", 0)  # this test is about the two direct forms
 
     def run(k, sym):
         ctx.set_option("stencil_sym", sym)
@@ -232,6 +233,7 @@ def test_mirror_symmetric_fast_path(ctx):
     k = ok.compute_halation_kernel(229.33, halation_green_factor=0.3).copy()
     k[3, 20, 0] = np.nextafter(k[3, 20, 0], np.float32(1))  # break the symmetry of the red plane by one ulp
     np.testing.assert_array_equal(run(k, 1)[..., 0], run(k, 0)[..., 0])
+    ctx.set_option("stencil_fft", 1)
 
 
 @pytest.mark.parametrize("scale", [14.22, 166.67, 341.33])
