@@ -34,7 +34,7 @@ __device__ __forceinline__ cplx cmulc(cplx a, cplx b) {  // a * conj(b)
 constexpr int kN = kFftN;            // 256
 constexpr int kLine = kN + 1;        // LDS line pitch in complex elements: +1 keeps the transposing accesses conflict-free
 constexpr int kLines = 16;           // lines per workgroup
-constexpr int kFftThreads = 256;     // 4 waves, 4 lines each
+constexpr int kFftThreads = 512;     // 8 waves, 2 lines each
 
 // Forward: natural order in, digit-reversed out.  x: one LDS line; tw[k] = exp(-2 pi i k / 256).
 __device__ __forceinline__ void fft256_forward(cplx* x, const cplx* tw, int lane) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void fft256_backward(cplx* x, const cplx* tw, int lan
 }
 
 __device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* tw_global) {
-    tw_lds[threadIdx.x] = tw_global[threadIdx.x];  // kFftThreads == kN
+    if (threadIdx.x < kN) tw_lds[threadIdx.x] = tw_global[threadIdx.x];
 }
 
 // window origin (first input row / column) and validity of window `t` of the launch
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
     const bool hasA = window_of(a, 2 * (a.pair0 + pair), wyA, wxA), hasB = window_of(a, 2 * (a.pair0 + pair) + 1, wyB, wxB);
     const float* src = a.src.data + (long long)a.ch * a.src.plane_stride;
-    // load: one thread per column, 16 rows
-    const int c = threadIdx.x;
-    for (int i = 0; i < kLines; ++i) {
+    // load: one thread per column, the rows split over the thread groups
+    const int c = threadIdx.x % kN;
+    for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN) {
         const int r = r0 + i;
         double re = 0.0, im = 0.0;
         if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x 256 plane, no reflection
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs
     load_twiddles(tw, a.tw);
     const int pair = blockIdx.y, k0 = blockIdx.x * kLines;
     const cplx* s1 = a.s1 + (long long)pair * kN * kN;
-    for (int i = 0; i < kLines; ++i) lines[i * kLine + threadIdx.x] = s1[(long long)(k0 + i) * kN + threadIdx.x];
+    for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN)
+        lines[i * kLine + threadIdx.x % kN] = s1[(long long)(k0 + i) * kN + threadIdx.x % kN];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = wave; i < kLines; i += kFftThreads / 64) {
@@ -151,15 +152,16 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs
     __syncthreads();
     if (mode == 1) {
         cplx* kf = a.kf_out;
-        for (int i = 0; i < kLines; ++i) {
-            const cplx v = lines[i * kLine + threadIdx.x];
-            kf[(long long)(k0 + i) * kN + threadIdx.x] = make_double2(v.x, -v.y);
+        for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN) {
+            const cplx v = lines[i * kLine + threadIdx.x % kN];
+            kf[(long long)(k0 + i) * kN + threadIdx.x % kN] = make_double2(v.x, -v.y);
         }
         return;
     }
     cplx* s2 = a.s2 + (long long)pair * kN * kN;
     const int kk = threadIdx.x & 15;
-    for (int r = threadIdx.x >> 4; r < kN; r += kFftThreads / 16) s2[(long long)r * kN + k0 + kk] = lines[kk * kLine + r];
+    for (int r = threadIdx.x >> 4; r < a.vy; r += kFftThreads / 16)  // pass 3 never reads the rows past the valid outputs
+        s2[(long long)r * kN + k0 + kk] = lines[kk * kLine + r];
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -170,20 +172,22 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
     load_twiddles(tw, a.tw);
     const int pair = blockIdx.y, r0 = blockIdx.x * kLines;
     const cplx* s2 = a.s2 + (long long)pair * kN * kN;
-    for (int i = 0; i < kLines; ++i) lines[i * kLine + threadIdx.x] = s2[(long long)(r0 + i) * kN + threadIdx.x];
+    for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN)
+        if (r0 + i < a.vy) lines[i * kLine + threadIdx.x % kN] = s2[(long long)(r0 + i) * kN + threadIdx.x % kN];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = wave; i < kLines; i += kFftThreads / 64) fft256_backward(lines + i * kLine, tw, lane);
     __syncthreads();
     // outputs: window row r0 + i, column c -> pixel (wy + ay + r, wx + ax + c) for r <= 256 - kh, c <= 256 - kw
-    const int c = threadIdx.x;
+    const int c = threadIdx.x % kN;
     if (c >= a.vx) return;
     float* dplane = a.dst.data + (long long)a.ch * a.dst.plane_stride;
-    for (int half = 0; half < 2; ++half) {
+    {
+        const int half = threadIdx.x / kN;  // thread group 0 stores window A (real parts), group 1 window B (imaginary parts)
         int wy, wx;
-        if (!window_of(a, 2 * (a.pair0 + pair) + half, wy, wx)) continue;
+        if (!window_of(a, 2 * (a.pair0 + pair) + half, wy, wx)) return;
         const int gx = wx + a.ax + c;
-        if (gx >= a.W) continue;
+        if (gx >= a.W) return;
         for (int i = 0; i < kLines; ++i) {
             const int r = r0 + i;
             if (r >= a.vy) break;
