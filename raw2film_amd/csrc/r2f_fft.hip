@@ -33,8 +33,14 @@ __device__ __forceinline__ cplx cmulc(cplx a, cplx b) {  // a * conj(b)
 
 constexpr int kN = kFftN;            // 256
 constexpr int kLine = kN + 1;        // LDS line pitch in complex elements: +1 keeps the transposing accesses conflict-free
-constexpr int kLines = 16;           // lines per workgroup
-constexpr int kFftThreads = 512;     // 8 waves, 2 lines each
+#ifndef R2F_FFT_LINES
+#define R2F_FFT_LINES 8
+#endif
+#ifndef R2F_FFT_THREADS
+#define R2F_FFT_THREADS 512
+#endif
+constexpr int kLines = R2F_FFT_LINES;  // lines per workgroup
+constexpr int kFftThreads = R2F_FFT_THREADS;  // one wave per line at a time
 
 // Forward: natural order in, digit-reversed out.  x: one LDS line; tw[k] = exp(-2 pi i k / 256).
 __device__ __forceinline__ void fft256_forward(cplx* x, const cplx* tw, int lane) {
@@ -119,10 +125,10 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = wave; i < kLines; i += kFftThreads / 64) fft256_forward(lines + i * kLine, tw, lane);
     __syncthreads();
-    // transposed store: S1[pair][k][r0 .. r0+15]; 16 lanes cover the 16 rows of one k (256 contiguous bytes)
+    // transposed store: S1[pair][k][r0 .. r0 + kLines): kLines lanes cover the rows of one k (contiguous bytes)
     cplx* s1 = a.s1 + (long long)pair * kN * kN;
-    const int rr = threadIdx.x & 15;
-    for (int k = threadIdx.x >> 4; k < kN; k += kFftThreads / 16) s1[(long long)k * kN + r0 + rr] = lines[rr * kLine + k];
+    const int rr = threadIdx.x % kLines;
+    for (int k = threadIdx.x / kLines; k < kN; k += kFftThreads / kLines) s1[(long long)k * kN + r0 + rr] = lines[rr * kLine + k];
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
@@ -159,8 +165,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs
         return;
     }
     cplx* s2 = a.s2 + (long long)pair * kN * kN;
-    const int kk = threadIdx.x & 15;
-    for (int r = threadIdx.x >> 4; r < a.vy; r += kFftThreads / 16)  // pass 3 never reads the rows past the valid outputs
+    const int kk = threadIdx.x % kLines;
+    for (int r = threadIdx.x / kLines; r < a.vy; r += kFftThreads / kLines)  // pass 3 never reads the rows past the valid outputs
         s2[(long long)r * kN + k0 + kk] = lines[kk * kLine + r];
 }
 
