@@ -42,31 +42,55 @@ constexpr int kLine = kN + 1;        // LDS line pitch in complex elements: +1 k
 constexpr int kLines = R2F_FFT_LINES;  // lines per workgroup
 constexpr int kFftThreads = R2F_FFT_THREADS;  // one wave per line at a time
 
-// Forward: natural order in, digit-reversed out.  x: one LDS line; tw[k] = exp(-2 pi i k / 256).
-__device__ __forceinline__ void fft256_forward(cplx* x, const cplx* tw, int lane) {
+// A lane's twiddles for the four radix-4 stages (stage s works on spans of L = 64 >> 2s): W^e, W^2e, W^3e with
+// e = (lane mod L) * 64 / L.  They depend on the lane only, so they live in registers for every line a wave transforms.
+struct LaneTwiddles {
+    cplx w1[3], w2[3], w3[3];  // the last stage (L = 1) has e = 0: no twiddle at all
+};
+
+__device__ __forceinline__ LaneTwiddles lane_twiddles(const cplx* tw_global, int lane) {
+    LaneTwiddles t;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int L = 64 >> (2 * s), e = (lane & (L - 1)) * (64 / L);
+        t.w1[s] = tw_global[e];
+        t.w2[s] = tw_global[2 * e];
+        t.w3[s] = tw_global[3 * e];
+    }
+    return t;
+}
+
+// Forward: natural order in, digit-reversed out.  x: one LDS line.
+__device__ __forceinline__ void fft256_forward(cplx* x, const LaneTwiddles& t, int lane) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int L = 64 >> (2 * s);
-        const int j = lane & (L - 1), base = ((lane / L) * 4 * L) + j, e = j * (64 / L);
+        const int j = lane & (L - 1), base = ((lane / L) * 4 * L) + j;
         const cplx x0 = x[base], x1 = x[base + L], x2 = x[base + 2 * L], x3 = x[base + 3 * L];
         const cplx a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d0 = csub(x1, x3);
         const cplx d = make_double2(d0.y, -d0.x);  // (x1 - x3) * (-i)
         x[base] = cadd(a, c);
-        x[base + L] = cmul(cadd(b, d), tw[e]);
-        x[base + 2 * L] = cmul(csub(a, c), tw[2 * e]);
-        x[base + 3 * L] = cmul(csub(b, d), tw[3 * e]);
+        if (s < 3) {
+            x[base + L] = cmul(cadd(b, d), t.w1[s]);
+            x[base + 2 * L] = cmul(csub(a, c), t.w2[s]);
+            x[base + 3 * L] = cmul(csub(b, d), t.w3[s]);
+        } else {
+            x[base + L] = cadd(b, d);
+            x[base + 2 * L] = csub(a, c);
+            x[base + 3 * L] = csub(b, d);
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 // Backward (unnormalised: 256 x the inverse): digit-reversed in, natural out.
-__device__ __forceinline__ void fft256_backward(cplx* x, const cplx* tw, int lane) {
+__device__ __forceinline__ void fft256_backward(cplx* x, const LaneTwiddles& t, int lane) {
 #pragma unroll
     for (int s = 3; s >= 0; --s) {
         const int L = 64 >> (2 * s);
-        const int j = lane & (L - 1), base = ((lane / L) * 4 * L) + j, e = j * (64 / L);
-        const cplx x0 = x[base], x1 = cmulc(x[base + L], tw[e]), x2 = cmulc(x[base + 2 * L], tw[2 * e]),
-                   x3 = cmulc(x[base + 3 * L], tw[3 * e]);
+        const int j = lane & (L - 1), base = ((lane / L) * 4 * L) + j;
+        cplx x0 = x[base], x1 = x[base + L], x2 = x[base + 2 * L], x3 = x[base + 3 * L];
+        if (s < 3) x1 = cmulc(x1, t.w1[s]), x2 = cmulc(x2, t.w2[s]), x3 = cmulc(x3, t.w3[s]);
         const cplx a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d0 = csub(x1, x3);
         const cplx d = make_double2(-d0.y, d0.x);  // (x1 - x3) * (+i)
         x[base] = cadd(a, c);
@@ -75,10 +99,6 @@ __device__ __forceinline__ void fft256_backward(cplx* x, const cplx* tw, int lan
         x[base + 3 * L] = csub(b, d);
         __builtin_amdgcn_wave_barrier();
     }
-}
-
-__device__ __forceinline__ void load_twiddles(cplx* tw_lds, const cplx* tw_global) {
-    if (threadIdx.x < kN) tw_lds[threadIdx.x] = tw_global[threadIdx.x];
 }
 
 // window origin (first input row / column) and validity of window `t` of the launch
@@ -93,9 +113,8 @@ __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, 
 // ---------------------------------------------------------------------------------------------------- pass 1
 __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 fsm[];
-    cplx* tw = fsm;
-    cplx* lines = fsm + kN;
-    load_twiddles(tw, a.tw);
+    cplx* lines = fsm;
+    const LaneTwiddles tw = lane_twiddles(a.tw, threadIdx.x & 63);
     const int pair = blockIdx.y, r0 = blockIdx.x * kLines;
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
     const bool hasA = window_of(a, 2 * (a.pair0 + pair), wyA, wxA), hasB = window_of(a, 2 * (a.pair0 + pair) + 1, wyB, wxB);
@@ -136,9 +155,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
 // mode 1: forward along r only and store the conjugate: this IS the kernel spectrum (input = the padded kernel image)
 __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs a, const int mode) {
     extern __shared__ __attribute__((aligned(16))) double2 fsm[];
-    cplx* tw = fsm;
-    cplx* lines = fsm + kN;
-    load_twiddles(tw, a.tw);
+    cplx* lines = fsm;
+    const LaneTwiddles tw = lane_twiddles(a.tw, threadIdx.x & 63);
     const int pair = blockIdx.y, k0 = blockIdx.x * kLines;
     const cplx* s1 = a.s1 + (long long)pair * kN * kN;
     for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN)
@@ -173,9 +191,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs
 // ---------------------------------------------------------------------------------------------------- pass 3
 __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 fsm[];
-    cplx* tw = fsm;
-    cplx* lines = fsm + kN;
-    load_twiddles(tw, a.tw);
+    cplx* lines = fsm;
+    const LaneTwiddles tw = lane_twiddles(a.tw, threadIdx.x & 63);
     const int pair = blockIdx.y, r0 = blockIdx.x * kLines;
     const cplx* s2 = a.s2 + (long long)pair * kN * kN;
     for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN)
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
-static size_t fft_lds_bytes() { return (size_t)(kN + kLines * kLine) * sizeof(cplx); }
+static size_t fft_lds_bytes() { return (size_t)(kLines * kLine) * sizeof(cplx); }
 
 hipError_t fft_init_attributes() {
     hipError_t e;
