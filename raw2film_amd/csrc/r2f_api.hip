@@ -503,10 +503,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
     const int pairs = (a.ntiles + 1) / 2, batch = std::min(pairs, ctx->opt_fft_batch);
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * img * sizeof(double2));
     if (rc) return rc;
-    rc = ensure_bytes(ctx, ctx->fft_s2, (size_t)batch * img * sizeof(double2));
-    if (rc) return rc;
     a.s1 = static_cast<double2*>(ctx->fft_s1.p);
-    a.s2 = static_cast<double2*>(ctx->fft_s2.p);
+    a.s2 = nullptr;
     for (int p0 = 0; p0 < pairs; p0 += batch) {
         a.pair0 = p0;
         a.npairs = std::min(batch, pairs - p0);

@@ -8,14 +8,18 @@
 // Unit of work: a PAIR of 256 x 256 input windows of one channel packed as real + imaginary part of one complex image (the
 // kernel is real, so the correlation of the complex image is the pair of correlations -- no Hermitian bookkeeping at all).
 // Window (ty, tx) produces the outputs [ty, ty + 256 - kh] x [tx, tx + 256 - kw] from the input rows ty - ay .. + 255.
+// One scratch image S[r][k] (complex128, 1 MB) per pair:
 //
-//   pass 1  rows:     load (reflect-101 on the global frame), 256 forward FFTs along x, store TRANSPOSED   S1[k'][r]
-//   pass 2  columns:  256 forward FFTs along r, multiply by conj(K^)[k'][r'], 256 inverse FFTs, store row-major S2[r][k']
-//   pass 3  rows:     256 inverse FFTs along k', scale 2^-16, crop to the valid outputs, [log + density curve], store
+//   pass 1  rows:     load (reflect-101 on the global frame), forward FFT along x                      -> S[r][k]
+//   pass 2  columns:  forward FFT along r, multiply by conj(K^)[r'][k], inverse FFT along r', in place  -> S[r][k]
+//   pass 3  rows:     inverse FFT along k, scale 2^-16, crop to the valid outputs, [log + density curve], store
 //
-// One wave transforms one 256-point line in LDS: radix-4 decimation in frequency forward (natural in, base-4
-// digit-reversed out), radix-4 decimation in time backward (digit-reversed in, natural out), so no reordering pass exists;
-// the kernel's spectrum is produced by the same two forward passes and therefore sits in the same digit-reversed layout.
+// A 256-point line is transformed by 16 lanes holding 16 elements each (element n = lane + 16 m): a 16-point DFT in
+// registers, the twiddles W_256^(lane p), a 16 x 16 transpose through LDS, a second 16-point DFT -- natural order in and
+// out, one LDS round trip per transform.  (The first version ran four radix-4 stages through LDS and was bound by
+// ds_write_b128 issue: 0.6 ms per 1 024 pairs in pass 2.)  A wave carries 4 lines; lines of a wave are 4 neighbouring rows
+// (passes 1, 3: 256-byte segments per access) or 4 neighbouring columns (pass 2: a gather of 64-byte pieces, the other half
+// of each 128-byte line belongs to the next wave of the same workgroup).
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
@@ -30,75 +34,98 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x *
 __device__ __forceinline__ cplx cmulc(cplx a, cplx b) {  // a * conj(b)
     return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
-
-constexpr int kN = kFftN;            // 256
-constexpr int kLine = kN + 1;        // LDS line pitch in complex elements: +1 keeps the transposing accesses conflict-free
-#ifndef R2F_FFT_LINES
-#define R2F_FFT_LINES 8
-#endif
-#ifndef R2F_FFT_THREADS
-#define R2F_FFT_THREADS 512
-#endif
-constexpr int kLines = R2F_FFT_LINES;  // lines per workgroup
-constexpr int kFftThreads = R2F_FFT_THREADS;  // one wave per line at a time
-
-// A lane's twiddles for the four radix-4 stages (stage s works on spans of L = 64 >> 2s): W^e, W^2e, W^3e with
-// e = (lane mod L) * 64 / L.  They depend on the lane only, so they live in registers for every line a wave transforms.
-struct LaneTwiddles {
-    cplx w1[3], w2[3], w3[3];  // the last stage (L = 1) has e = 0: no twiddle at all
-};
-
-__device__ __forceinline__ LaneTwiddles lane_twiddles(const cplx* tw_global, int lane) {
-    LaneTwiddles t;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int L = 64 >> (2 * s), e = (lane & (L - 1)) * (64 / L);
-        t.w1[s] = tw_global[e];
-        t.w2[s] = tw_global[2 * e];
-        t.w3[s] = tw_global[3 * e];
-    }
-    return t;
+template <bool INV>
+__device__ __forceinline__ cplx ctw(cplx a, cplx w) {  // a * w (forward) or a * conj(w) (inverse)
+    return INV ? cmulc(a, w) : cmul(a, w);
 }
 
-// Forward: natural order in, digit-reversed out.  x: one LDS line.
-__device__ __forceinline__ void fft256_forward(cplx* x, const LaneTwiddles& t, int lane) {
+constexpr int kN = kFftN;             // 256
+constexpr int kFftThreads = 256;      // 4 waves x 4 lines
+constexpr int kTPitch = 17;           // transpose tile row pitch (doubles): 16 + 1
+constexpr int kTLine = 16 * kTPitch;  // 272 doubles per line: = 16 (mod 32), so two lines fill the 32 8-byte slots exactly
+
+// 4-point DFT, natural order in and out (forward kernel exp(-2 pi i / 4) = -i).
+template <bool INV>
+__device__ __forceinline__ void dft4(cplx& a, cplx& b, cplx& c, cplx& d) {
+    const cplx s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+    const cplx r3 = INV ? make_double2(-s3.y, s3.x) : make_double2(s3.y, -s3.x);  // (-+ i) * s3
+    a = cadd(s0, s2);
+    c = csub(s0, s2);
+    b = cadd(s1, r3);
+    d = csub(s1, r3);
+}
+
+// 16-point DFT in registers, natural order in and out: 4 x 4 Cooley-Tukey with the constants W_16^(c r).
+template <bool INV>
+__device__ __forceinline__ void dft16(cplx (&v)[16]) {
+    constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int L = 64 >> (2 * s);
-        const int j = lane & (L - 1), base = ((lane / L) * 4 * L) + j;
-        const cplx x0 = x[base], x1 = x[base + L], x2 = x[base + 2 * L], x3 = x[base + 3 * L];
-        const cplx a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d0 = csub(x1, x3);
-        const cplx d = make_double2(d0.y, -d0.x);  // (x1 - x3) * (-i)
-        x[base] = cadd(a, c);
-        if (s < 3) {
-            x[base + L] = cmul(cadd(b, d), t.w1[s]);
-            x[base + 2 * L] = cmul(csub(a, c), t.w2[s]);
-            x[base + 3 * L] = cmul(csub(b, d), t.w3[s]);
-        } else {
-            x[base + L] = cadd(b, d);
-            x[base + 2 * L] = csub(a, c);
-            x[base + 3 * L] = csub(b, d);
+    for (int c = 0; c < 4; ++c) dft4<INV>(v[c], v[c + 4], v[c + 8], v[c + 12]);  // u[c][r] at v[c + 4 r]
+    // u[c][r] *= W_16^(c r): W^1 = (c1, -s1), W^2 = (h, -h), W^3 = (s1, -c1), W^4 = -i, W^6 = (-h, -h), W^9 = (-c1, s1)
+    v[1 + 4] = ctw<INV>(v[1 + 4], make_double2(c1, -s1));
+    v[1 + 8] = ctw<INV>(v[1 + 8], make_double2(h, -h));
+    v[1 + 12] = ctw<INV>(v[1 + 12], make_double2(s1, -c1));
+    v[2 + 4] = ctw<INV>(v[2 + 4], make_double2(h, -h));
+    v[2 + 8] = ctw<INV>(v[2 + 8], make_double2(0.0, -1.0));
+    v[2 + 12] = ctw<INV>(v[2 + 12], make_double2(-h, -h));
+    v[3 + 4] = ctw<INV>(v[3 + 4], make_double2(s1, -c1));
+    v[3 + 8] = ctw<INV>(v[3 + 8], make_double2(-h, -h));
+    v[3 + 12] = ctw<INV>(v[3 + 12], make_double2(-c1, s1));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4<INV>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);  // out[r + 4 s] at v[4 r + s]
+    // 4 x 4 index transpose (register renaming only)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = r + 1; s < 4; ++s) {
+            const cplx t = v[4 * r + s];
+            v[4 * r + s] = v[4 * s + r];
+            v[4 * s + r] = t;
         }
-        __builtin_amdgcn_wave_barrier();
-    }
 }
 
-// Backward (unnormalised: 256 x the inverse): digit-reversed in, natural out.
-__device__ __forceinline__ void fft256_backward(cplx* x, const LaneTwiddles& t, int lane) {
-#pragma unroll
-    for (int s = 3; s >= 0; --s) {
-        const int L = 64 >> (2 * s);
-        const int j = lane & (L - 1), base = ((lane / L) * 4 * L) + j;
-        cplx x0 = x[base], x1 = x[base + L], x2 = x[base + 2 * L], x3 = x[base + 3 * L];
-        if (s < 3) x1 = cmulc(x1, t.w1[s]), x2 = cmulc(x2, t.w2[s]), x3 = cmulc(x3, t.w3[s]);
-        const cplx a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d0 = csub(x1, x3);
-        const cplx d = make_double2(-d0.y, d0.x);  // (x1 - x3) * (+i)
-        x[base] = cadd(a, c);
-        x[base + L] = cadd(b, d);
-        x[base + 2 * L] = csub(a, c);
-        x[base + 3 * L] = csub(b, d);
-        __builtin_amdgcn_wave_barrier();
+// 256-point transform of the line whose element (l + 16 m) sits in v[m] of lane l (l = lane & 15); on return v[q] holds
+// output element (l + 16 q).  w1 = exp(-2 pi i l / 256).  tbuf: this WAVE's transpose buffer, 4 lines x 272 doubles.
+template <bool INV>
+__device__ __forceinline__ void fft256(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
+    dft16<INV>(v);
+    // v[p] *= w1^p; the powers come from a multiplication tree of depth <= 5 (a few ulp)
+    {
+        const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3),
+                   w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+        v[1] = ctw<INV>(v[1], w1);
+        v[2] = ctw<INV>(v[2], w2);
+        v[3] = ctw<INV>(v[3], w3);
+        v[4] = ctw<INV>(v[4], w4);
+        v[5] = ctw<INV>(v[5], w5);
+        v[6] = ctw<INV>(v[6], w6);
+        v[7] = ctw<INV>(v[7], w7);
+        v[8] = ctw<INV>(v[8], w8);
+        v[9] = ctw<INV>(v[9], cmul(w8, w1));
+        v[10] = ctw<INV>(v[10], cmul(w5, w5));
+        v[11] = ctw<INV>(v[11], cmul(w8, w3));
+        v[12] = ctw<INV>(v[12], cmul(w6, w6));
+        v[13] = ctw<INV>(v[13], cmul(w8, w5));
+        v[14] = ctw<INV>(v[14], cmul(w7, w7));
+        v[15] = ctw<INV>(v[15], cmul(w8, w7));
     }
+    // 16 x 16 transpose inside each 16-lane group, real parts then imaginary parts through the same buffer
+    const int l = lane & 15;
+    double* t = tbuf + (lane >> 4) * kTLine;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t[p * kTPitch + l] = v[p].x;
+    __builtin_amdgcn_wave_barrier();
+    double re[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) re[j] = t[l * kTPitch + j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t[p * kTPitch + l] = v[p].y;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = make_double2(re[j], t[l * kTPitch + j]);
+    __builtin_amdgcn_wave_barrier();
+    dft16<INV>(v);
 }
 
 // window origin (first input row / column) and validity of window `t` of the launch
@@ -110,144 +137,125 @@ __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, 
     return true;
 }
 
+__device__ __forceinline__ double* wave_tbuf(double* smem) { return smem + (threadIdx.x >> 6) * 4 * kTLine; }
+
 // ---------------------------------------------------------------------------------------------------- pass 1
+// grid (256 / 16, pairs): a workgroup transforms 16 rows, a wave 4 of them.
 __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double2 fsm[];
-    cplx* lines = fsm;
-    const LaneTwiddles tw = lane_twiddles(a.tw, threadIdx.x & 63);
-    const int pair = blockIdx.y, r0 = blockIdx.x * kLines;
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
     const bool hasA = window_of(a, 2 * (a.pair0 + pair), wyA, wxA), hasB = window_of(a, 2 * (a.pair0 + pair) + 1, wyB, wxB);
     const float* src = a.src.data + (long long)a.ch * a.src.plane_stride;
-    // load: one thread per column, the rows split over the thread groups
-    const int c = threadIdx.x % kN;
-    for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN) {
-        const int r = r0 + i;
-        double re = 0.0, im = 0.0;
-        if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x 256 plane, no reflection
-            re = (double)src[(long long)r * kN + c];
-        } else {
-            if (hasA) {
-                int sy = reflect101(wyA + r, a.H_global) - a.src.gy0;
-                sy = clampi(sy, 0, a.src.rows - 1);  // rows outside the buffer only feed discarded outputs
-                re = (double)src[(long long)sy * a.W + reflect101(wxA + c, a.W)];
-            }
-            if (hasB) {
-                int sy = reflect101(wyB + r, a.H_global) - a.src.gy0;
-                sy = clampi(sy, 0, a.src.rows - 1);
-                im = (double)src[(long long)sy * a.W + reflect101(wxB + c, a.W)];
-            }
+    cplx v[16];
+    if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x 256 plane, no reflection
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = make_double2((double)src[(long long)r * kN + l + 16 * m], 0.0);
+    } else {
+        const float* rowA = src;
+        const float* rowB = src;
+        if (hasA) {
+            const int sy = reflect101(wyA + r, a.H_global) - a.src.gy0;
+            rowA = src + (long long)clampi(sy, 0, a.src.rows - 1) * a.W;  // rows outside the buffer only feed discarded outputs
         }
-        lines[i * kLine + c] = make_double2(re, im);
+        if (hasB) {
+            const int sy = reflect101(wyB + r, a.H_global) - a.src.gy0;
+            rowB = src + (long long)clampi(sy, 0, a.src.rows - 1) * a.W;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int c = l + 16 * m;
+            const double re = hasA ? (double)rowA[reflect101(wxA + c, a.W)] : 0.0;
+            const double im = hasB ? (double)rowB[reflect101(wxB + c, a.W)] : 0.0;
+            v[m] = make_double2(re, im);
+        }
     }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < kLines; i += kFftThreads / 64) fft256_forward(lines + i * kLine, tw, lane);
-    __syncthreads();
-    // transposed store: S1[pair][k][r0 .. r0 + kLines): kLines lanes cover the rows of one k (contiguous bytes)
-    cplx* s1 = a.s1 + (long long)pair * kN * kN;
-    const int rr = threadIdx.x % kLines;
-    for (int k = threadIdx.x / kLines; k < kN; k += kFftThreads / kLines) s1[(long long)k * kN + r0 + rr] = lines[rr * kLine + k];
+    fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
+    cplx* s1 = a.s1 + ((long long)pair * kN + r) * kN;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s1[l + 16 * q] = v[q];
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
-// mode 0: forward along r, multiply by the kernel spectrum, backward, store row-major S2[r][k]
-// mode 1: forward along r only and store the conjugate: this IS the kernel spectrum (input = the padded kernel image)
+// grid (256 / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.
+// mode 0: forward along r, multiply by the kernel spectrum, inverse, store back
+// mode 1: forward only; the conjugate IS the kernel spectrum (input = the padded kernel image)
 __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs a, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) double2 fsm[];
-    cplx* lines = fsm;
-    const LaneTwiddles tw = lane_twiddles(a.tw, threadIdx.x & 63);
-    const int pair = blockIdx.y, k0 = blockIdx.x * kLines;
-    const cplx* s1 = a.s1 + (long long)pair * kN * kN;
-    for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN)
-        lines[i * kLine + threadIdx.x % kN] = s1[(long long)(k0 + i) * kN + threadIdx.x % kN];
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < kLines; i += kFftThreads / 64) {
-        cplx* x = lines + i * kLine;
-        fft256_forward(x, tw, lane);
-        if (mode == 1) continue;
-        const cplx* kf = a.kf + (long long)(k0 + i) * kN;
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
+    cplx* s1 = a.s1 + (long long)pair * kN * kN + k;
+    cplx v[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[lane + 64 * q] = cmul(x[lane + 64 * q], kf[lane + 64 * q]);
-        __builtin_amdgcn_wave_barrier();
-        fft256_backward(x, tw, lane);
-    }
-    __syncthreads();
+    for (int m = 0; m < 16; ++m) v[m] = s1[(long long)(l + 16 * m) * kN];
+    const cplx w1 = a.tw[l];
+    double* tbuf = wave_tbuf(fsm);
+    fft256<false>(v, w1, tbuf, lane);
     if (mode == 1) {
-        cplx* kf = a.kf_out;
-        for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN) {
-            const cplx v = lines[i * kLine + threadIdx.x % kN];
-            kf[(long long)(k0 + i) * kN + threadIdx.x % kN] = make_double2(v.x, -v.y);
-        }
+        cplx* kf = a.kf_out + k;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kf[(long long)(l + 16 * q) * kN] = make_double2(v[q].x, -v[q].y);
         return;
     }
-    cplx* s2 = a.s2 + (long long)pair * kN * kN;
-    const int kk = threadIdx.x % kLines;
-    for (int r = threadIdx.x / kLines; r < a.vy; r += kFftThreads / kLines)  // pass 3 never reads the rows past the valid outputs
-        s2[(long long)r * kN + k0 + kk] = lines[kk * kLine + r];
+    const cplx* kf = a.kf + k;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], kf[(long long)(l + 16 * q) * kN]);
+    fft256<true>(v, w1, tbuf, lane);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (l + 16 * q < a.vy) s1[(long long)(l + 16 * q) * kN] = v[q];  // pass 3 never reads the rows past the valid outputs
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
+// grid (ceil(vy / 16), pairs)
 __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double2 fsm[];
-    cplx* lines = fsm;
-    const LaneTwiddles tw = lane_twiddles(a.tw, threadIdx.x & 63);
-    const int pair = blockIdx.y, r0 = blockIdx.x * kLines;
-    const cplx* s2 = a.s2 + (long long)pair * kN * kN;
-    for (int i = threadIdx.x / kN; i < kLines; i += kFftThreads / kN)
-        if (r0 + i < a.vy) lines[i * kLine + threadIdx.x % kN] = s2[(long long)(r0 + i) * kN + threadIdx.x % kN];
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < kLines; i += kFftThreads / 64) fft256_backward(lines + i * kLine, tw, lane);
-    __syncthreads();
-    // outputs: window row r0 + i, column c -> pixel (wy + ay + r, wx + ax + c) for r <= 256 - kh, c <= 256 - kw
-    const int c = threadIdx.x % kN;
-    if (c >= a.vx) return;
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
+    const cplx* s1 = a.s1 + ((long long)pair * kN + (live ? r : 0)) * kN;
+    cplx v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = s1[l + 16 * m];
+    fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
+    if (!live) return;
     float* dplane = a.dst.data + (long long)a.ch * a.dst.plane_stride;
-    {
-        const int half = threadIdx.x / kN;  // thread group 0 stores window A (real parts), group 1 window B (imaginary parts)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
         int wy, wx;
-        if (!window_of(a, 2 * (a.pair0 + pair) + half, wy, wx)) return;
-        const int gx = wx + a.ax + c;
-        if (gx >= a.W) return;
-        for (int i = 0; i < kLines; ++i) {
-            const int r = r0 + i;
-            if (r >= a.vy) break;
-            const int gy = wy + a.ay + r;
-            if (gy >= a.y1) break;
-            const cplx v = lines[i * kLine + c];
-            float o = (float)((half ? v.y : v.x) * (1.0 / 65536.0));
+        if (!window_of(a, 2 * (a.pair0 + pair) + half, wy, wx)) continue;
+        const int gy = wy + a.ay + r;
+        if (gy >= a.y1) continue;
+        float* drow = dplane + (long long)(gy - a.dst.gy0) * a.W;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = l + 16 * q, gx = wx + a.ax + c;
+            if (c >= a.vx || gx >= a.W) continue;
+            float o = (float)((half ? v[q].y : v[q].x) * (1.0 / 65536.0));
             if (a.epilogue == 1) o = log_curve(a.curve, a.ch, o, a.log_eps);
-            dplane[(long long)(gy - a.dst.gy0) * a.W + gx] = o;
+            drow[gx] = o;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
-static size_t fft_lds_bytes() { return (size_t)(kLines * kLine) * sizeof(cplx); }
+static size_t fft_lds_bytes() { return (size_t)(kFftThreads / 64) * 4 * kTLine * sizeof(double); }
 
-hipError_t fft_init_attributes() {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds_bytes());
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds_bytes());
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds_bytes());
-}
+hipError_t fft_init_attributes() { return hipSuccess; }
 
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(kN / kLines, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+    hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(kN / 16, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(fft_cols_kernel, dim3(kN / kLines, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
+    hipLaunchKernelGGL(fft_cols_kernel, dim3(kN / 16, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
     return hipGetLastError();
 }
 
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s) {
-    const int blocks = (a.vy + kLines - 1) / kLines;  // rows beyond the valid outputs are never stored
+    const int blocks = (a.vy + 15) / 16;  // rows beyond the valid outputs are never stored
     hipLaunchKernelGGL(fft_rows_inv_kernel, dim3(blocks, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
     return hipGetLastError();
 }

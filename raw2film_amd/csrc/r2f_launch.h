@@ -140,10 +140,10 @@ struct FftConvArgs {
     int pair0, npairs;
     int raw;                  // 1: src is the zero-padded 256 x 256 kernel image itself (kernel-spectrum build)
     const double2* tw;        // exp(-2 pi i k / 256), k < 256
-    const double2* kf;        // conj of the kernel spectrum, [k'][r'] (digit-reversed both ways)
+    const double2* kf;        // conj of the kernel's 2-D spectrum, [r'][k]
     double2* kf_out;          // pass 2, mode 1
-    double2* s1;              // pass 1 -> 2, npairs x 256 x 256, transposed
-    double2* s2;              // pass 2 -> 3, npairs x 256 x 256, row-major
+    double2* s1;              // npairs x 256 x 256 scratch images S[r][k], transformed in place
+    double2* s2;              // unused
     int epilogue;
     DevCurve curve;
     float log_eps;
