@@ -163,12 +163,22 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
             const int sy = reflect101(wyB + r, a.H_global) - a.src.gy0;
             rowB = src + (long long)clampi(sy, 0, a.src.rows - 1) * a.W;
         }
+        // windows that do not touch the left / right frame edge (all but two per row of windows) need no reflection
+        const bool inA = wxA >= 0 && wxA + kN <= a.W, inB = wxB >= 0 && wxB + kN <= a.W;
+        if ((!hasA || inA) && (!hasB || inB)) {
+            const float* pa = rowA + (hasA ? wxA : 0) + l;
+            const float* pb = rowB + (hasB ? wxB : 0) + l;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int c = l + 16 * m;
-            const double re = hasA ? (double)rowA[reflect101(wxA + c, a.W)] : 0.0;
-            const double im = hasB ? (double)rowB[reflect101(wxB + c, a.W)] : 0.0;
-            v[m] = make_double2(re, im);
+            for (int m = 0; m < 16; ++m)
+                v[m] = make_double2(hasA ? (double)pa[16 * m] : 0.0, hasB ? (double)pb[16 * m] : 0.0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int c = l + 16 * m;
+                const double re = hasA ? (double)rowA[reflect101(wxA + c, a.W)] : 0.0;
+                const double im = hasB ? (double)rowB[reflect101(wxB + c, a.W)] : 0.0;
+                v[m] = make_double2(re, im);
+            }
         }
     }
     fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
