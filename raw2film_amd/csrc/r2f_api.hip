@@ -64,7 +64,7 @@ struct r2f_ctx {
     DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_s2, fft_kimg;
     bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
     int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
-    int opt_fft_min_taps = 2000;  // ... "large enough": cropped box of at least this many taps (and at most 129 x 129)
+    int opt_fft_min_taps = 900;   // ... "large enough": cropped box of at least this many taps (and at most 129 x 129)
     int opt_fft_batch = 1024;    // window pairs per batch (2 MB of scratch each)
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     int lanczos_key[4] = {0, 0, 0, 0};

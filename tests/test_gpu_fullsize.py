@@ -54,8 +54,15 @@ def test_windows_of_the_100mp_render_match_the_oracle(full, y0, x0):
     assert err <= 1e-5, err
 
 
-def test_row_shards_of_the_100mp_frame_are_bit_identical(full):
+@pytest.mark.parametrize("fft", [0, 1])
+def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
+    """Direct stencils: bit for bit (every pixel sums its taps in the same order whatever the tile or shard).  FFT stencils:
+    the windows are anchored at the shard's first row, so a pixel's 256 x 256 window differs between the two renders and
+    with it the fp64 rounding noise (~1e-13): after the one rounding to fp32 a handful of pixels may differ by an ulp."""
     ctx, params, p, frame, out = full
+    ctx.set_option("stencil_fft", fft)
+    if not fft:
+        out, _ = ctx.render(frame, params)
     rh, rm = p.halation_kernel.shape[0] // 2, p.mtf_kernel.shape[0] // 2
     bounds = [0, 1000, 4096, 5121, H_FULL]  # uneven shards, each at least a halo tall
     for a, b in zip(bounds[:-1], bounds[1:]):
@@ -69,8 +76,15 @@ def test_row_shards_of_the_100mp_frame_are_bit_identical(full):
         ctx.stage_mtf(D, D2, params, src_gy0=d_lo, dst_gy0=a, y0=a, y1=b, H_global=H_FULL)
         part = torch.empty((b - a, W_FULL, 3), dtype=torch.float32, device="cuda")
         ctx.stage_tail(D2, params, src_gy0=a, out_f32=part, out_gy0=a, y0=a, y1=b, H_global=H_FULL)
-        assert torch.equal(part, out[a:b]), (a, b)
+        if fft:
+            ref = out[a:b]
+            diff = (part - ref).abs()
+            assert float((diff / ref.abs().clamp_min(0.1)).max()) <= 5e-7, (a, b)
+            assert float((diff > 0).float().mean()) <= 1e-3, (a, b)
+        else:
+            assert torch.equal(part, out[a:b]), (a, b)
         del E, D, D2, part
+    ctx.set_option("stencil_fft", 1)
 
 
 def test_a_constant_100mp_frame_stays_constant(full):
