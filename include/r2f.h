@@ -187,9 +187,16 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
                       int H_global, void* stream);
 
 /* Introspection for the measurement harness: what the device form of stencil `which` executes.  out: 3 channels x 8 ints
- * {entries, row steps, LDS phases, mirror-paired (0/1), cropped rows, cropped (padded) columns, rows per lane, 0}.  One entry =
+ * {entries, row steps, LDS phases, mirror-paired (0/1), cropped rows, cropped (padded) columns, rows per lane, takes the FFT form
+ * (0/1: then the direct form's numbers before it are not what runs)}.  One entry =
  * 32 packed FMAs per lane for 16 pixels (x2 taps when mirror-paired). */
 int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
+
+/* Per-launch device timing of the FFT stencil passes, for the roofline line of bench.py.  After r2f_set_option(ctx,
+ * "kernel_timing", 1) every launch of pass cls (0 rows forward, 1 columns, 2 rows inverse) is bracketed by events on its own
+ * stream; this call waits for them, returns their summed duration, the launch count and the summed algorithmic bytes
+ * (scratch images and windows the pass has to move; the 1 MB kernel spectrum stays in L2), and resets the counters. */
+int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes);
 
 /* Tuning knob for A/B runs: stencil tile variant (0 = auto). */
 int r2f_set_option(r2f_ctx* ctx, const char* name, int value);

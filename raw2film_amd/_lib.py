@@ -117,6 +117,7 @@ _SIGNATURES = {
     ),
     "r2f_resize_lanczos4_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "r2f_lanczos4_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "r2f_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int), _P(C.c_double)]),
     "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -332,8 +332,14 @@ class HipContext:
         """Per channel: dict(entries, rowsteps, phases, sym, kh, kw, q) of the device form of stencil `which` (bench.py)."""
         out = (C.c_int * 24)()
         self._check(self._lib.r2f_stencil_stats(self._h, int(which), out))
-        keys = ("entries", "rowsteps", "phases", "sym", "kh", "kw", "q")
-        return [dict(zip(keys, out[8 * c:8 * c + 7])) for c in range(3)]
+        keys = ("entries", "rowsteps", "phases", "sym", "kh", "kw", "q", "fft")
+        return [dict(zip(keys, out[8 * c:8 * c + 8])) for c in range(3)]
+
+    def kernel_timing(self, cls: int):
+        """(total ms, launches, algorithmic bytes) of FFT pass `cls` since the last call; needs set_option("kernel_timing", 1)."""
+        ms, n, b = C.c_double(), C.c_int(), C.c_double()
+        self._check(self._lib.r2f_kernel_timing(self._h, int(cls), C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
 
     def histogram_counts(self, image_u8):
         """Per-channel bin counts of a uint8 (H, W, 3) device image -> int32 (3, 256) device tensor (utils.py:160-165)."""

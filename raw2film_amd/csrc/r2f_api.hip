@@ -63,6 +63,11 @@ struct r2f_ctx {
     // FFT form of large stencils (r2f_fft.hip): twiddles, per stencil and channel the kernel spectrum, pass scratch
     DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_s2, fft_kimg;
     bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
+    // optional per-launch timing of the FFT passes with events on the launch stream (bench.py's roofline): class 0 / 1 / 2 =
+    // pass 1 / 2 / 3; algorithmic bytes are summed alongside
+    int opt_timing = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev[3];
+    double timing_bytes[3] = {0, 0, 0};
     int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
     int opt_fft_min_taps = 900;   // ... "large enough": cropped box of at least this many taps (and at most 129 x 129)
     int opt_fft_batch = 1024;    // window pairs per batch (2 MB of scratch each)
@@ -505,12 +510,33 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
     if (rc) return rc;
     a.s1 = static_cast<double2*>(ctx->fft_s1.p);
     a.s2 = nullptr;
+    auto timed = [&](int cls, double bytes, auto&& launch) -> int {
+        if (!ctx->opt_timing) {
+            R2F_HIP(ctx, launch());
+            return R2F_OK;
+        }
+        hipEvent_t e0, e1;
+        R2F_HIP(ctx, hipEventCreate(&e0));
+        R2F_HIP(ctx, hipEventCreate(&e1));
+        R2F_HIP(ctx, hipEventRecord(e0, s));
+        R2F_HIP(ctx, launch());
+        R2F_HIP(ctx, hipEventRecord(e1, s));
+        ctx->timing_ev[cls].push_back({e0, e1});
+        ctx->timing_bytes[cls] += bytes;
+        return R2F_OK;
+    };
     for (int p0 = 0; p0 < pairs; p0 += batch) {
         a.pair0 = p0;
         a.npairs = std::min(batch, pairs - p0);
-        R2F_HIP(ctx, launch_fft_rows_fwd(a, s));
-        R2F_HIP(ctx, launch_fft_cols(a, 0, s));
-        R2F_HIP(ctx, launch_fft_rows_inv(a, s));
+        // algorithmic bytes of the passes: window floats in (2 per pair) + scratch image out; scratch in + valid rows out;
+        // valid rows in + valid outputs out.  The kernel spectrum (1 MB) stays in L2.
+        const double np = a.npairs, full = (double)img * sizeof(double2), part = full * a.vy / kFftN;
+        rc = timed(0, np * (2.0 * img * sizeof(float) + full), [&] { return launch_fft_rows_fwd(a, s); });
+        if (rc) return rc;
+        rc = timed(1, np * (full + part), [&] { return launch_fft_cols(a, 0, s); });
+        if (rc) return rc;
+        rc = timed(2, np * (part + 2.0 * a.vy * a.vx * sizeof(float)), [&] { return launch_fft_rows_inv(a, s); });
+        if (rc) return rc;
     }
     return R2F_OK;
 }
@@ -648,6 +674,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "stencil_ablate")) {
         ctx->opt_ablate = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "kernel_timing")) {
+        ctx->opt_timing = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft")) {
@@ -810,6 +840,25 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
     return run_stencil(ctx, which, src, dst, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
 }
 
+int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes) {
+    if (!ctx || cls < 0 || cls > 2 || !total_ms || !launches || !bytes) return R2F_EINVAL;
+    double sum = 0.0;
+    for (auto& ev : ctx->timing_ev[cls]) {
+        R2F_HIP(ctx, hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        R2F_HIP(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        sum += ms;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    *total_ms = sum;
+    *launches = (int)ctx->timing_ev[cls].size();
+    *bytes = ctx->timing_bytes[cls];
+    ctx->timing_ev[cls].clear();
+    ctx->timing_bytes[cls] = 0.0;
+    return R2F_OK;
+}
+
 int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
     if (!ctx || !out) return R2F_EINVAL;
     if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "stencil: which must be 0..2");
@@ -824,7 +873,7 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
         const DevStencil& d = set.dev[c];
         int* o = out + 8 * c;
         o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym;
-        o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q, o[7] = 0;
+        o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q, o[7] = fft_eligible(ctx, set, c) ? 1 : 0;
     }
     return R2F_OK;
 }

@@ -8,7 +8,7 @@
 // Unit of work: a PAIR of 256 x 256 input windows of one channel packed as real + imaginary part of one complex image (the
 // kernel is real, so the correlation of the complex image is the pair of correlations -- no Hermitian bookkeeping at all).
 // Window (ty, tx) produces the outputs [ty, ty + 256 - kh] x [tx, tx + 256 - kw] from the input rows ty - ay .. + 255.
-// One scratch image S[r][k] (complex128, 1 MB) per pair:
+// One scratch image S(r, k) (complex128, 1 MB, column-blocked layout, see sidx) per pair:
 //
 //   pass 1  rows:     load (reflect-101 on the global frame), forward FFT along x                      -> S[r][k]
 //   pass 2  columns:  forward FFT along r, multiply by conj(K^)[r'][k], inverse FFT along r', in place  -> S[r][k]
@@ -139,6 +139,11 @@ __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, 
 
 __device__ __forceinline__ double* wave_tbuf(double* smem) { return smem + (threadIdx.x >> 6) * 4 * kTLine; }
 
+// Scratch / spectrum layout: element (r, k) of a 256 x 256 image sits at ((k / 4) * 256 + r) * 4 + k % 4, i.e. blocks of four
+// neighbouring columns are interleaved row by row.  The column pass (a wave = 4 neighbouring columns x 16 rows per access)
+// then moves 1 KB contiguous per instruction, and the row passes (a wave = 4 neighbouring rows) 256-byte pieces.
+__device__ __forceinline__ long long sidx(int r, int k) { return ((long long)((k >> 2) * kN + r) << 2) + (k & 3); }
+
 // ---------------------------------------------------------------------------------------------------- pass 1
 // grid (256 / 16, pairs): a workgroup transforms 16 rows, a wave 4 of them.
 __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConvArgs a) {
@@ -182,9 +187,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
         }
     }
     fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
-    cplx* s1 = a.s1 + ((long long)pair * kN + r) * kN;
+    cplx* s1 = a.s1 + (long long)pair * kN * kN;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s1[l + 16 * q] = v[q];
+    for (int q = 0; q < 16; ++q) s1[sidx(r, l + 16 * q)] = v[q];
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
@@ -195,26 +200,24 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
-    cplx* s1 = a.s1 + (long long)pair * kN * kN + k;
+    cplx* s1 = a.s1 + (long long)pair * kN * kN;
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = s1[(long long)(l + 16 * m) * kN];
+    for (int m = 0; m < 16; ++m) v[m] = s1[sidx(l + 16 * m, k)];
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
     if (mode == 1) {
-        cplx* kf = a.kf_out + k;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) kf[(long long)(l + 16 * q) * kN] = make_double2(v[q].x, -v[q].y);
+        for (int q = 0; q < 16; ++q) a.kf_out[sidx(l + 16 * q, k)] = make_double2(v[q].x, -v[q].y);
         return;
     }
-    const cplx* kf = a.kf + k;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], kf[(long long)(l + 16 * q) * kN]);
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], a.kf[sidx(l + 16 * q, k)]);
     fft256<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 16 * q < a.vy) s1[(long long)(l + 16 * q) * kN] = v[q];  // pass 3 never reads the rows past the valid outputs
+        if (l + 16 * q < a.vy) s1[sidx(l + 16 * q, k)] = v[q];  // pass 3 never reads the rows past the valid outputs
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -224,10 +227,10 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const cplx* s1 = a.s1 + ((long long)pair * kN + (live ? r : 0)) * kN;
+    const cplx* s1 = a.s1 + (long long)pair * kN * kN;
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = s1[l + 16 * m];
+    for (int m = 0; m < 16; ++m) v[m] = s1[sidx(live ? r : 0, l + 16 * m)];
     fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
     if (!live) return;
     float* dplane = a.dst.data + (long long)a.ch * a.dst.plane_stride;
