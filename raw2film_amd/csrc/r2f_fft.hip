@@ -139,10 +139,13 @@ __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, 
 
 __device__ __forceinline__ double* wave_tbuf(double* smem) { return smem + (threadIdx.x >> 6) * 4 * kTLine; }
 
-// Scratch / spectrum layout: element (r, k) of a 256 x 256 image sits at ((k / 4) * 256 + r) * 4 + k % 4, i.e. blocks of four
-// neighbouring columns are interleaved row by row.  The column pass (a wave = 4 neighbouring columns x 16 rows per access)
-// then moves 1 KB contiguous per instruction, and the row passes (a wave = 4 neighbouring rows) 256-byte pieces.
-__device__ __forceinline__ long long sidx(int r, int k) { return ((long long)((k >> 2) * kN + r) << 2) + (k & 3); }
+// Scratch / spectrum layout: 16 x 16 blocks [r / 16][k / 16] of 4 KB; inside a block four neighbouring columns are
+// interleaved row by row: [(k / 4) % 4][r % 16][k % 4].  The column pass (a wave = 4 neighbouring columns x 16 rows per
+// access) then moves 1 KB contiguous per instruction, and the row passes (a wave = 4 neighbouring rows x 16 columns) four
+// 256-byte pieces of one block.
+__device__ __forceinline__ long long sidx(int r, int k) {
+    return ((long long)((r >> 4) * 16 + (k >> 4)) << 8) + ((((k >> 2) & 3) * 16 + (r & 15)) << 2) + (k & 3);
+}
 
 // ---------------------------------------------------------------------------------------------------- pass 1
 // grid (256 / 16, pairs): a workgroup transforms 16 rows, a wave 4 of them.
