@@ -149,7 +149,7 @@ __device__ __forceinline__ long long sidx(int r, int k) {
 
 // ---------------------------------------------------------------------------------------------------- pass 1
 // grid (256 / 16, pairs): a workgroup transforms 16 rows, a wave 4 of them.
-__global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConvArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -157,7 +157,13 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
     const bool hasA = window_of(a, 2 * (a.pair0 + pair), wyA, wxA), hasB = window_of(a, 2 * (a.pair0 + pair) + 1, wyB, wxB);
     const float* src = a.src.data + (long long)a.ch * a.src.plane_stride;
     cplx v[16];
-    if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x 256 plane, no reflection
+#ifndef R2F_FFT_EXP
+#define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
+#endif
+    if (R2F_FFT_EXP & 1) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
+    } else if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x 256 plane, no reflection
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2((double)src[(long long)r * kN + l + 16 * m], 0.0);
     } else {
@@ -173,24 +179,40 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_fwd_kernel(const FftConv
         }
         // windows that do not touch the left / right frame edge (all but two per row of windows) need no reflection
         const bool inA = wxA >= 0 && wxA + kN <= a.W, inB = wxB >= 0 && wxB + kN <= a.W;
-        if ((!hasA || inA) && (!hasB || inB)) {
-            const float* pa = rowA + (hasA ? wxA : 0) + l;
-            const float* pb = rowB + (hasB ? wxB : 0) + l;
+        // all loads of a window are issued before the first one is used (a per-element `has ? load : 0` had compiled into
+        // thirty-two branches, each waiting for its own load)
+        float fa[16], fb[16];
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
-                v[m] = make_double2(hasA ? (double)pa[16 * m] : 0.0, hasB ? (double)pb[16 * m] : 0.0);
-        } else {
+        for (int m = 0; m < 16; ++m) fa[m] = fb[m] = 0.f;
+        if (hasA) {
+            if (inA) {
+                const float* pa = rowA + wxA + l;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int c = l + 16 * m;
-                const double re = hasA ? (double)rowA[reflect101(wxA + c, a.W)] : 0.0;
-                const double im = hasB ? (double)rowB[reflect101(wxB + c, a.W)] : 0.0;
-                v[m] = make_double2(re, im);
+                for (int m = 0; m < 16; ++m) fa[m] = pa[16 * m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) fa[m] = rowA[reflect101(wxA + l + 16 * m, a.W)];
             }
         }
+        if (hasB) {
+            if (inB) {
+                const float* pb = rowB + wxB + l;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) fb[m] = pb[16 * m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) fb[m] = rowB[reflect101(wxB + l + 16 * m, a.W)];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = make_double2((double)fa[m], (double)fb[m]);
     }
-    fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
+    if (!(R2F_FFT_EXP & 4)) fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
     cplx* s1 = a.s1 + (long long)pair * kN * kN;
+    if (R2F_FFT_EXP & 2) {
+        if (v[3].x == 1.2345e300) s1[0] = v[5];  // keep the transform alive without storing
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) s1[sidx(r, l + 16 * q)] = v[q];
 }
