@@ -70,7 +70,7 @@ struct r2f_ctx {
     double timing_bytes[3] = {0, 0, 0};
     int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
     int opt_fft_min_taps = 900;   // ... "large enough": cropped box of at least this many taps (and at most 129 x 129)
-    int opt_fft_batch = 1024;    // window pairs per batch (2 MB of scratch each)
+    int opt_fft_batch = 192;     // window pairs per launch triple: 192 MB of scratch stay inside the 256 MB Infinity Cache
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     int lanczos_key[4] = {0, 0, 0, 0};
     int opt_xcd_band = 0;  // tile columns per band of the xcd_remap = 2 order; 0 = auto
@@ -473,7 +473,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
     a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
     a.ax = set.kw / 2 - b[2];
     a.vy = kFftN - bh + 1;
-    a.vx = kFftN - bw + 1;
+    a.vx = (kFftN - bw + 1) & ~3;  // a multiple of 4: window origins stay 16-byte aligned for the float4 stores of pass 3
     int rc = ensure_bytes(ctx, ctx->fft_s1, img * sizeof(double2));
     if (rc) return rc;
     if (!ctx->fft_kf_valid[which][c]) {  // the kernel's spectrum: the same two forward passes on its zero-padded image
@@ -505,13 +505,14 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
     a.epilogue = epilogue;
     a.curve = ctx->curve;
     a.log_eps = log_eps;
+    a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
     const int pairs = (a.ntiles + 1) / 2, batch = std::min(pairs, ctx->opt_fft_batch);
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * img * sizeof(double2));
     if (rc) return rc;
     a.s1 = static_cast<double2*>(ctx->fft_s1.p);
     a.s2 = nullptr;
     auto timed = [&](int cls, double bytes, auto&& launch) -> int {
-        if (!ctx->opt_timing) {
+        if (!(ctx->opt_timing & (1 << cls))) {
             R2F_HIP(ctx, launch());
             return R2F_OK;
         }
@@ -677,7 +678,7 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         return R2F_OK;
     }
     if (!strcmp(name, "kernel_timing")) {
-        ctx->opt_timing = value ? 1 : 0;
+        ctx->opt_timing = value & 7;  // bit per pass: 1 rows forward, 2 columns, 4 rows inverse
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft")) {

@@ -254,10 +254,22 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
     const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
     const cplx* s1 = a.s1 + (long long)pair * kN * kN;
     cplx v[16];
+#ifndef R2F_FFT_EXP3
+#define R2F_FFT_EXP3 0  // development switch for pass 3: bit 0 no loads, bit 1 no stores, bit 2 no transform
+#endif
+    if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = s1[sidx(live ? r : 0, l + 16 * m)];
-    fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
+        for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = s1[sidx(live ? r : 0, l + 16 * m)];
+    }
+    if (!(R2F_FFT_EXP3 & 4)) fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
     if (!live) return;
+    if (R2F_FFT_EXP3 & 2) {
+        if (v[3].x == 1.2345e300) a.dst.data[0] = (float)v[5].y;
+        return;
+    }
     float* dplane = a.dst.data + (long long)a.ch * a.dst.plane_stride;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -265,14 +277,36 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
         if (!window_of(a, 2 * (a.pair0 + pair) + half, wy, wx)) continue;
         const int gy = wy + a.ay + r;
         if (gy >= a.y1) continue;
-        float* drow = dplane + (long long)(gy - a.dst.gy0) * a.W;
+        float* drow = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax + l;
+        // the 16 outputs of this lane first, then the curve on all of them at once (independent gathers), then the stores
+        float o[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = l + 16 * q, gx = wx + a.ax + c;
-            if (c >= a.vx || gx >= a.W) continue;
-            float o = (float)((half ? v[q].y : v[q].x) * (1.0 / 65536.0));
-            if (a.epilogue == 1) o = log_curve(a.curve, a.ch, o, a.log_eps);
-            drow[gx] = o;
+        for (int q = 0; q < 16; ++q) o[q] = (float)((half ? v[q].y : v[q].x) * (1.0 / 65536.0));
+        if (a.epilogue == 1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[q] = log10_fast(o[q], a.log_eps);
+            curve_eval_batch<16, 1>(a.curve.cells, a.curve, a.ch, o);
+        }
+        const int c_end = min(a.vx, a.W - (wx + a.ax));  // columns [0, c_end) of the window are valid outputs inside the frame
+        if (a.vec4) {
+            // lane l holds columns l + 16 q; through this line's (idle) transpose buffer every lane gets four neighbouring
+            // columns and stores them as one float4 (window origins and the frame width are multiples of 4 here)
+            float* tf = reinterpret_cast<float*>(wave_tbuf(fsm) + (lane >> 4) * kTLine);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tf[l + 16 * q] = o[q];
+            __builtin_amdgcn_wave_barrier();
+            float* dbase = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * (l + 16 * j);
+                const float4 val = *reinterpret_cast<const float4*>(tf + c);
+                if (c < c_end) *reinterpret_cast<float4*>(dbase + c) = val;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (l + 16 * q < c_end) drow[16 * q] = o[q];
         }
     }
 }

@@ -147,6 +147,7 @@ struct FftConvArgs {
     int epilogue;
     DevCurve curve;
     float log_eps;
+    int vec4;                 // 1: vx % 4 == 0, W % 4 == 0 and dst planes 16-byte aligned -> float4 stores in pass 3
 };
 hipError_t fft_init_attributes();
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s);

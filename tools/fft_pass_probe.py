@@ -16,7 +16,7 @@ params = proc.prepare(neg, 6, 0.4, (W, H), seed=1, print_film=prt, matrix=REC709
 out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 for _ in range(2): ctx.render(img, params, out_f32=out)
 torch.cuda.synchronize()
-ctx.set_option("kernel_timing", 1)
+ctx.set_option("kernel_timing", 7)
 for c in range(3): ctx.kernel_timing(c)
 N = 5
 for _ in range(N): ctx.render(img, params, out_f32=out)
