@@ -1,0 +1,127 @@
+"""The fp64 overlap-save FFT form of the large stencils (r2f_fft.hip) against the oracle and against the direct form:
+kernel sizes around the eligibility limits, frames smaller than one window, odd widths (scalar store path), row ranges with
+halo rows (what a row shard calls), batching, arbitrary (non-symmetric, signed) taps."""
+
+import numpy as np
+import pytest
+
+from oracle import kernels as ok
+from oracle import stages as st
+
+from helpers import assert_close, stocks
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture()
+def ctx():
+    from raw2film_amd.context import HipContext
+
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def planes(a):
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(a, (2, 0, 1)))).cuda()
+
+
+def run(ctx, which, img, k, fft, rows=None, **opts):
+    H, W = img.shape[:2]
+    ctx.set_option("stencil_fft", fft)
+    for name, v in opts.items():
+        ctx.set_option(name, v)
+    ctx.set_kernel(which, k)
+    y0, y1 = rows or (0, H)
+    dst = torch.zeros((3, y1 - y0, W), dtype=torch.float32, device="cuda")
+    ctx.stage_stencil(which, planes(img), dst, dst_gy0=y0, y0=y0, y1=y1, H_global=H)
+    return np.transpose(dst.cpu().numpy(), (1, 2, 0))
+
+
+def uses_fft(ctx, which):
+    return [c["fft"] for c in ctx.stencil_stats(which)]
+
+
+@pytest.mark.parametrize("shape", [(300, 417), (64, 64), (1, 7), (9, 1), (257, 256), (173, 344), (601, 130)])
+def test_fft_form_matches_oracle_and_direct_form(ctx, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.uniform(0.0, 2.0, shape + (3,)).astype(np.float32)
+    img[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = 500.0  # a specular next to shadows: the fp32-FFT killer
+    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 x 87, blue plane = identity
+    a = run(ctx, 0, img, k, 1)
+    assert uses_fft(ctx, 0) == [1, 1, 0]
+    b = run(ctx, 0, img, k, 0)
+    ref = st.convolve_2d(img, k)
+    assert_close(a, ref, 2e-6, 1e-2, "fft form")  # fp64 inside: an order of magnitude tighter than the fp32 direct sum needs
+    assert_close(b, ref, 1e-5, 1e-2, "direct form")
+    np.testing.assert_array_equal(a[..., 2], b[..., 2])  # the identity plane runs the direct kernel either way
+
+
+def test_eligibility_limits(ctx):
+    img = np.random.default_rng(1).uniform(0, 1, (140, 150, 3)).astype(np.float32)
+    rng = np.random.default_rng(2)
+    for n, expect in ((29, 0), (31, 1), (129, 1), (131, 0)):  # >= 900 taps and at most 129 x 129
+        k = rng.uniform(-0.2, 1.0, (n, n, 1)).astype(np.float32)
+        k /= k.sum()
+        out = run(ctx, 1, img, k, 1)
+        assert uses_fft(ctx, 1) == [expect] * 3, n
+        assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-2, f"{n} taps")
+    # rectangular boxes count too
+    k = np.zeros((87, 87, 1), np.float32)
+    k[40:47, :, 0] = rng.uniform(0, 1, (7, 87))  # 7 x 87 = 609 taps: direct
+    run(ctx, 1, img, k / k.sum(), 1)
+    assert uses_fft(ctx, 1) == [0, 0, 0]
+    ctx.set_option("stencil_fft_min_taps", 500)
+    out = run(ctx, 1, img, k / k.sum(), 1)
+    assert uses_fft(ctx, 1) == [1, 1, 1]
+    assert_close(out, st.convolve_2d(img, np.repeat(k / k.sum(), 3, axis=2)), 1e-5, 1e-2, "7 x 87 by FFT")
+
+
+def test_arbitrary_taps_and_anchor(ctx):
+    """Nothing symmetric, negative taps, an off-centre bounding box: the anchor stays cv.filter2D's (kh/2, kw/2)."""
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 1, (200, 310, 3)).astype(np.float32)
+    k = np.zeros((61, 45, 3), np.float32)
+    k[5:50, 3:40] = rng.normal(0, 1, (45, 37, 3))  # box off-centre inside the 61 x 45 stencil
+    out = run(ctx, 1, img, k, 1)
+    assert uses_fft(ctx, 1) == [1, 1, 1]
+    assert_close(out, st.convolve_2d(img, k), 1e-5, 1.0, "arbitrary taps")
+
+
+def test_row_range_with_halo_rows_equals_the_whole_frame_to_rounding(ctx):
+    rng = np.random.default_rng(4)
+    H, W = 700, 260
+    img = rng.uniform(0, 2, (H, W, 3)).astype(np.float32)
+    k = ok.compute_halation_kernel(229.33, halation_green_factor=0.3)  # 59 x 59
+    whole = run(ctx, 0, img, k, 1)
+    r = k.shape[0] // 2
+    for y0, y1 in ((0, 300), (300, 301), (301, 700)):
+        lo, hi = max(y0 - r, 0), min(y1 + r, H)
+        ctx.set_kernel(0, k)
+        src = planes(img[lo:hi])
+        dst = torch.zeros((3, y1 - y0, W), dtype=torch.float32, device="cuda")
+        ctx.stage_stencil(0, src, dst, src_gy0=lo, dst_gy0=y0, y0=y0, y1=y1, H_global=H)
+        part = np.transpose(dst.cpu().numpy(), (1, 2, 0))
+        assert np.abs(part - whole[y0:y1]).max() <= 5e-7  # other windows, same fp64 arithmetic: at most an ulp of fp32
+
+
+def test_batching_does_not_change_a_bit(ctx):
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 2, (520, 530, 3)).astype(np.float32)
+    k = ok.mtf_kernel(stocks()[0].mtf, 341.33)  # 35 x 35 x 3: 9 windows per channel
+    ref = run(ctx, 1, img, k, 1)
+    for batch in (1, 2, 3, 7):
+        np.testing.assert_array_equal(run(ctx, 1, img, k, 1, stencil_fft_batch=batch), ref)
+
+
+def test_kernel_change_rebuilds_the_spectrum(ctx):
+    rng = np.random.default_rng(6)
+    img = rng.uniform(0, 1, (90, 120, 3)).astype(np.float32)
+    k1 = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)
+    k2 = ok.compute_halation_kernel(341.33, halation_green_factor=1.0, halation_intensity=2.0)
+    a = run(ctx, 0, img, k1, 1)
+    b = run(ctx, 0, img, k2, 1)
+    assert_close(a, st.convolve_2d(img, k1), 2e-6, 1e-2, "first kernel")
+    assert_close(b, st.convolve_2d(img, k2), 2e-6, 1e-2, "second kernel")
+    np.testing.assert_array_equal(run(ctx, 0, img, k1, 1), a)
