@@ -592,9 +592,19 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     // large kernels take the fp64 FFT form channel by channel; the direct kernel runs the rest
     a.nchan = 0;
     for (int c = 0; c < 3; ++c) {
+        int tb[4];
+        tap_box(set, c, tb);
         if (fft_eligible(ctx, set, c)) {
             rc = run_stencil_fft(ctx, which, c, src, dst, y0, y1, W, H, epilogue, log_eps, s);
             if (rc) return rc;
+        } else if (tb[0] == tb[1] && tb[2] == tb[3] && tb[0] == set.kh / 2 && tb[2] == set.kw / 2 && ctx->opt_ablate == 0) {
+            TapArgs t;  // a single tap at the anchor: pointwise
+            t.src = to_dev(src), t.dst = to_dev(dst);
+            t.ch = c, t.y0 = y0, t.y1 = y1, t.W = W;
+            t.w = set.host[((size_t)tb[0] * set.kw + tb[2]) * set.kc + (set.kc == 1 ? 0 : c)];
+            t.epilogue = epilogue, t.curve = ctx->curve, t.log_eps = log_eps;
+            t.vec = (planes_vec_ok(src, W) && planes_vec_ok(dst, W)) ? 1 : 0;
+            R2F_HIP(ctx, launch_single_tap(t, s));
         } else {
             a.chan[a.nchan++] = c;
         }

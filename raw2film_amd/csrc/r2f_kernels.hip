@@ -376,6 +376,37 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     }
 }
 
+// ------------------------------------------------------------------------------ single-tap stencil channel
+// The blue plane of the colour-stock halation is the identity (effects.py:248-263: f_b = 0): one tap of weight 1 at the
+// anchor.  Pointwise, 4 B + 4 B per pixel, instead of the tiled kernel's LDS round trip.
+__global__ __launch_bounds__(256) void single_tap_kernel(const TapArgs a) {
+    const int gy = a.y0 + blockIdx.y;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= a.W) return;
+    const float* s = a.src.data + (long long)a.ch * a.src.plane_stride + (long long)(gy - a.src.gy0) * a.W + x;
+    float* d = a.dst.data + (long long)a.ch * a.dst.plane_stride + (long long)(gy - a.dst.gy0) * a.W + x;
+    const int nv = min(4, a.W - x);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.vec && nv == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(s);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    } else {
+        for (int p = 0; p < nv; ++p) v[p] = s[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p] = a.w * v[p];
+    if (a.epilogue == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p] = log10_fast(v[p], a.log_eps);
+        curve_eval_batch<4, 1>(a.curve.cells, a.curve, a.ch, v);
+    }
+    if (a.vec && nv == 4) {
+        *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int p = 0; p < nv; ++p) d[p] = v[p];
+    }
+}
+
 // ------------------------------------------------------------------------------ tail (grain)
 __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -970,6 +1001,12 @@ hipError_t launch_resize_area(const ResizeArgs& a, hipStream_t s) {
 hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s) {
     if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
     hipLaunchKernelGGL(warp_affine_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_single_tap(const TapArgs& a, hipStream_t s) {
+    if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    hipLaunchKernelGGL(single_tap_kernel, dim3((a.W + 1023) / 1024, a.y1 - a.y0), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -128,6 +128,18 @@ struct LanczosArgs {
     const short* ycoef;  // out_h x 8
 };
 
+// A channel whose stencil has a single tap (the halation's identity plane): dst = epilogue(w * src) over rows [y0, y1).
+struct TapArgs {
+    DevPlanes src, dst;
+    int ch, y0, y1, W;
+    float w;
+    int epilogue;
+    DevCurve curve;
+    float log_eps;
+    int vec;
+};
+hipError_t launch_single_tap(const TapArgs& a, hipStream_t s);
+
 // Overlap-save FFT form of a large stencil (r2f_fft.hip): one channel, windows [pair0*2, (pair0+npairs)*2) of the launch.
 constexpr int kFftN = 256;
 struct FftConvArgs {
