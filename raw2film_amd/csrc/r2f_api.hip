@@ -451,12 +451,13 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     return bh <= kFftN / 2 + 1 && bw <= kFftN / 2 + 1 && bh * bw >= ctx->opt_fft_min_taps;
 }
 
-// One channel of a stencil as an fp64 overlap-save FFT correlation (r2f_fft.hip).
-int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
-                    int epilogue, float log_eps, hipStream_t s) {
+// The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
+// their window pairs share the launches.
+int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2f_planes* src, const r2f_planes* dst, int y0, int y1,
+                    int W, int H, int epilogue, float log_eps, hipStream_t s) {
     StencilSet& set = ctx->stencil[which];
     int b[4];
-    tap_box(set, c, b);
+    tap_box(set, chans[0], b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
     const size_t img = (size_t)kFftN * kFftN;
     if (!ctx->fft_tw.p) {
@@ -477,11 +478,14 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
     a.vx = (kFftN - bw + 1) & ~3;  // a multiple of 4: window origins stay 16-byte aligned for the float4 stores of pass 3
     int rc = ensure_bytes(ctx, ctx->fft_s1, img * sizeof(double2));
     if (rc) return rc;
-    if (!ctx->fft_kf_valid[which][c]) {  // the kernel's spectrum: the same two forward passes on its zero-padded image
+    for (int i = 0; i < nch; ++i) {
+        const int c = chans[i];
+        if (ctx->fft_kf_valid[which][c]) continue;
+        // the kernel's spectrum: the same two forward passes on its zero-padded image
         std::vector<float> kimg(img, 0.f);
         const int kc = set.kc == 1 ? 0 : c;
-        for (int i = 0; i < bh; ++i)
-            for (int j = 0; j < bw; ++j) kimg[(size_t)i * kFftN + j] = set.host[((size_t)(b[0] + i) * set.kw + b[2] + j) * set.kc + kc];
+        for (int y = 0; y < bh; ++y)
+            for (int x = 0; x < bw; ++x) kimg[(size_t)y * kFftN + x] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
         rc = upload(ctx, ctx->fft_kimg, kimg.data(), img * sizeof(float));
         if (rc) return rc;
         rc = ensure_bytes(ctx, ctx->fft_kf[which][c], img * sizeof(double2));
@@ -489,6 +493,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
         FftConvArgs k = a;
         k.src.data = static_cast<float*>(ctx->fft_kimg.p);
         k.raw = 1;
+        k.nch = 1, k.chan[0] = 0, k.ppc = 1;
         k.ntiles = 1, k.gx = 1, k.npairs = 1, k.pair0 = 0;
         k.s1 = static_cast<double2*>(ctx->fft_s1.p);
         k.kf_out = static_cast<double2*>(ctx->fft_kf[which][c].p);
@@ -498,16 +503,20 @@ int run_stencil_fft(r2f_ctx* ctx, int which, int c, const r2f_planes* src, const
     }
     a.src = to_dev(src);
     a.dst = to_dev(dst);
-    a.ch = c;
+    a.nch = nch;
+    for (int i = 0; i < nch; ++i) {
+        a.chan[i] = chans[i];
+        a.kfs[i] = static_cast<const double2*>(ctx->fft_kf[which][chans[i]].p);
+    }
     a.y0 = y0, a.y1 = y1, a.W = W, a.H_global = H;
     a.gx = (W + a.vx - 1) / a.vx;
     a.ntiles = a.gx * ((y1 - y0 + a.vy - 1) / a.vy);
-    a.kf = static_cast<const double2*>(ctx->fft_kf[which][c].p);
+    a.ppc = (a.ntiles + 1) / 2;
     a.epilogue = epilogue;
     a.curve = ctx->curve;
     a.log_eps = log_eps;
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
-    const int pairs = (a.ntiles + 1) / 2, batch = std::min(pairs, ctx->opt_fft_batch);
+    const int pairs = a.ppc * nch, batch = std::min(pairs, ctx->opt_fft_batch);
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * img * sizeof(double2));
     if (rc) return rc;
     a.s1 = static_cast<double2*>(ctx->fft_s1.p);
@@ -589,13 +598,22 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
     a.epilogue = epilogue;
     a.curve = ctx->curve;
     a.log_eps = log_eps;
-    // large kernels take the fp64 FFT form channel by channel; the direct kernel runs the rest
+    // large kernels take the fp64 FFT form (channels with the same tap box share their launches); single taps are
+    // pointwise; the direct kernel runs the rest
     a.nchan = 0;
+    bool done[3] = {false, false, false};
     for (int c = 0; c < 3; ++c) {
+        if (done[c]) continue;
         int tb[4];
         tap_box(set, c, tb);
         if (fft_eligible(ctx, set, c)) {
-            rc = run_stencil_fft(ctx, which, c, src, dst, y0, y1, W, H, epilogue, log_eps, s);
+            int group[3], ng = 0;
+            for (int d = c; d < 3; ++d) {
+                int ob[4];
+                tap_box(set, d, ob);
+                if (!done[d] && fft_eligible(ctx, set, d) && !memcmp(ob, tb, sizeof tb)) group[ng++] = d, done[d] = true;
+            }
+            rc = run_stencil_fft(ctx, which, group, ng, src, dst, y0, y1, W, H, epilogue, log_eps, s);
             if (rc) return rc;
         } else if (tb[0] == tb[1] && tb[2] == tb[3] && tb[0] == set.kh / 2 && tb[2] == set.kw / 2 && ctx->opt_ablate == 0) {
             TapArgs t;  // a single tap at the anchor: pointwise

@@ -154,8 +154,9 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
-    const bool hasA = window_of(a, 2 * (a.pair0 + pair), wyA, wxA), hasB = window_of(a, 2 * (a.pair0 + pair) + 1, wyB, wxB);
-    const float* src = a.src.data + (long long)a.ch * a.src.plane_stride;
+    const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc;  // channel-major pair numbering
+    const bool hasA = window_of(a, 2 * pc, wyA, wxA), hasB = window_of(a, 2 * pc + 1, wyB, wxB);
+    const float* src = a.src.data + (long long)a.chan[ci] * a.src.plane_stride;
     cplx v[16];
 #ifndef R2F_FFT_EXP
 #define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
@@ -232,13 +233,14 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
+    const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
     if (mode == 1) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) a.kf_out[sidx(l + 16 * q, k)] = make_double2(v[q].x, -v[q].y);
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], a.kf[sidx(l + 16 * q, k)]);
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], kf[sidx(l + 16 * q, k)]);
     fft256<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
@@ -270,11 +272,12 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
         if (v[3].x == 1.2345e300) a.dst.data[0] = (float)v[5].y;
         return;
     }
-    float* dplane = a.dst.data + (long long)a.ch * a.dst.plane_stride;
+    const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc, ch = a.chan[ci];
+    float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         int wy, wx;
-        if (!window_of(a, 2 * (a.pair0 + pair) + half, wy, wx)) continue;
+        if (!window_of(a, 2 * pc + half, wy, wx)) continue;
         const int gy = wy + a.ay + r;
         if (gy >= a.y1) continue;
         float* drow = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax + l;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
         if (a.epilogue == 1) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) o[q] = log10_fast(o[q], a.log_eps);
-            curve_eval_batch<16, 1>(a.curve.cells, a.curve, a.ch, o);
+            curve_eval_batch<16, 1>(a.curve.cells, a.curve, ch, o);
         }
         const int c_end = min(a.vx, a.W - (wx + a.ax));  // columns [0, c_end) of the window are valid outputs inside the frame
         if (a.vec4) {

@@ -144,7 +144,8 @@ hipError_t launch_single_tap(const TapArgs& a, hipStream_t s);
 constexpr int kFftN = 256;
 struct FftConvArgs {
     DevPlanes src, dst;
-    int ch;                   // plane of src / dst, channel of the curve
+    int nch, chan[3];         // channels of this launch (planes of src / dst, curve channels); pairs are numbered channel-major
+    int ppc;                  // window pairs per channel
     int y0, y1, W, H_global;  // output rows [y0, y1) of the global frame
     int ay, ax;               // anchor inside the cropped kernel box
     int vy, vx;               // valid outputs per window: 256 - kh + 1, 256 - kw + 1
@@ -152,7 +153,7 @@ struct FftConvArgs {
     int pair0, npairs;
     int raw;                  // 1: src is the zero-padded 256 x 256 kernel image itself (kernel-spectrum build)
     const double2* tw;        // exp(-2 pi i k / 256), k < 256
-    const double2* kf;        // conj of the kernel's 2-D spectrum, [r'][k]
+    const double2* kfs[3];    // per launch channel: conj of the kernel's 2-D spectrum (scratch layout)
     double2* kf_out;          // pass 2, mode 1
     double2* s1;              // npairs x 256 x 256 scratch images S[r][k], transformed in place
     double2* s2;              // unused
