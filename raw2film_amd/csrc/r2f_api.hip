@@ -69,7 +69,7 @@ struct r2f_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev[3];
     double timing_bytes[3] = {0, 0, 0};
     int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
-    int opt_fft_min_taps = 400;   // ... "large enough": cropped box of at least this many taps (and at most 129 x 129);
+    int opt_fft_min_taps = 400;   // ... "large enough": cropped box of at least this many taps (and at most 200 x 200);
                                  // measured crossover with the direct form: 17 x 17 ties, 23 x 23 is 1.5x faster by FFT
     int opt_fft_batch = 192;     // window pairs per launch triple: 192 MB of scratch stay inside the 256 MB Infinity Cache
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
@@ -448,7 +448,9 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     int b[4];
     tap_box(s, c, b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
-    return bh <= kFftN / 2 + 1 && bw <= kFftN / 2 + 1 && bh * bw >= ctx->opt_fft_min_taps;
+    // up to 200 taps a side: a 256-point window then still yields 57 x 56 outputs, and the FFT form stays ahead of the direct
+    // sum (whose cost grows with the tap count) until ~220
+    return bh <= 200 && bw <= 200 && bh * bw >= ctx->opt_fft_min_taps;
 }
 
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);

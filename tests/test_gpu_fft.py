@@ -61,7 +61,7 @@ def test_fft_form_matches_oracle_and_direct_form(ctx, shape):
 def test_eligibility_limits(ctx):
     img = np.random.default_rng(1).uniform(0, 1, (140, 150, 3)).astype(np.float32)
     rng = np.random.default_rng(2)
-    for n, expect in ((19, 0), (21, 1), (129, 1), (131, 0)):  # >= 400 taps and at most 129 x 129
+    for n, expect in ((19, 0), (21, 1), (129, 1), (171, 1), (199, 1), (201, 0)):  # >= 400 taps and at most 200 x 200
         k = rng.uniform(-0.2, 1.0, (n, n, 1)).astype(np.float32)
         k /= k.sum()
         out = run(ctx, 1, img, k, 1)
