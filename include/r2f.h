@@ -102,7 +102,10 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int 
 /* --- whole-frame render: CpuProcessor.process hot loop cpu_processor.py:363-407,
  *     GpuProcessor._execute_gpu_pipeline gpu_processor.py:1756-1877 ---
  * in: device image (in_layout), H x W.  out_f32_hwc / out_u8_hwc: device (H, W, 3), either may be NULL.
- * workspace: device scratch of at least r2f_workspace_bytes(...) bytes (caller-owned). */
+ * workspace: device scratch of at least r2f_workspace_bytes(...) bytes (caller-owned): the plane sets between the stages.
+ * Stencils of >= 400 taps run as fp64 overlap-save FFTs (like cv.filter2D's own DFT branch above 11 x 11 taps, which the
+ * reference's CPU path takes for both of them); their pass scratch (1 MiB per window pair in flight, 192 by default) and
+ * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use. */
 size_t r2f_workspace_bytes(const r2f_params* p, int H, int W);
 int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32_hwc,
                uint8_t* out_u8_hwc, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
