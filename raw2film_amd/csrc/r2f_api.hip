@@ -71,6 +71,11 @@ struct r2f_ctx {
     int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
     int opt_fft_min_taps = 400;   // ... "large enough": cropped box of at least this many taps (and at most 200 x 200);
                                  // measured crossover with the direct form: 17 x 17 ties, 23 x 23 is 1.5x faster by FFT
+    // two internal streams take alternate batches (each with its own half of the scratch), so the tail of one launch
+    // overlaps the head of the other stream's; fenced against the caller's stream with events
+    hipStream_t fft_stream[2] = {nullptr, nullptr};
+    hipEvent_t fft_ev_in = nullptr, fft_ev_out[2] = {nullptr, nullptr};
+    int opt_fft_streams = 2;
     int opt_fft_batch = 192;     // window pairs per launch triple: 192 MB of scratch stay inside the 256 MB Infinity Cache
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     int lanczos_key[4] = {0, 0, 0, 0};
@@ -518,12 +523,25 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.curve = ctx->curve;
     a.log_eps = log_eps;
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
-    const int pairs = a.ppc * nch, batch = std::min(pairs, ctx->opt_fft_batch);
-    rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * img * sizeof(double2));
+    const int pairs = a.ppc * nch;
+    // batches alternate between two internal streams when there is enough work for that to matter
+    const int nstreams = (ctx->opt_fft_streams == 2 && pairs > ctx->opt_fft_batch) ? 2 : 1;
+    const int batch = std::min(pairs, std::max(1, ctx->opt_fft_batch / nstreams));
+    rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img * sizeof(double2));
     if (rc) return rc;
-    a.s1 = static_cast<double2*>(ctx->fft_s1.p);
     a.s2 = nullptr;
-    auto timed = [&](int cls, double bytes, auto&& launch) -> int {
+    hipStream_t lanes[2] = {s, s};
+    if (nstreams == 2) {
+        for (int i = 0; i < 2; ++i) {
+            if (!ctx->fft_stream[i]) R2F_HIP(ctx, hipStreamCreateWithFlags(&ctx->fft_stream[i], hipStreamNonBlocking));
+            if (!ctx->fft_ev_out[i]) R2F_HIP(ctx, hipEventCreateWithFlags(&ctx->fft_ev_out[i], hipEventDisableTiming));
+            lanes[i] = ctx->fft_stream[i];
+        }
+        if (!ctx->fft_ev_in) R2F_HIP(ctx, hipEventCreateWithFlags(&ctx->fft_ev_in, hipEventDisableTiming));
+        R2F_HIP(ctx, hipEventRecord(ctx->fft_ev_in, s));  // everything queued on the caller's stream so far (src, spectra)
+        for (int i = 0; i < 2; ++i) R2F_HIP(ctx, hipStreamWaitEvent(lanes[i], ctx->fft_ev_in, 0));
+    }
+    auto timed = [&](int cls, double bytes, hipStream_t st, auto&& launch) -> int {
         if (!(ctx->opt_timing & (1 << cls))) {
             R2F_HIP(ctx, launch());
             return R2F_OK;
@@ -531,26 +549,35 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         hipEvent_t e0, e1;
         R2F_HIP(ctx, hipEventCreate(&e0));
         R2F_HIP(ctx, hipEventCreate(&e1));
-        R2F_HIP(ctx, hipEventRecord(e0, s));
+        R2F_HIP(ctx, hipEventRecord(e0, st));
         R2F_HIP(ctx, launch());
-        R2F_HIP(ctx, hipEventRecord(e1, s));
+        R2F_HIP(ctx, hipEventRecord(e1, st));
         ctx->timing_ev[cls].push_back({e0, e1});
         ctx->timing_bytes[cls] += bytes;
         return R2F_OK;
     };
-    for (int p0 = 0; p0 < pairs; p0 += batch) {
+    int turn = 0;
+    for (int p0 = 0; p0 < pairs; p0 += batch, turn ^= 1) {
+        const int li = nstreams == 2 ? turn : 0;
+        hipStream_t st = lanes[li];
         a.pair0 = p0;
         a.npairs = std::min(batch, pairs - p0);
+        a.s1 = static_cast<double2*>(ctx->fft_s1.p) + (size_t)li * batch * img;
         // algorithmic bytes of the passes: window floats in (2 per pair) + scratch image out; scratch in + valid rows out;
         // valid rows in + valid outputs out.  The kernel spectrum (1 MB) stays in L2.
         const double np = a.npairs, full = (double)img * sizeof(double2), part = full * a.vy / kFftN;
-        rc = timed(0, np * (2.0 * img * sizeof(float) + full), [&] { return launch_fft_rows_fwd(a, s); });
+        rc = timed(0, np * (2.0 * img * sizeof(float) + full), st, [&] { return launch_fft_rows_fwd(a, st); });
         if (rc) return rc;
-        rc = timed(1, np * (full + part), [&] { return launch_fft_cols(a, 0, s); });
+        rc = timed(1, np * (full + part), st, [&] { return launch_fft_cols(a, 0, st); });
         if (rc) return rc;
-        rc = timed(2, np * (part + 2.0 * a.vy * a.vx * sizeof(float)), [&] { return launch_fft_rows_inv(a, s); });
+        rc = timed(2, np * (part + 2.0 * a.vy * a.vx * sizeof(float)), st, [&] { return launch_fft_rows_inv(a, st); });
         if (rc) return rc;
     }
+    if (nstreams == 2)
+        for (int i = 0; i < 2; ++i) {
+            R2F_HIP(ctx, hipEventRecord(ctx->fft_ev_out[i], lanes[i]));
+            R2F_HIP(ctx, hipStreamWaitEvent(s, ctx->fft_ev_out[i], 0));
+        }
     return R2F_OK;
 }
 
@@ -683,6 +710,11 @@ void r2f_destroy(r2f_ctx* ctx) {
     ctx->fft_kimg.release();
     for (auto& row : ctx->fft_kf)
         for (auto& b : row) b.release();
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->fft_stream[i]) (void)hipStreamDestroy(ctx->fft_stream[i]);
+        if (ctx->fft_ev_out[i]) (void)hipEventDestroy(ctx->fft_ev_out[i]);
+    }
+    if (ctx->fft_ev_in) (void)hipEventDestroy(ctx->fft_ev_in);
     delete ctx;
 }
 
@@ -718,6 +750,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "stencil_fft_min_taps")) {
         ctx->opt_fft_min_taps = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_streams")) {
+        if (value < 1 || value > 2) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be 1 or 2");
+        ctx->opt_fft_streams = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_batch")) {
