@@ -73,8 +73,8 @@ struct r2f_ctx {
                                  // measured crossover with the direct form: 17 x 17 ties, 23 x 23 is 1.5x faster by FFT
     // two internal streams take alternate batches (each with its own half of the scratch), so the tail of one launch
     // overlaps the head of the other stream's; fenced against the caller's stream with events
-    hipStream_t fft_stream[2] = {nullptr, nullptr};
-    hipEvent_t fft_ev_in = nullptr, fft_ev_out[2] = {nullptr, nullptr};
+    hipStream_t fft_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fft_ev_in = nullptr, fft_ev_out[4] = {nullptr, nullptr, nullptr, nullptr};
     int opt_fft_streams = 2;
     int opt_fft_batch = 192;     // window pairs per launch triple: 192 MB of scratch stay inside the 256 MB Infinity Cache
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
@@ -525,21 +525,21 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
     const int pairs = a.ppc * nch;
     // batches alternate between two internal streams when there is enough work for that to matter
-    const int nstreams = (ctx->opt_fft_streams == 2 && pairs > ctx->opt_fft_batch) ? 2 : 1;
+    const int nstreams = pairs > ctx->opt_fft_batch ? ctx->opt_fft_streams : 1;
     const int batch = std::min(pairs, std::max(1, ctx->opt_fft_batch / nstreams));
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img * sizeof(double2));
     if (rc) return rc;
     a.s2 = nullptr;
-    hipStream_t lanes[2] = {s, s};
-    if (nstreams == 2) {
-        for (int i = 0; i < 2; ++i) {
+    hipStream_t lanes[4] = {s, s, s, s};
+    if (nstreams > 1) {
+        for (int i = 0; i < nstreams; ++i) {
             if (!ctx->fft_stream[i]) R2F_HIP(ctx, hipStreamCreateWithFlags(&ctx->fft_stream[i], hipStreamNonBlocking));
             if (!ctx->fft_ev_out[i]) R2F_HIP(ctx, hipEventCreateWithFlags(&ctx->fft_ev_out[i], hipEventDisableTiming));
             lanes[i] = ctx->fft_stream[i];
         }
         if (!ctx->fft_ev_in) R2F_HIP(ctx, hipEventCreateWithFlags(&ctx->fft_ev_in, hipEventDisableTiming));
         R2F_HIP(ctx, hipEventRecord(ctx->fft_ev_in, s));  // everything queued on the caller's stream so far (src, spectra)
-        for (int i = 0; i < 2; ++i) R2F_HIP(ctx, hipStreamWaitEvent(lanes[i], ctx->fft_ev_in, 0));
+        for (int i = 0; i < nstreams; ++i) R2F_HIP(ctx, hipStreamWaitEvent(lanes[i], ctx->fft_ev_in, 0));
     }
     auto timed = [&](int cls, double bytes, hipStream_t st, auto&& launch) -> int {
         if (!(ctx->opt_timing & (1 << cls))) {
@@ -557,8 +557,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         return R2F_OK;
     };
     int turn = 0;
-    for (int p0 = 0; p0 < pairs; p0 += batch, turn ^= 1) {
-        const int li = nstreams == 2 ? turn : 0;
+    for (int p0 = 0; p0 < pairs; p0 += batch, turn = (turn + 1) % nstreams) {
+        const int li = turn;
         hipStream_t st = lanes[li];
         a.pair0 = p0;
         a.npairs = std::min(batch, pairs - p0);
@@ -573,8 +573,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         rc = timed(2, np * (part + 2.0 * a.vy * a.vx * sizeof(float)), st, [&] { return launch_fft_rows_inv(a, st); });
         if (rc) return rc;
     }
-    if (nstreams == 2)
-        for (int i = 0; i < 2; ++i) {
+    if (nstreams > 1)
+        for (int i = 0; i < nstreams; ++i) {
             R2F_HIP(ctx, hipEventRecord(ctx->fft_ev_out[i], lanes[i]));
             R2F_HIP(ctx, hipStreamWaitEvent(s, ctx->fft_ev_out[i], 0));
         }
@@ -710,7 +710,7 @@ void r2f_destroy(r2f_ctx* ctx) {
     ctx->fft_kimg.release();
     for (auto& row : ctx->fft_kf)
         for (auto& b : row) b.release();
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (ctx->fft_stream[i]) (void)hipStreamDestroy(ctx->fft_stream[i]);
         if (ctx->fft_ev_out[i]) (void)hipEventDestroy(ctx->fft_ev_out[i]);
     }
@@ -753,7 +753,7 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_streams")) {
-        if (value < 1 || value > 2) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be 1 or 2");
+        if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
         return R2F_OK;
     }
