@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--config", default="cfg4_100mp", choices=["cfg4_100mp", "cfg3_45mp", "cfg2_24mp", "cfg5_batch"])
     ap.add_argument("--frames", type=int, default=64, help="cfg5_batch: frames per step, dealt round-robin to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--side-grain", action="store_true", help="A/B: make the grain field on a side stream while the stencils run")
     ap.add_argument("--direct-stencils", action="store_true", help="A/B: run the stencils in their direct fp32 form instead of fp64 FFTs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the measured configuration); gloo + --same-device validates the N > 1 code path on one GPU")
@@ -99,7 +100,7 @@ def main():
         renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, rank=0, world=1)
         frames_here = len([i for i in range(args.frames) if i % world == rank])
     else:
-        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects)
+        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, side_grain=args.side_grain)
         frames_here = 1
     r0, r1 = renderer.plan.r0, renderer.plan.r1
 

@@ -132,6 +132,16 @@ int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_i
 int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const float* burn_map,
                    float* out_f32_hwc, uint8_t* out_u8_hwc, int out_gy0, int y0, int y1, int W, int H_global,
                    void* stream);
+/* The grain in two halves, so that the first can run on another stream while the stencils run: r2f_stage_grain_field writes
+ * the grain field G = K_g * N (noise.wgsl + the convolution of grain.wgsl:63-75; a function of the seed and the pixel
+ * coordinates only) for rows [y0, y1) to `field` planes; r2f_stage_tail_field is r2f_stage_tail with that field applied
+ * pointwise (out = D + G * lut(D), clip, 3-D LUT) instead of being generated in the same kernel.  Same arithmetic, same
+ * results as r2f_stage_tail.  Not combinable with a burn map (use r2f_stage_grain there). */
+int r2f_stage_grain_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* field, int y0, int y1, int W, int H_global,
+                          void* stream);
+int r2f_stage_tail_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* field, float* out_f32,
+                         uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream);
+
 /* S6 grain + clip alone, density planes -> density planes (the first half of the tail when S7 is on: the burn map
  * is a function of the WHOLE grained frame, so the frame has to exist before any pixel can be finished). */
 int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,

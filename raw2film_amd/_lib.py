@@ -118,6 +118,11 @@ _SIGNATURES = {
     "r2f_resize_lanczos4_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "r2f_lanczos4_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "r2f_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int), _P(C.c_double)]),
+    "r2f_stage_grain_field": (C.c_int, [C.c_void_p, _P(Params), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "r2f_stage_tail_field": (
+        C.c_int,
+        [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
     "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -237,6 +237,21 @@ class HipContext:
         )
         self._check(rc)
 
+    def stage_grain_field(self, field, params, *, dst_gy0=0, y0, y1, H_global):
+        """The grain field K_g * N for rows [y0, y1) -> (3, rows, W) planes; no image involved."""
+        pf = self.planes(field, dst_gy0)
+        self._check(self._lib.r2f_stage_grain_field(self._h, C.byref(params), C.byref(pf), y0, y1, int(field.shape[2]), H_global,
+                                                    self._stream()))
+
+    def stage_tail_field(self, density, field, params, *, src_gy0=0, field_gy0=0, out_f32=None, out_u8=None, out_gy0=0, y0, y1,
+                         H_global):
+        """stage_tail with a grain field made by stage_grain_field instead of generating it in the same kernel."""
+        pd, pf = self.planes(density, src_gy0), self.planes(field, field_gy0)
+        self._check(self._lib.r2f_stage_tail_field(
+            self._h, C.byref(params), C.byref(pd), C.byref(pf),
+            out_f32.data_ptr() if out_f32 is not None else None, out_u8.data_ptr() if out_u8 is not None else None,
+            out_gy0, y0, y1, int(density.shape[2]), H_global, self._stream()))
+
     def stage_grain(self, density_in, density_out, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
         """S6 + clip alone (planes -> planes): first half of the tail when S7 is on."""
         self._stencil_call(self._lib.r2f_stage_grain, C.byref(params), density_in, src_gy0, density_out, dst_gy0, y0, y1, H_global)

@@ -954,15 +954,22 @@ static bool burn_geometry(const r2f_params* p, int H, int W, int* h_lo, int* w_l
     return *h_lo >= 1 && *w_lo >= 1;
 }
 
+// density == nullptr && planes_out: the grain field alone (K_g * noise) -> planes_out.
+// gfield: a grain field computed that way is applied pointwise instead of being generated here.
 static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* planes_out,
                     const float* burn_map, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global,
-                    void* stream) {
+                    void* stream, const r2f_planes* gfield = nullptr) {
     if (y1 <= y0) return R2F_OK;
+    const bool field_only = density == nullptr && planes_out != nullptr;
+    if (field_only) {
+        static const r2f_planes none = {nullptr, 0, 0, 0};
+        density = &none;
+    }
     const bool to_planes = planes_out != nullptr;
     if (W <= 0 || y0 < 0 || y1 > H_global || (!to_planes && y0 < out_gy0)) return fail(ctx, R2F_EINVAL, "tail: bad geometry");
     if (!to_planes && !out_f32 && !out_u8) return fail(ctx, R2F_EINVAL, "tail: no output buffer");
     if (!to_planes && !ctx->lut3d.tex) return fail(ctx, R2F_EINVAL, "output LUT not set (r2f_set_lut3d)");
-    int rc = check_rows(ctx, "tail src", density, y0, y1);
+    int rc = field_only ? R2F_OK : check_rows(ctx, "tail src", density, y0, y1);
     if (rc) return rc;
     TailArgs a;
     memset(&a, 0, sizeof a);
@@ -975,23 +982,35 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
     a.W = W;
     a.H_global = H_global;
     a.grain = (p->flags & R2F_F_GRAIN) ? 1 : 0;
+    if (gfield) {  // the field was made ahead of time: this call is the pointwise half
+        if (!a.grain) return fail(ctx, R2F_EINVAL, "tail: a grain field was passed but the grain flag is off");
+        rc = check_rows(ctx, "grain field", gfield, y0, y1);
+        if (rc) return rc;
+        if (!ctx->grain_lut.cells) return fail(ctx, R2F_EINVAL, "grain LUT not set (r2f_set_grain_lut)");
+        a.grain = 0;
+        a.gfield = to_dev(gfield);
+        a.has_gfield = 1;
+        a.grain_lut = ctx->grain_lut;
+    }
     a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
     a.seed = p->seed;
     a.lut3d = ctx->lut3d;
     a.lut3d_scale = p->lut3d_scale;
     a.lut3d_mode = p->lut3d_mode;
-    bool vec = planes_vec_ok(density, W);
+    bool vec = field_only ? true : planes_vec_ok(density, W);
+    if (gfield) vec = vec && planes_vec_ok(gfield, W);
     if (to_planes) {
         if (!a.grain) return fail(ctx, R2F_EINVAL, "grain stage called with the grain flag off");
         rc = check_rows(ctx, "grain dst", planes_out, y0, y1);
         if (rc) return rc;
-        a.to_planes = 1;
+        a.to_planes = field_only ? 2 : 1;
         a.dst = to_dev(planes_out);
         vec = vec && planes_vec_ok(planes_out, W);
     } else {
         vec = vec && (!out_f32 || aligned16(out_f32)) && (!out_u8 || (reinterpret_cast<uintptr_t>(out_u8) & 3u) == 0);
         if (burn_map) {
-            if (a.grain) return fail(ctx, R2F_EINVAL, "tail with a burn map: apply the grain first (r2f_stage_grain) and clear R2F_F_GRAIN");
+            if (a.grain || a.has_gfield)
+                return fail(ctx, R2F_EINVAL, "tail with a burn map: apply the grain first (r2f_stage_grain) and clear R2F_F_GRAIN");
             int h_lo, w_lo;
             if (!burn_geometry(p, H_global, W, &h_lo, &w_lo)) return fail(ctx, R2F_EINVAL, "burn: bad burn_cell");
             a.burn.map = burn_map;
@@ -1028,6 +1047,20 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
                    uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
     return run_tail(ctx, p, density, nullptr, burn_map, out_f32, out_u8, out_gy0, y0, y1, W, H_global, stream);
+}
+
+int r2f_stage_grain_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* field, int y0, int y1, int W, int H_global,
+                          void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    if (!field) return fail(ctx, R2F_EINVAL, "grain field: null destination");
+    return run_tail(ctx, p, nullptr, field, nullptr, nullptr, nullptr, 0, y0, y1, W, H_global, stream);
+}
+
+int r2f_stage_tail_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* field, float* out_f32,
+                         uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    if (!field) return fail(ctx, R2F_EINVAL, "tail: null grain field");
+    return run_tail(ctx, p, density, nullptr, nullptr, out_f32, out_u8, out_gy0, y0, y1, W, H_global, stream, field);
 }
 
 int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1, int W,

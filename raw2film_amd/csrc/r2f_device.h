@@ -248,9 +248,11 @@ __device__ __forceinline__ void apply_lut3d_tetra(const DevLut3D& L, float s, fl
     const float4 ca = L.tex[base + e1];
     const float4 cb = L.tex[base + e1 + e2];
     const float4 c1 = L.tex[base + er + eg + eb];
-    r = ((c0.x + d1 * (ca.x - c0.x)) + d2 * (cb.x - ca.x)) + d3 * (c1.x - cb.x);
-    g = ((c0.y + d1 * (ca.y - c0.y)) + d2 * (cb.y - ca.y)) + d3 * (c1.y - cb.y);
-    b = ((c0.z + d1 * (ca.z - c0.z)) + d2 * (cb.z - ca.z)) + d3 * (c1.z - cb.z);
+    // explicit fused multiply-adds: the same bits from every kernel that samples the LUT (the compiler's own contraction
+    // choices differed between the tail kernel and the pointwise one)
+    r = fmaf(d3, c1.x - cb.x, fmaf(d2, cb.x - ca.x, fmaf(d1, ca.x - c0.x, c0.x)));
+    g = fmaf(d3, c1.y - cb.y, fmaf(d2, cb.y - ca.y, fmaf(d1, ca.y - c0.y, c0.y)));
+    b = fmaf(d3, c1.z - cb.z, fmaf(d2, cb.z - ca.z, fmaf(d1, ca.z - c0.z, c0.z)));
 }
 
 // S8 GPU-variant: trilinear between texel centres, lut_3d.wgsl:27-40 (fp32 LUT).

@@ -218,6 +218,9 @@ struct Lut3dArgs {
     int lut3d_mode;
     int vec;
     BurnUp burn;
+    DevPlanes gfield;  // has_gfield: the grain field K_g * noise computed ahead of time (tail_kernel, to_planes = 2)
+    int has_gfield;
+    DevCurve grain_lut;
 };
 
 // S7: the highlight map at pixel (gy, x): ndimage.zoom(map, cell, order=1) = linear interpolation at the
@@ -244,6 +247,17 @@ __global__ __launch_bounds__(256) void lut3d_kernel(const Lut3dArgs a) {
     const int nv = min(4, a.W - x);
     float r[4], g[4], b[4];
     load_planes4(a.src, gy, x, a.W, nv, a.vec != 0, r, g, b);
+    if (a.has_gfield) {  // S6c grain.wgsl:78-89 + clip cpu_processor.py:397, with the field from the side stream
+        float gr[4], gg[4], gb[4];
+        load_planes4(a.gfield, gy, x, a.W, nv, a.vec != 0, gr, gg, gb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // product and sum rounded separately, like NumPy's image + grain * factor (and like the fused tail kernel)
+            r[q] = fmaxf(__fadd_rn(r[q], __fmul_rn(gr[q], curve_eval(a.grain_lut, 0, r[q]))), 0.f);
+            g[q] = fmaxf(__fadd_rn(g[q], __fmul_rn(gg[q], curve_eval(a.grain_lut, 1, g[q]))), 0.f);
+            b[q] = fmaxf(__fadd_rn(b[q], __fmul_rn(gb[q], curve_eval(a.grain_lut, 2, b[q]))), 0.f);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (a.burn.map) {  // S7: subtract the up-sampled highlight map from all three channels, clip at 0
@@ -469,6 +483,12 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
         const int gy = tile_y0 + ty * Q + q;
         if (gy >= a.y1) break;
         float r[4], g[4], b[4];
+        if (a.to_planes == 2) {  // the field itself: nothing of the image is read
+#pragma unroll
+            for (int p = 0; p < 4; ++p) r[p] = G[0][q / 2][p][q & 1], g[p] = G[1][q / 2][p][q & 1], b[p] = G[2][q / 2][p][q & 1];
+            store_planes4(a.dst, gy, gx, a.W, nv, vec, r, g, b);
+            continue;
+        }
         load_planes4(a.src, gy, gx, a.W, nv, vec, r, g, b);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -483,9 +503,9 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
                 ag = curve_eval(a.grain_lut, 1, g[p]);
                 ab = curve_eval(a.grain_lut, 2, b[p]);
             }
-            r[p] = fmaxf(r[p] + G[0][q / 2][p][q & 1] * ar, 0.f);
-            g[p] = fmaxf(g[p] + G[1][q / 2][p][q & 1] * ag, 0.f);
-            b[p] = fmaxf(b[p] + G[2][q / 2][p][q & 1] * ab, 0.f);
+            r[p] = fmaxf(__fadd_rn(r[p], __fmul_rn(G[0][q / 2][p][q & 1], ar)), 0.f);
+            g[p] = fmaxf(__fadd_rn(g[p], __fmul_rn(G[1][q / 2][p][q & 1], ag)), 0.f);
+            b[p] = fmaxf(__fadd_rn(b[p], __fmul_rn(G[2][q / 2][p][q & 1], ab)), 0.f);
             if (!a.to_planes && !(R2F_TAIL_EXP & 4)) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
         }
         if (a.to_planes)
@@ -954,6 +974,9 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
         l.lut3d_mode = a.lut3d_mode;
         l.vec = a.vec;
         l.burn = a.burn;
+        l.gfield = a.gfield;
+        l.has_gfield = a.has_gfield;
+        l.grain_lut = a.grain_lut;
         const int quads = (a.W + 3) / 4;
         dim3 block(64, 4), grid((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4);
         hipLaunchKernelGGL(lut3d_kernel, grid, block, 0, s, l);

@@ -74,7 +74,8 @@ struct TailArgs {
     int out_gy0;
     int y0, y1, W, H_global;
     int grain;  // 0/1
-    int to_planes;  // 1: stop after grain + clip and write density planes `dst` (S7 needs the whole grained frame)
+    int to_planes;  // 1: stop after grain + clip and write density planes `dst` (S7 needs the whole grained frame);
+                    // 2: write the grain field itself (K_g * noise, no image involved) to `dst`
     DevPlanes dst;
     BurnUp burn;
     int mono;
@@ -86,6 +87,8 @@ struct TailArgs {
     int lut3d_mode;
     int vec;
     int cells_in_lds, cells_off;  // set by the launcher: grain-LUT cells copied to LDS at float offset cells_off
+    DevPlanes gfield;             // grain == 0 && has_gfield: a precomputed grain field is applied pointwise (lut3d_kernel)
+    int has_gfield;
 };
 
 constexpr int kChromaMaxTaps = 63;

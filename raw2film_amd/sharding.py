@@ -92,6 +92,14 @@ class HipStageBackend:
         self.ctx.stage_tail(D, params, src_gy0=d_gy0, out_f32=out_f32, out_u8=out_u8, out_gy0=out_gy0, y0=y0, y1=y1,
                             H_global=H, burn_map=burn_map)
 
+    def grain_field(self, F, f_gy0, y0, y1, H):
+        """K_g * N for rows [y0, y1): depends on the seed and the coordinates only, so it can run beside the stencils."""
+        self.ctx.stage_grain_field(F, self.params, dst_gy0=f_gy0, y0=y0, y1=y1, H_global=H)
+
+    def tail_field(self, D, d_gy0, F, f_gy0, out_f32, out_u8, out_gy0, y0, y1, H):
+        self.ctx.stage_tail_field(D, F, self.params, src_gy0=d_gy0, field_gy0=f_gy0, out_f32=out_f32, out_u8=out_u8,
+                                  out_gy0=out_gy0, y0=y0, y1=y1, H_global=H)
+
     def grain(self, D, d_gy0, G, g_gy0, y0, y1, H):
         self.ctx.stage_grain(D, G, self.params, src_gy0=d_gy0, dst_gy0=g_gy0, y0=y0, y1=y1, H_global=H)
 
@@ -114,7 +122,7 @@ class RowShardedRenderer:
     """
 
     def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,
-                 group=None, rank=None, world=None):
+                 group=None, rank=None, world=None, side_grain: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -150,6 +158,12 @@ class RowShardedRenderer:
         self.D2 = backend.empty(p.rows, W) if mtf else None
         self.Dplain = backend.empty(p.rows, W) if not (halation or mtf) else None
         self.G = backend.empty(p.rows, W) if (burn and grain) else None  # grained density, needed whole before S7
+        # The grain field does not depend on the image: with a device backend it is made on a side stream while the
+        # (memory-bound) stencils run, and the tail shrinks to a pointwise pass.
+        self.side_grain = bool(side_grain and grain and not burn and (halation or mtf) and hasattr(backend, "grain_field")
+                               and getattr(backend, "device", None) is not None and torch.cuda.is_available())
+        self.F = backend.empty(p.rows, W) if self.side_grain else None
+        self.side_stream = torch.cuda.Stream(device=backend.device) if self.side_grain else None
 
     # ------------------------------------------------------------------ neighbour exchange
     def _exchange(self, buf, buf_gy0: int, above: int, below: int):
@@ -208,6 +222,14 @@ class RowShardedRenderer:
         out_*: this rank's own rows of the result, (rows, W, 3)."""
         p, be = self.plan, self.backend
         H = p.H
+        field_ready = None
+        if self.side_grain:
+            torch = self.torch
+            main = torch.cuda.current_stream()
+            self.side_stream.wait_stream(main)  # the previous frame's tail may still be reading F
+            with torch.cuda.stream(self.side_stream):
+                be.grain_field(self.F, p.r0, p.r0, p.r1, H)
+                field_ready = self.side_stream.record_event()
         if not (self.halation or self.mtf or self.grain or self.burn):  # LUTs only: one fused pointwise pass
             be.front_to_output(image_rows, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
             return out_f32, out_u8
@@ -231,7 +253,11 @@ class RowShardedRenderer:
                 be.mtf(self.D, self.d_lo, self.D2, p.r0, p.r0, p.r1, H)
                 cur, cur_lo = self.D2, p.r0
         if not self.burn:
-            be.tail(cur, cur_lo, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+            if field_ready is not None:
+                self.torch.cuda.current_stream().wait_event(field_ready)
+                be.tail_field(cur, cur_lo, self.F, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
+            else:
+                be.tail(cur, cur_lo, out_f32, out_u8, p.r0, p.r0, p.r1, H)
             return out_f32, out_u8
         # S7: the highlight map is a function of the whole grained frame -> grain to planes, every rank reduces the
         # cells its rows touch, one tiny all-reduce adds the partial sums, every rank blurs the (replicated) map.

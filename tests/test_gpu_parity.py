@@ -534,3 +534,31 @@ def test_resize_area_against_oracle(ctx, layout, shape, out):
     t = dev(img) if layout == "hwc3" else to_planes(img)
     got = from_planes(ctx.resize_area(t, out[0], out[1]))
     assert_close(got, ref, 2e-6, 1e-6, f"area resize {shape}->{out}")
+
+
+def test_grain_field_split_equals_the_fused_tail_bit_for_bit(ctx):
+    """r2f_stage_grain_field + r2f_stage_tail_field (the field made ahead of time, e.g. on a side stream) == r2f_stage_tail."""
+    neg, prt, _ = stocks()
+    H, W = 150, 212
+    for grain in (2, 1):
+        p = oracle_inputs(neg, prt, 341.33, halation=False, mtf=False, grain=grain, seed=77)
+        params = setup_ctx(ctx, p)
+        rng = np.random.default_rng(grain)
+        dens = rng.uniform(0.0, 3.5, (H, W, 3)).astype(np.float32)
+        D = to_planes(dens)
+        fused = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        ctx.stage_tail(D, params, out_f32=fused, y0=0, y1=H, H_global=H)
+        F = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_grain_field(F, params, y0=0, y1=H, H_global=H)
+        split = torch.empty_like(fused)
+        ctx.stage_tail_field(D, F, params, out_f32=split, y0=0, y1=H, H_global=H)
+        assert torch.equal(fused, split)
+        # and in two row ranges with their own field buffers (what a row shard does)
+        for y0, y1 in ((0, 70), (70, H)):
+            Fp = torch.empty((3, y1 - y0, W), dtype=torch.float32, device="cuda")
+            ctx.stage_grain_field(Fp, params, dst_gy0=y0, y0=y0, y1=y1, H_global=H)
+            part = torch.empty((y1 - y0, W, 3), dtype=torch.float32, device="cuda")
+            ctx.stage_tail_field(D, Fp, params, field_gy0=y0, out_f32=part, out_gy0=y0, y0=y0, y1=y1, H_global=H)
+            assert torch.equal(part, fused[y0:y1])
+        ref = st.apply_lut_tetrahedral(st.apply_grain(dens, p.grain_lut, p.grain_kernel, p.seed, grain == 1), p.lut_3d, 0.25)
+        assert_close(split.cpu().numpy(), ref, 1e-5, 1e-1, "split tail vs oracle")
