@@ -214,6 +214,15 @@ def main():
                                  "outputs written back ((256 - k + 1) / 256 MiB); the 1 MiB kernel spectrum is L2-resident",
                 "passes_ms_per_step": {"rows_fwd": extra[0][0] / 2, "cols": fft_ms[1][0] / args.steps, "rows_inv": extra[2][0] / 2,
                                        "note": "cols: events in the timed steps; the other two passes: two extra steps after them"},
+                "concurrency": "launches alternate between two internal streams, so two FFT-pass kernels usually share the GPU: "
+                               "kernel_ms and achieved are per launch under that sharing; the line below is the aggregate",
+                "stencil_stages": (lambda b, ms: {"algorithmic_bytes_per_step": b, "ms_per_step": ms, "GB/s": b / (ms * 1e-3) / 1e9,
+                                                  "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                  "note": "all three passes of halation + MTF (window floats in, scratch "
+                                                          "written, read, written back, read, outputs out) over the two "
+                                                          "stages' wall time, single-tap plane included"})(
+                    extra[0][2] / 2 + bytes_alg / args.steps + extra[2][2] / 2,
+                    float(stage_ms["halation"]) + float(stage_ms.get("mtf", 0.0))),
                 "stencil_flops": {
                     "halation_direct_equivalent_tflops": flops_nnz / (hal_ms * 1e-3) / 1e12,
                     "note": "what a direct evaluation of the reference's halation stencil (2 flop per non-zero tap) would need, "
