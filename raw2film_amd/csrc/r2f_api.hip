@@ -168,7 +168,7 @@ int upload_curve(r2f_ctx* ctx, DeviceBuf& buf, DevCurve& cv, const float* lut, i
 struct StreamHost {
     std::vector<float> w;
     std::vector<int> rowinfo, phases;  // rowinfo: 4 ints per non-empty row step (DevStencil::rowinfo)
-    int n_phases = 0, n_rowsteps = 0, n_entries = 0, max_lds_rows = 0;
+    int n_phases = 0, n_rowsteps = 0, n_entries = 0, max_lds_rows = 0, mask_first_or = 0, mask_last_or = 0;
 };
 
 // `tap(i, j)` = weight of the (virtual) cropped stencil, 0 outside; kh x kw virtual taps.
@@ -223,6 +223,8 @@ void build_stream(Tap tap, int kh, int kw, bool sym, int Q, int RS, int TH, int 
             out.rowinfo.push_back((m - m0) * RS + 4 * c_lo);
             out.rowinfo.push_back(sym ? (m - m0) * RS + 2 * r - 4 * c_lo - 4 : 0);
             out.rowinfo.push_back(live(c_lo) | live(c_hi) << 4);
+            out.mask_first_or |= live(c_lo);
+            out.mask_last_or |= live(c_hi);
             for (int c = c_lo; c <= c_hi; ++c) {
                 ++out.n_entries;
                 for (int t = 0; t < 4; ++t)
@@ -330,6 +332,8 @@ int ensure_stencil(r2f_ctx* ctx, int which, int Q, int TW, int TH, size_t lds_bu
         d.n_phases = sh.n_phases;
         d.n_rowsteps = sh.n_rowsteps;
         d.n_entries = sh.n_entries;
+        d.mask_first_or = sh.mask_first_or;
+        d.mask_last_or = sh.mask_last_or;
         d.max_lds_rows = sh.max_lds_rows;
         int rc = upload(ctx, s.wbuf[c], sh.w.data(), sh.w.size() * sizeof(float));
         if (rc) return rc;

@@ -57,6 +57,7 @@ struct DevStencil {
     int n_phases;
     int n_rowsteps;        // total non-empty row steps
     int n_entries;         // total entries (without the two dummies)
+    int mask_first_or, mask_last_or;  // unions over the row steps of the live masks of their first / last entry
     int kh, kw;            // cropped taps
     int kw_pad;            // kw rounded up to a multiple of 4
     int ay, ax;            // anchor inside the cropped box
@@ -456,12 +457,21 @@ __device__ __forceinline__ void tap_fma_sym(const typename WVec<4 * Q>::type& w,
 // FIRST: the entry starts the row partial (multiply instead of fma).  MASKED: only the tap columns whose bit is set in
 // `mask` are evaluated -- the first and last entry of a row step usually hold padding columns or the rim of a disc
 // (all-zero weights); `mask` is wave-uniform (it comes from the row-step record), so each test is a scalar branch.
-template <int Q, bool FIRST, bool MASKED>
+// CM >= 0: the mask is a compile-time constant (the tail kernel is instantiated for the masks small grain stencils have), so the
+// dead tap columns cost nothing at all -- not even a branch.
+template <int Q, bool FIRST, bool MASKED, int CM = -1>
 __device__ __forceinline__ void entry_fma_sym(const typename WVec<4 * Q>::type& w, const float4v& la, const float4v& lb,
                                               const float4v& ra, const float4v& rb, float2v (&part)[Q / 2][4], const int mask) {
     const float lw[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
     const float rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    if (!MASKED) {
+    if (CM >= 0) {
+        constexpr int M = CM < 0 ? 15 : CM;
+        constexpr int first_live = (M & 1) ? 0 : (M & 2) ? 1 : (M & 4) ? 2 : 3;
+        if (M & 1) tap_fma_sym<Q, 0, FIRST && first_live == 0>(w, lw, rw, part);
+        if (M & 2) tap_fma_sym<Q, 1, FIRST && first_live == 1>(w, lw, rw, part);
+        if (M & 4) tap_fma_sym<Q, 2, FIRST && first_live == 2>(w, lw, rw, part);
+        if (M & 8) tap_fma_sym<Q, 3, FIRST && first_live == 3>(w, lw, rw, part);
+    } else if (!MASKED) {
         tap_fma_sym<Q, 0, FIRST>(w, lw, rw, part);
         tap_fma_sym<Q, 1, false>(w, lw, rw, part);
         tap_fma_sym<Q, 2, false>(w, lw, rw, part);
@@ -492,7 +502,7 @@ struct SymOperands {
 #define R2F_EXP 0  // development switch (tools/ablate_stencil.py): bit 0 no LDS reads, 1 no weight loads, 2 no FMAs
 #endif
 
-template <int Q, bool FIRST, bool MASKED>
+template <int Q, bool FIRST, bool MASKED, int CM = -1>
 __device__ __forceinline__ void entry_step_sym(const float* lds, const int noff, const int noffr,
                                                const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
                                                const SymOperands<Q>& cur, SymOperands<Q>& nxt, float2v (&part)[Q / 2][4],
@@ -522,7 +532,7 @@ __device__ __forceinline__ void entry_step_sym(const float* lds, const int noff,
         else
             part[0][0] += float2v{cur.w[0] + cur.w[4 * Q - 1], cur.la.x + cur.lb.w + cur.ra.x + cur.rb.w};
     } else
-        entry_fma_sym<Q, FIRST, MASKED>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part, mask);
+        entry_fma_sym<Q, FIRST, MASKED, CM>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part, mask);
     ++e;
 }
 
@@ -530,7 +540,8 @@ __device__ __forceinline__ void entry_step_sym(const float* lds, const int noff,
 // alternate entry by entry; the current entry sits in set A at the top of every row step.  MASKS = false evaluates every
 // tap column of every entry (the tail kernel's 9x9 grain stencil: two entries per row step, the branches cost more than
 // the padding columns they skip -- 2.0 vs 1.8 ms).
-template <int Q, bool MASKS>
+// CMF / CML >= 0: compile-time live masks of the first / last entry of every row step (supersets of the per-row masks).
+template <int Q, bool MASKS, int CMF = -1, int CML = -1>
 __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const DevStencil& st, int row_begin, int row_end,
                                                        int e0, float2v (&acc)[Q / 2][4]) {
     typedef typename WVec<4 * Q>::type wvec;
@@ -554,7 +565,15 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
             const bool only = cnt <= 1;
             const int no = only ? ri_n.y : off, nor = only ? ri_n.z : offr;
             off += 4, offr -= 4;
-            entry_step_sym<Q, true, MASKS>(lds, no, nor, wstream, wmul, e, A, B, part, m_first, info + r + 2, &ri_nn);
+            if (CMF >= 0) {
+                if (only)
+                    entry_step_sym<Q, true, false, (CMF >= 0 ? (CMF & CML) : -1)>(lds, no, nor, wstream, wmul, e, A, B, part, 15,
+                                                                                  info + r + 2, &ri_nn);
+                else
+                    entry_step_sym<Q, true, false, CMF>(lds, no, nor, wstream, wmul, e, A, B, part, 15, info + r + 2, &ri_nn);
+            } else {
+                entry_step_sym<Q, true, MASKS>(lds, no, nor, wstream, wmul, e, A, B, part, m_first, info + r + 2, &ri_nn);
+            }
         }
         int i = 1;
         for (; i + 2 < cnt; i += 2) {  // two middle entries: i (set B) and i + 1 (set A); entry i + 2 exists in this row step
@@ -564,10 +583,10 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
         }
         if (i + 1 < cnt) {  // two entries left: a middle one (set B), then the last (set A)
             entry_step_sym<Q, false, false>(lds, off, offr, wstream, wmul, e, B, A, part);
-            entry_step_sym<Q, false, MASKS>(lds, ri_n.y, ri_n.z, wstream, wmul, e, A, B, part, m_last);
+            entry_step_sym<Q, false, MASKS, CML>(lds, ri_n.y, ri_n.z, wstream, wmul, e, A, B, part, m_last);
             A = B;
         } else if (i < cnt) {  // one entry left: the last (set B)
-            entry_step_sym<Q, false, MASKS>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part, m_last);
+            entry_step_sym<Q, false, MASKS, CML>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part, m_last);
         } else {  // cnt == 1
             A = B;
         }

@@ -187,7 +187,13 @@ struct StencilVariant {
 };
 constexpr int kNumStencilVariants = 3;
 extern const StencilVariant kStencilVariants[kNumStencilVariants];
-constexpr int kTailBX = 16, kTailBY = 32, kTailQ = 2;  // grain/tail tile 64 x 64, 512 threads
+#ifndef R2F_TAIL_BX
+#define R2F_TAIL_BX 16
+#endif
+#ifndef R2F_TAIL_BY
+#define R2F_TAIL_BY 32
+#endif
+constexpr int kTailBX = R2F_TAIL_BX, kTailBY = R2F_TAIL_BY, kTailQ = 2;  // grain/tail tile 64 x 64, 512 threads
 constexpr size_t kMaxLds = 160 * 1024;
 
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan);
