@@ -61,7 +61,7 @@ struct r2f_ctx {
     } tile_order[4];
     int tile_order_next = 0;
     // FFT form of large stencils (r2f_fft.hip): twiddles, per stencil and channel the kernel spectrum, pass scratch
-    DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_s2, fft_kimg;
+    DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_kimg;
     bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
     // optional per-launch timing of the FFT passes with events on the launch stream (bench.py's roofline): class 0 / 1 / 2 =
     // pass 1 / 2 / 3; algorithmic bytes are summed alongside
@@ -533,7 +533,6 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     const int batch = std::min(pairs, std::max(1, ctx->opt_fft_batch / nstreams));
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img * sizeof(double2));
     if (rc) return rc;
-    a.s2 = nullptr;
     hipStream_t lanes[4] = {s, s, s, s};
     if (nstreams > 1) {
         for (int i = 0; i < nstreams; ++i) {
@@ -679,7 +678,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
 // =============================================================================== C ABI
 extern "C" {
 
-const char* r2f_version(void) { return "r2f-hip 0.2 gfx950 abi2"; }
+const char* r2f_version(void) { return "r2f-hip 0.3 gfx950 abi3"; }
 
 int r2f_create(int device, r2f_ctx** out) {
     if (!out) return R2F_EINVAL;
@@ -710,7 +709,6 @@ void r2f_destroy(r2f_ctx* ctx) {
     ctx->lanczos_buf.release();
     ctx->fft_tw.release();
     ctx->fft_s1.release();
-    ctx->fft_s2.release();
     ctx->fft_kimg.release();
     for (auto& row : ctx->fft_kf)
         for (auto& b : row) b.release();

@@ -158,8 +158,7 @@ struct FftConvArgs {
     const double2* tw;        // exp(-2 pi i k / 256), k < 256
     const double2* kfs[3];    // per launch channel: conj of the kernel's 2-D spectrum (scratch layout)
     double2* kf_out;          // pass 2, mode 1
-    double2* s1;              // npairs x 256 x 256 scratch images S[r][k], transformed in place
-    double2* s2;              // unused
+    double2* s1;              // npairs x 256 x 256 scratch images, transformed in place (layout: sidx in r2f_fft.hip)
     int epilogue;
     DevCurve curve;
     float log_eps;
