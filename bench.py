@@ -215,7 +215,10 @@ def main():
                 "passes_ms_per_step": {"rows_fwd": extra[0][0] / 2, "cols": fft_ms[1][0] / args.steps, "rows_inv": extra[2][0] / 2,
                                        "note": "cols: events in the timed steps; the other two passes: two extra steps after them"},
                 "concurrency": "launches alternate between two internal streams, so two FFT-pass kernels usually share the GPU: "
-                               "kernel_ms and achieved are per launch under that sharing; the line below is the aggregate",
+                               "kernel_ms and achieved are per launch under that sharing; the line below is the aggregate. The "
+                               "event pair around a ~50 us launch also spans its dispatch gap (~5 us), so kernel_ms reads ~10 % "
+                               "above rocprofv3's kernel-only average (profiles/r01_kernel_stats.csv): the quoted frac is the "
+                               "conservative one",
                 "stencil_stages": (lambda b, ms: {"algorithmic_bytes_per_step": b, "ms_per_step": ms, "GB/s": b / (ms * 1e-3) / 1e9,
                                                   "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                   "note": "all three passes of halation + MTF (window floats in, scratch "
