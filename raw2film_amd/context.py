@@ -344,11 +344,19 @@ class HipContext:
         return out
 
     def stencil_stats(self, which: int):
-        """Per channel: dict(entries, rowsteps, phases, sym, kh, kw, q) of the device form of stencil `which` (bench.py)."""
+        """Per channel: dict(entries, rowsteps, phases, sym, kh, kw, q, fft, window) of the device form of stencil `which`
+        (bench.py); fft = 1: the channel takes the FFT form, window = (rows, columns) of its last launch or None."""
         out = (C.c_int * 24)()
         self._check(self._lib.r2f_stencil_stats(self._h, int(which), out))
-        keys = ("entries", "rowsteps", "phases", "sym", "kh", "kw", "q", "fft")
-        return [dict(zip(keys, out[8 * c:8 * c + 8])) for c in range(3)]
+        keys = ("entries", "rowsteps", "phases", "sym", "kh", "kw", "q")
+        stats = []
+        for c in range(3):
+            d = dict(zip(keys, out[8 * c:8 * c + 7]))
+            word = out[8 * c + 7]
+            d["fft"] = word & 1
+            d["window"] = ((word >> 1) // 1024, (word >> 1) % 1024) if word >> 1 else None
+            stats.append(d)
+        return stats
 
     def kernel_timing(self, cls: int):
         """(total ms, launches, algorithmic bytes) of FFT pass `cls` since the last call; needs set_option("kernel_timing", 1)."""

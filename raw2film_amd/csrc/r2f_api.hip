@@ -63,6 +63,8 @@ struct r2f_ctx {
     // FFT form of large stencils (r2f_fft.hip): twiddles, per stencil and channel the kernel spectrum, pass scratch
     DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_kimg;
     bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
+    int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 1024 + nx) each spectrum was built for
+    int opt_fft_window = 0;      // window columns: 0 = the cheaper of 256 / 512 per stencil and frame width, or one of them forced
     // optional per-launch timing of the FFT passes with events on the launch stream (bench.py's roofline): class 0 / 1 / 2 =
     // pass 1 / 2 / 3; algorithmic bytes are summed alongside
     int opt_timing = 0;
@@ -462,6 +464,20 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     return bh <= 200 && bw <= 200 && bh * bw >= ctx->opt_fft_min_taps;
 }
 
+// Window width for a tap box bw wide on a frame W wide: 256 or 512 columns, whichever covers a row of the frame with fewer
+// scratch columns (windows x nx).  Rows per window stay 256: pass 2 then still skips the rows without valid outputs, and
+// a 512-point column transform does not fit the register file.  Chosen from the frame width alone, so every row shard of a
+// frame (and every call on it) uses the same shape and the kernel spectra are built once.
+void fft_window(const r2f_ctx* ctx, int bw, int W, int* ny, int* nx) {
+    *ny = kFftN;
+    if (ctx->opt_fft_window) {
+        *nx = ctx->opt_fft_window;
+        return;
+    }
+    const int v256 = (256 - bw + 1) & ~3, v512 = (512 - bw + 1) & ~3;
+    *nx = (long long)((W + v512 - 1) / v512) * 512 < (long long)((W + v256 - 1) / v256) * 256 ? 512 : 256;
+}
+
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
 // their window pairs share the launches.
 int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2f_planes* src, const r2f_planes* dst, int y0, int y1,
@@ -470,12 +486,16 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     int b[4];
     tap_box(set, chans[0], b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
-    const size_t img = (size_t)kFftN * kFftN;
+    int ny = 256, nx = 256;
+    fft_window(ctx, bw, W, &ny, &nx);
+    const size_t img = (size_t)ny * nx;
     if (!ctx->fft_tw.p) {
-        std::vector<double> tw(2 * kFftN);
+        // W_256^k, k < 256, then W_512^k, k < 256
+        std::vector<double> tw(4 * kFftN);
         for (int k = 0; k < kFftN; ++k) {
-            const double ang = -2.0 * 3.14159265358979323846264338327950288 * k / kFftN;
-            tw[2 * k] = std::cos(ang), tw[2 * k + 1] = std::sin(ang);
+            const double pi = 3.14159265358979323846264338327950288;
+            tw[2 * k] = std::cos(-2.0 * pi * k / kFftN), tw[2 * k + 1] = std::sin(-2.0 * pi * k / kFftN);
+            tw[2 * (kFftN + k)] = std::cos(-pi * k / kFftN), tw[2 * (kFftN + k) + 1] = std::sin(-pi * k / kFftN);
         }
         int rc = upload(ctx, ctx->fft_tw, tw.data(), tw.size() * sizeof(double));
         if (rc) return rc;
@@ -483,20 +503,22 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     FftConvArgs a;
     memset(&a, 0, sizeof a);
     a.tw = static_cast<const double2*>(ctx->fft_tw.p);
+    a.tw512 = a.tw + kFftN;
+    a.nx = nx;
     a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
     a.ax = set.kw / 2 - b[2];
-    a.vy = kFftN - bh + 1;
-    a.vx = (kFftN - bw + 1) & ~3;  // a multiple of 4: window origins stay 16-byte aligned for the float4 stores of pass 3
+    a.vy = ny - bh + 1;
+    a.vx = (nx - bw + 1) & ~3;  // a multiple of 4: window origins stay 16-byte aligned for the float4 stores of pass 3
     int rc = ensure_bytes(ctx, ctx->fft_s1, img * sizeof(double2));
     if (rc) return rc;
     for (int i = 0; i < nch; ++i) {
         const int c = chans[i];
-        if (ctx->fft_kf_valid[which][c]) continue;
+        if (ctx->fft_kf_valid[which][c] && ctx->fft_kf_dims[which][c] == ny * 1024 + nx) continue;
         // the kernel's spectrum: the same two forward passes on its zero-padded image
         std::vector<float> kimg(img, 0.f);
         const int kc = set.kc == 1 ? 0 : c;
         for (int y = 0; y < bh; ++y)
-            for (int x = 0; x < bw; ++x) kimg[(size_t)y * kFftN + x] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
+            for (int x = 0; x < bw; ++x) kimg[(size_t)y * nx + x] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
         rc = upload(ctx, ctx->fft_kimg, kimg.data(), img * sizeof(float));
         if (rc) return rc;
         rc = ensure_bytes(ctx, ctx->fft_kf[which][c], img * sizeof(double2));
@@ -511,6 +533,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         R2F_HIP(ctx, launch_fft_rows_fwd(k, s));
         R2F_HIP(ctx, launch_fft_cols(k, 1, s));
         ctx->fft_kf_valid[which][c] = true;
+        ctx->fft_kf_dims[which][c] = ny * 1024 + nx;
     }
     a.src = to_dev(src);
     a.dst = to_dev(dst);
@@ -529,8 +552,10 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
     const int pairs = a.ppc * nch;
     // batches alternate between two internal streams when there is enough work for that to matter
-    const int nstreams = pairs > ctx->opt_fft_batch ? ctx->opt_fft_streams : 1;
-    const int batch = std::min(pairs, std::max(1, ctx->opt_fft_batch / nstreams));
+    // opt_fft_batch counts 256 x 256 pairs (1 MB of scratch each); larger windows take proportionally fewer per launch
+    const int fft_batch = std::max(1, (int)((size_t)ctx->opt_fft_batch * kFftN * kFftN / img));
+    const int nstreams = pairs > fft_batch ? ctx->opt_fft_streams : 1;
+    const int batch = std::min(pairs, std::max(1, fft_batch / nstreams));
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img * sizeof(double2));
     if (rc) return rc;
     hipStream_t lanes[4] = {s, s, s, s};
@@ -568,7 +593,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         a.s1 = static_cast<double2*>(ctx->fft_s1.p) + (size_t)li * batch * img;
         // algorithmic bytes of the passes: window floats in (2 per pair) + scratch image out; scratch in + valid rows out;
         // valid rows in + valid outputs out.  The kernel spectrum (1 MB) stays in L2.
-        const double np = a.npairs, full = (double)img * sizeof(double2), part = full * a.vy / kFftN;
+        const double np = a.npairs, full = (double)img * sizeof(double2), part = full * a.vy / ny;
         rc = timed(0, np * (2.0 * img * sizeof(float) + full), st, [&] { return launch_fft_rows_fwd(a, st); });
         if (rc) return rc;
         rc = timed(1, np * (full + part), st, [&] { return launch_fft_cols(a, 0, st); });
@@ -748,6 +773,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "stencil_fft")) {
         ctx->opt_fft = value ? 1 : 0;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_window")) {
+        if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window must be 0, 256 or 512");
+        ctx->opt_fft_window = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_min_taps")) {
@@ -944,7 +974,8 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
         const DevStencil& d = set.dev[c];
         int* o = out + 8 * c;
         o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym;
-        o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q, o[7] = fft_eligible(ctx, set, c) ? 1 : 0;
+        o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q;
+        o[7] = fft_eligible(ctx, set, c) ? 1 | ((ctx->fft_kf_valid[which][c] ? ctx->fft_kf_dims[which][c] : 0) << 1) : 0;
     }
     return R2F_OK;
 }

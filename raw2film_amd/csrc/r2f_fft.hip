@@ -20,6 +20,13 @@
 // ds_write_b128 issue: 0.6 ms per 1 024 pairs in pass 2.)  A wave carries 4 lines; lines of a wave are 4 neighbouring rows
 // (passes 1, 3: 256-byte segments per access) or 4 neighbouring columns (pass 2: a gather of 64-byte pieces, the other half
 // of each 128-byte line belongs to the next wave of the same workgroup).
+//
+// Windows are 256 rows by 256 or 512 columns (FftConvArgs::nx; the host picks the width that moves the fewest scratch
+// bytes for the stencil and the frame: an 87-tap disc keeps 66 % of a 256-wide window's columns but 83 % of a 512-wide
+// one's).  A 512-point row is transformed by 32 lanes holding 16 elements each (fft512: 512 = 32 x 16, the same two
+// register DFTs around an LDS transpose, plus one radix-2 step across neighbouring lanes by DPP), so the row passes keep
+// their register budget and a wave carries 2 rows instead of 4; pass 2 only sees twice as many columns.  Rows per window
+// stay 256: pass 2 then still skips the rows without valid outputs.
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
@@ -84,31 +91,34 @@ __device__ __forceinline__ void dft16(cplx (&v)[16]) {
         }
 }
 
+// v[p] *= w1^p (conjugated powers for the inverse); the powers come from a multiplication tree of depth <= 5 (a few ulp)
+template <bool INV>
+__device__ __forceinline__ void twiddle_powers(cplx (&v)[16], const cplx w1) {
+    const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3),
+               w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+    v[1] = ctw<INV>(v[1], w1);
+    v[2] = ctw<INV>(v[2], w2);
+    v[3] = ctw<INV>(v[3], w3);
+    v[4] = ctw<INV>(v[4], w4);
+    v[5] = ctw<INV>(v[5], w5);
+    v[6] = ctw<INV>(v[6], w6);
+    v[7] = ctw<INV>(v[7], w7);
+    v[8] = ctw<INV>(v[8], w8);
+    v[9] = ctw<INV>(v[9], cmul(w8, w1));
+    v[10] = ctw<INV>(v[10], cmul(w5, w5));
+    v[11] = ctw<INV>(v[11], cmul(w8, w3));
+    v[12] = ctw<INV>(v[12], cmul(w6, w6));
+    v[13] = ctw<INV>(v[13], cmul(w8, w5));
+    v[14] = ctw<INV>(v[14], cmul(w7, w7));
+    v[15] = ctw<INV>(v[15], cmul(w8, w7));
+}
+
 // 256-point transform of the line whose element (l + 16 m) sits in v[m] of lane l (l = lane & 15); on return v[q] holds
 // output element (l + 16 q).  w1 = exp(-2 pi i l / 256).  tbuf: this WAVE's transpose buffer, 4 lines x 272 doubles.
 template <bool INV>
 __device__ __forceinline__ void fft256(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
     dft16<INV>(v);
-    // v[p] *= w1^p; the powers come from a multiplication tree of depth <= 5 (a few ulp)
-    {
-        const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3),
-                   w7 = cmul(w4, w3), w8 = cmul(w4, w4);
-        v[1] = ctw<INV>(v[1], w1);
-        v[2] = ctw<INV>(v[2], w2);
-        v[3] = ctw<INV>(v[3], w3);
-        v[4] = ctw<INV>(v[4], w4);
-        v[5] = ctw<INV>(v[5], w5);
-        v[6] = ctw<INV>(v[6], w6);
-        v[7] = ctw<INV>(v[7], w7);
-        v[8] = ctw<INV>(v[8], w8);
-        v[9] = ctw<INV>(v[9], cmul(w8, w1));
-        v[10] = ctw<INV>(v[10], cmul(w5, w5));
-        v[11] = ctw<INV>(v[11], cmul(w8, w3));
-        v[12] = ctw<INV>(v[12], cmul(w6, w6));
-        v[13] = ctw<INV>(v[13], cmul(w8, w5));
-        v[14] = ctw<INV>(v[14], cmul(w7, w7));
-        v[15] = ctw<INV>(v[15], cmul(w8, w7));
-    }
+    twiddle_powers<INV>(v, w1);
     // 16 x 16 transpose inside each 16-lane group, real parts then imaginary parts through the same buffer
     const int l = lane & 15;
     double* t = tbuf + (lane >> 4) * kTLine;
@@ -128,6 +138,56 @@ __device__ __forceinline__ void fft256(cplx (&v)[16], const cplx w1, double* tbu
     dft16<INV>(v);
 }
 
+// A lane's double moved to / from its neighbour lane ^ 1 (DPP quad_perm [1, 0, 3, 2], no LDS).
+__device__ __forceinline__ double swap_lane1(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kTPitch512 = 34;                // transpose tile row pitch of a 512-point line: 32 + 2 (conflict-free both ways)
+constexpr int kTLine512 = 16 * kTPitch512;    // 544 doubles per line; a wave's 2 lines fill the same 1 088 doubles as 4 x 272
+
+// 512-point transform of the line whose element (l + 32 j) sits in v[j] of lane l (l = lane & 31): 512 = 32 x 16.  A 16-point
+// DFT over j, the twiddles W_512^(l p), a transpose after which the lane pair (2 p, 2 p + 1) holds the even / odd l of
+// output residue p, a second 16-point DFT, and one radix-2 step across the pair.  On return v[i] of lane l holds output
+// element 256 (l & 1) + 16 i + (l >> 1).  w1 = exp(-2 pi i l / 512).  tbuf: this WAVE's transpose buffer.
+template <bool INV>
+__device__ __forceinline__ void fft512(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
+    constexpr double kC32[16] = {1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058};
+    constexpr double kS32[16] = {0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891};
+    dft16<INV>(v);
+    twiddle_powers<INV>(v, w1);
+    const int l = lane & 31;
+    double* t = tbuf + (lane >> 5) * kTLine512;
+    const double* rd = t + (l >> 1) * kTPitch512 + (l & 1);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t[p * kTPitch512 + l] = v[p].x;
+    __builtin_amdgcn_wave_barrier();
+    double re[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) re[i] = rd[2 * i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t[p * kTPitch512 + l] = v[p].y;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = make_double2(re[i], rd[2 * i]);
+    __builtin_amdgcn_wave_barrier();
+    dft16<INV>(v);  // even lanes: E[i] over the even l, odd lanes: O[i] over the odd l
+    // X[i] = E[i] + W_32^i O[i] (even lane), X[16 + i] = E[i] - W_32^i O[i] (odd lane)
+    const bool odd = l & 1;
+    if (odd) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v[i] = ctw<INV>(v[i], make_double2(kC32[i], -kS32[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const cplx o = make_double2(swap_lane1(v[i].x), swap_lane1(v[i].y));
+        v[i] = odd ? csub(o, v[i]) : cadd(v[i], o);
+    }
+}
+
 // window origin (first input row / column) and validity of window `t` of the launch
 __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, int& wx) {
     if (t >= a.ntiles) return false;
@@ -143,30 +203,53 @@ __device__ __forceinline__ double* wave_tbuf(double* smem) { return smem + (thre
 // interleaved row by row: [(k / 4) % 4][r % 16][k % 4].  The column pass (a wave = 4 neighbouring columns x 16 rows per
 // access) then moves 1 KB contiguous per instruction, and the row passes (a wave = 4 neighbouring rows x 16 columns) four
 // 256-byte pieces of one block.
-__device__ __forceinline__ long long sidx(int r, int k) {
-    return ((long long)((r >> 4) * 16 + (k >> 4)) << 8) + ((((k >> 2) & 3) * 16 + (r & 15)) << 2) + (k & 3);
+// nbx = blocks per block row = nx / 16.
+// (unsigned: with the uniform image base in SGPRs an access then needs one offset VGPR, not a 64-bit address pair)
+__device__ __forceinline__ unsigned sidx(int r, int k, int nbx) {
+    return (unsigned)((((r >> 4) * nbx + (k >> 4)) << 8) + ((((k >> 2) & 3) * 16 + (r & 15)) << 2) + (k & 3));
+}
+
+// element `idx` of a scratch image: the byte offset stays a 32-bit value, so the access is SGPR base + one offset VGPR
+__device__ __forceinline__ cplx& at(cplx* base, unsigned idx) {
+    return *reinterpret_cast<cplx*>(reinterpret_cast<char*>(base) + (idx << 4));
+}
+__device__ __forceinline__ const cplx& at(const cplx* base, unsigned idx) {
+    return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + (idx << 4));
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 1
-// grid (256 / 16, pairs): a workgroup transforms 16 rows, a wave 4 of them.
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    const int lane = threadIdx.x & 63, l = lane & 15;
-    const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
+// grid (256 / rows per workgroup, pairs).  X512 = false: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
+// X512 = true: 32 lanes per (512-point) row, 8 rows per workgroup, 2 per wave.
+#ifndef R2F_FFT_EXP
+#define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
+#endif
+template <bool X512>
+struct RowGeom {
+    static constexpr int NX = X512 ? 512 : 256, NBX = NX / 16, LPL = X512 ? 32 : 16, ROWS = kFftThreads / LPL;
+    // column (or frequency) held in register q of lane l after a transform
+    static __device__ __forceinline__ int out_col(int l, int q) { return X512 ? 256 * (l & 1) + 16 * q + (l >> 1) : l + 16 * q; }
+    static __device__ __forceinline__ double* line_buf(double* wave_buf, int lane) {
+        return wave_buf + (X512 ? (lane >> 5) * kTLine512 : (lane >> 4) * kTLine);
+    }
+};
+
+template <bool X512>
+__device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* fsm) {
+    typedef RowGeom<X512> G;
+    constexpr int NX = G::NX, LPL = G::LPL;
+    const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
+    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
     const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc;  // channel-major pair numbering
     const bool hasA = window_of(a, 2 * pc, wyA, wxA), hasB = window_of(a, 2 * pc + 1, wyB, wxB);
     const float* src = a.src.data + (long long)a.chan[ci] * a.src.plane_stride;
-    cplx v[16];
-#ifndef R2F_FFT_EXP
-#define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
-#endif
+    cplx v[16];  // v[m]: element l + LPL m of the row
     if (R2F_FFT_EXP & 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
-    } else if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x 256 plane, no reflection
+    } else if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x nx plane, no reflection
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = make_double2((double)src[(long long)r * kN + l + 16 * m], 0.0);
+        for (int m = 0; m < 16; ++m) v[m] = make_double2((double)src[(long long)r * NX + l + LPL * m], 0.0);
     } else {
         const float* rowA = src;
         const float* rowB = src;
@@ -179,7 +262,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 
             rowB = src + (long long)clampi(sy, 0, a.src.rows - 1) * a.W;
         }
         // windows that do not touch the left / right frame edge (all but two per row of windows) need no reflection
-        const bool inA = wxA >= 0 && wxA + kN <= a.W, inB = wxB >= 0 && wxB + kN <= a.W;
+        const bool inA = wxA >= 0 && wxA + NX <= a.W, inB = wxB >= 0 && wxB + NX <= a.W;
         // all loads of a window are issued before the first one is used (a per-element `has ? load : 0` had compiled into
         // thirty-two branches, each waiting for its own load)
         float fa[16], fb[16];
@@ -189,84 +272,120 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 
             if (inA) {
                 const float* pa = rowA + wxA + l;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) fa[m] = pa[16 * m];
+                for (int m = 0; m < 16; ++m) fa[m] = pa[LPL * m];
             } else {
 #pragma unroll
-                for (int m = 0; m < 16; ++m) fa[m] = rowA[reflect101(wxA + l + 16 * m, a.W)];
+                for (int m = 0; m < 16; ++m) fa[m] = rowA[reflect101(wxA + l + LPL * m, a.W)];
             }
         }
         if (hasB) {
             if (inB) {
                 const float* pb = rowB + wxB + l;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) fb[m] = pb[16 * m];
+                for (int m = 0; m < 16; ++m) fb[m] = pb[LPL * m];
             } else {
 #pragma unroll
-                for (int m = 0; m < 16; ++m) fb[m] = rowB[reflect101(wxB + l + 16 * m, a.W)];
+                for (int m = 0; m < 16; ++m) fb[m] = rowB[reflect101(wxB + l + LPL * m, a.W)];
             }
         }
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2((double)fa[m], (double)fb[m]);
     }
-    if (!(R2F_FFT_EXP & 4)) fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
-    cplx* s1 = a.s1 + (long long)pair * kN * kN;
+    if (!(R2F_FFT_EXP & 4)) {
+        if (X512)
+            fft512<false>(v, a.tw512[l], wave_tbuf(fsm), lane);
+        else
+            fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
+    }
+    cplx* s1 = a.s1 + (long long)pair * kN * NX;
     if (R2F_FFT_EXP & 2) {
         if (v[3].x == 1.2345e300) s1[0] = v[5];  // keep the transform alive without storing
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s1[sidx(r, l + 16 * q)] = v[q];
+    for (int q = 0; q < 16; ++q) at(s1, sidx(r, G::out_col(l, q), G::NBX)) = v[q];
+}
+
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_rows_fwd_body<false>(a, fsm);
+}
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_x512_kernel(const FftConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_rows_fwd_body<true>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
-// grid (256 / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.
+// grid (nx / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.  NBX = nx / 16.
 // mode 0: forward along r, multiply by the kernel spectrum, inverse, store back
 // mode 1: forward only; the conjugate IS the kernel spectrum (input = the padded kernel image)
-__global__ __launch_bounds__(kFftThreads) void fft_cols_kernel(const FftConvArgs a, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
+template <int NBX>
+__device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
-    cplx* s1 = a.s1 + (long long)pair * kN * kN;
+    cplx* s1 = a.s1 + (long long)pair * kN * (NBX * 16);
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = s1[sidx(l + 16 * m, k)];
+    for (int m = 0; m < 16; ++m) v[m] = at(s1, sidx(l + 16 * m, k, NBX));
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
     const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
     if (mode == 1) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a.kf_out[sidx(l + 16 * q, k)] = make_double2(v[q].x, -v[q].y);
+        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], kf[sidx(l + 16 * q, k)]);
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(l + 16 * q, k, NBX)));
     fft256<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 16 * q < a.vy) s1[sidx(l + 16 * q, k)] = v[q];  // pass 3 never reads the rows past the valid outputs
+        if (l + 16 * q < a.vy) at(s1, sidx(l + 16 * q, k, NBX)) = v[q];  // pass 3 never reads the rows past the valid outputs
+}
+
+#ifndef R2F_FFT_WPE2
+#define R2F_FFT_WPE2 2
+#endif
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_kernel(const FftConvArgs a, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_cols_body<16>(a, mode, fsm);
+}
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_x512_kernel(const FftConvArgs a, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_cols_body<32>(a, mode, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
-// grid (ceil(vy / 16), pairs)
-__global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    const int lane = threadIdx.x & 63, l = lane & 15;
-    const int pair = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const cplx* s1 = a.s1 + (long long)pair * kN * kN;
-    cplx v[16];
+// grid (ceil(vy / rows per workgroup), pairs); lanes and rows as in pass 1
 #ifndef R2F_FFT_EXP3
 #define R2F_FFT_EXP3 0  // development switch for pass 3: bit 0 no loads, bit 1 no stores, bit 2 no transform
 #endif
+#ifndef R2F_FFT_CURVE_BATCH
+#define R2F_FFT_CURVE_BATCH 16
+#endif
+template <bool X512, bool EPI>
+__device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
+    typedef RowGeom<X512> G;
+    constexpr int NX = G::NX, LPL = G::LPL;
+    const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
+    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
+    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
+    const cplx* s1 = a.s1 + (long long)pair * kN * NX;
+    cplx v[16];
     if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
     } else {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = s1[sidx(live ? r : 0, l + 16 * m)];
+        for (int m = 0; m < 16; ++m) v[m] = at(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
     }
-    if (!(R2F_FFT_EXP3 & 4)) fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
+    if (!(R2F_FFT_EXP3 & 4)) {
+        if (X512)
+            fft512<true>(v, a.tw512[l], wave_tbuf(fsm), lane);
+        else
+            fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
+    }
     if (!live) return;
     if (R2F_FFT_EXP3 & 2) {
         if (v[3].x == 1.2345e300) a.dst.data[0] = (float)v[5].y;
@@ -274,34 +393,41 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
     }
     const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc, ch = a.chan[ci];
     float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
+    constexpr double scale = 1.0 / ((double)NX * kN);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         int wy, wx;
         if (!window_of(a, 2 * pc + half, wy, wx)) continue;
         const int gy = wy + a.ay + r;
         if (gy >= a.y1) continue;
-        float* drow = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax + l;
+        float* dbase = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax;
         // the 16 outputs of this lane first, then the curve on all of them at once (independent gathers), then the stores
         float o[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) o[q] = (float)((half ? v[q].y : v[q].x) * (1.0 / 65536.0));
-        if (a.epilogue == 1) {
+        for (int q = 0; q < 16; ++q) o[q] = (float)((half ? v[q].y : v[q].x) * scale);
+        if (EPI) {
+            constexpr int CB = R2F_FFT_CURVE_BATCH;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) o[q] = log10_fast(o[q], a.log_eps);
-            curve_eval_batch<16, 1>(a.curve.cells, a.curve, ch, o);
+            for (int b = 0; b < 16 / CB; ++b) {
+                float ob[CB];
+#pragma unroll
+                for (int q = 0; q < CB; ++q) ob[q] = log10_fast(o[CB * b + q], a.log_eps);
+                curve_eval_batch<CB, 1>(a.curve.cells, a.curve, ch, ob);
+#pragma unroll
+                for (int q = 0; q < CB; ++q) o[CB * b + q] = ob[q];
+            }
         }
         const int c_end = min(a.vx, a.W - (wx + a.ax));  // columns [0, c_end) of the window are valid outputs inside the frame
         if (a.vec4) {
-            // lane l holds columns l + 16 q; through this line's (idle) transpose buffer every lane gets four neighbouring
-            // columns and stores them as one float4 (window origins and the frame width are multiples of 4 here)
-            float* tf = reinterpret_cast<float*>(wave_tbuf(fsm) + (lane >> 4) * kTLine);
+            // through this line's (idle) transpose buffer every lane gets four neighbouring columns and stores them as one
+            // float4 (window origins and the frame width are multiples of 4 here)
+            float* tf = reinterpret_cast<float*>(G::line_buf(wave_tbuf(fsm), lane));
 #pragma unroll
-            for (int q = 0; q < 16; ++q) tf[l + 16 * q] = o[q];
+            for (int q = 0; q < 16; ++q) tf[G::out_col(l, q)] = o[q];
             __builtin_amdgcn_wave_barrier();
-            float* dbase = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int c = 4 * (l + 16 * j);
+                const int c = 4 * (l + LPL * j);
                 const float4 val = *reinterpret_cast<const float4*>(tf + c);
                 if (c < c_end) *reinterpret_cast<float4*>(dbase + c) = val;
             }
@@ -309,9 +435,18 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_inv_kernel(const FftConv
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (l + 16 * q < c_end) drow[16 * q] = o[q];
+                if (G::out_col(l, q) < c_end) dbase[G::out_col(l, q)] = o[q];
         }
     }
+}
+
+#ifndef R2F_FFT_WPE3
+#define R2F_FFT_WPE3 2
+#endif
+template <bool X512, bool EPI>
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (X512 ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_rows_inv_body<X512, EPI>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
@@ -320,18 +455,37 @@ static size_t fft_lds_bytes() { return (size_t)(kFftThreads / 64) * 4 * kTLine *
 hipError_t fft_init_attributes() { return hipSuccess; }
 
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(kN / 16, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+    if (a.nx == 512)
+        hipLaunchKernelGGL(fft_rows_fwd_x512_kernel, dim3(kN / RowGeom<true>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(kN / RowGeom<false>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(fft_cols_kernel, dim3(kN / 16, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
+    const dim3 grid(a.nx / 16, a.npairs);
+    if (a.nx == 512)
+        hipLaunchKernelGGL(fft_cols_x512_kernel, grid, dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
+    else
+        hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
     return hipGetLastError();
 }
 
+template <bool X512>
+static void launch_rows_inv(const FftConvArgs& a, hipStream_t s) {
+    const int rows = RowGeom<X512>::ROWS;
+    const dim3 grid((a.vy + rows - 1) / rows, a.npairs);  // rows beyond the valid outputs are never stored
+    if (a.epilogue == 1)
+        hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+}
+
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s) {
-    const int blocks = (a.vy + 15) / 16;  // rows beyond the valid outputs are never stored
-    hipLaunchKernelGGL(fft_rows_inv_kernel, dim3(blocks, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+    if (a.nx == 512)
+        launch_rows_inv<true>(a, s);
+    else
+        launch_rows_inv<false>(a, s);
     return hipGetLastError();
 }
 

@@ -43,14 +43,17 @@ def uses_fft(ctx, which):
     return [c["fft"] for c in ctx.stencil_stats(which)]
 
 
-@pytest.mark.parametrize("shape", [(300, 417), (64, 64), (1, 7), (9, 1), (257, 256), (173, 344), (601, 130)])
-def test_fft_form_matches_oracle_and_direct_form(ctx, shape):
+@pytest.mark.parametrize("window", [256, 512])
+@pytest.mark.parametrize("shape", [(300, 417), (64, 64), (1, 7), (9, 1), (257, 256), (173, 344), (601, 130), (200, 1100)])
+def test_fft_form_matches_oracle_and_direct_form(ctx, shape, window):
+    ctx.set_option("stencil_fft_window", window)
     rng = np.random.default_rng(shape[0])
     img = rng.uniform(0.0, 2.0, shape + (3,)).astype(np.float32)
     img[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = 500.0  # a specular next to shadows: the fp32-FFT killer
     k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 x 87, blue plane = identity
     a = run(ctx, 0, img, k, 1)
     assert uses_fft(ctx, 0) == [1, 1, 0]
+    assert [c["window"] for c in ctx.stencil_stats(0)] == [(256, window), (256, window), None]
     b = run(ctx, 0, img, k, 0)
     ref = st.convolve_2d(img, k)
     assert_close(a, ref, 2e-6, 1e-2, "fft form")  # fp64 inside: an order of magnitude tighter than the fp32 direct sum needs
@@ -78,8 +81,10 @@ def test_eligibility_limits(ctx):
     assert_close(out, st.convolve_2d(img, np.repeat(k / k.sum(), 3, axis=2)), 1e-5, 1e-2, "3 x 87 by FFT")
 
 
-def test_arbitrary_taps_and_anchor(ctx):
+@pytest.mark.parametrize("window", [256, 512])
+def test_arbitrary_taps_and_anchor(ctx, window):
     """Nothing symmetric, negative taps, an off-centre bounding box: the anchor stays cv.filter2D's (kh/2, kw/2)."""
+    ctx.set_option("stencil_fft_window", window)
     rng = np.random.default_rng(3)
     img = rng.uniform(0, 1, (200, 310, 3)).astype(np.float32)
     k = np.zeros((61, 45, 3), np.float32)
@@ -106,13 +111,35 @@ def test_row_range_with_halo_rows_equals_the_whole_frame_to_rounding(ctx):
         assert np.abs(part - whole[y0:y1]).max() <= 5e-7  # other windows, same fp64 arithmetic: at most an ulp of fp32
 
 
-def test_batching_does_not_change_a_bit(ctx):
+@pytest.mark.parametrize("window", [256, 512])
+def test_batching_does_not_change_a_bit(ctx, window):
+    ctx.set_option("stencil_fft_window", window)
     rng = np.random.default_rng(5)
     img = rng.uniform(0, 2, (520, 530, 3)).astype(np.float32)
     k = ok.mtf_kernel(stocks()[0].mtf, 341.33)  # 35 x 35 x 3: 9 windows per channel
     ref = run(ctx, 1, img, k, 1)
     for batch in (1, 2, 3, 7):
         np.testing.assert_array_equal(run(ctx, 1, img, k, 1, stencil_fft_batch=batch), ref)
+
+
+def test_window_width_follows_the_frame_width_and_spectra_follow_the_window(ctx):
+    """The default picks the width that covers a frame row with fewer scratch columns; switching it rebuilds the spectra."""
+    rng = np.random.default_rng(8)
+    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 taps: 168 valid columns of 256, 424 of 512
+    cols = np.nonzero(k[..., 0].any(axis=0))[0]
+    bw = int(cols[-1] - cols[0] + 1)
+    v256, v512 = (256 - bw + 1) & ~3, (512 - bw + 1) & ~3
+    seen = set()
+    for W in (160, 300, v512, v512 + 6, 600, 1700):
+        want = 512 if -(-W // v512) * 512 < -(-W // v256) * 256 else 256
+        seen.add(want)
+        img = rng.uniform(0, 2, (40, W, 3)).astype(np.float32)
+        out = run(ctx, 0, img, k, 1)
+        assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(256, want)] * 2, W
+        assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-2, f"width {W}")
+    assert seen == {256, 512}
+    with pytest.raises(Exception):
+        ctx.set_option("stencil_fft_window", 384)
 
 
 def test_kernel_change_rebuilds_the_spectrum(ctx):
