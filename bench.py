@@ -193,14 +193,17 @@ def main():
         if any(c["fft"] for c in st) and fft_ms[1][1] > 0:
             # The stencils run as fp64 overlap-save FFTs; their column pass is the kernel with the largest share of the step.
             tot_ms, launches, bytes_alg = fft_ms[1]
+            win = next(c["window"] for c in st if c["fft"])  # (rows, columns) of the halation windows; the MTF's may differ
+            cols_kernel = {(256, 256): "fft_cols_kernel", (256, 512): "fft_cols_x512_kernel", (512, 256): "fft_cols_y512_kernel",
+                           (512, 512): "fft_cols_y512_x512_kernel"}[tuple(win)]
             if tfiles and world == 1 and args.config == "cfg4_100mp":
                 for name, rec in json.load(open(os.path.join(ROOT, "profiles", tfiles[-1]))).items():
-                    if "fft_cols_kernel" in name:
+                    if cols_kernel + "(" in name:
                         traffic = rec["hbm_bytes_per_launch"]
             gbps = bytes_alg / (tot_ms * 1e-3) / 1e9
             result["roofline"] = {
-                "kernel": "r2f::fft_cols_kernel (pass 2 of the fp64 overlap-save FFT stencils: column FFT, x kernel spectrum, "
-                          "inverse column FFT, in place; halation and MTF launches together)",
+                "kernel": f"r2f::{cols_kernel} (pass 2 of the fp64 overlap-save FFT stencils, windows of {win[0]} rows x {win[1]} "
+                          "columns: column FFT, x kernel spectrum, inverse column FFT, in place; halation and MTF launches together)",
                 "bound": "hbm",
                 "achieved": gbps,
                 "peak": HBM_PEAK_GBPS,
@@ -210,8 +213,9 @@ def main():
                 "kernel_ms": tot_ms / launches,
                 "launches_per_step": launches / args.steps,
                 "bytes_per_launch": bytes_alg / launches,
-                "bytes_counted": "per window pair: the 256 x 256 complex128 scratch image read (1 MiB) + its rows that hold valid "
-                                 "outputs written back ((256 - k + 1) / 256 MiB); the 1 MiB kernel spectrum is L2-resident",
+                "bytes_counted": f"per window pair: the {win[0]} x {win[1]} complex128 scratch image read ({win[0] * win[1] >> 16} MiB) + "
+                                 f"its rows that hold valid outputs written back (({win[0]} - k + 1) / {win[0]} of it); the kernel "
+                                 "spectrum (same size) is L2-resident",
                 "passes_ms_per_step": {"rows_fwd": extra[0][0] / 2, "cols": fft_ms[1][0] / args.steps, "rows_inv": extra[2][0] / 2,
                                        "note": "cols: events in the timed steps; the other two passes: two extra steps after them"},
                 "concurrency": "launches alternate between two internal streams, so two FFT-pass kernels usually share the GPU: "

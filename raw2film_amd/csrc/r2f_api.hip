@@ -64,7 +64,8 @@ struct r2f_ctx {
     DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_kimg;
     bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
     int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 1024 + nx) each spectrum was built for
-    int opt_fft_window = 0;      // window columns: 0 = the cheaper of 256 / 512 per stencil and frame width, or one of them forced
+    int opt_fft_window = 0;      // window columns: 0 = the cheaper of 256 / 512 per stencil and frame, or one of them forced
+    int opt_fft_window_rows = 0;  // window rows, likewise
     // optional per-launch timing of the FFT passes with events on the launch stream (bench.py's roofline): class 0 / 1 / 2 =
     // pass 1 / 2 / 3; algorithmic bytes are summed alongside
     int opt_timing = 0;
@@ -453,29 +454,40 @@ void tap_box(const StencilSet& s, int c, int box[4]) {
     box[0] = i_lo, box[1] = i_hi, box[2] = j_lo, box[3] = j_hi;
 }
 
+constexpr int kFftMaxTaps = 400;
+
 // Does channel c of stencil `which` take the overlap-save FFT form?
 bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     if (!ctx->opt_fft) return false;
     int b[4];
     tap_box(s, c, b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
-    // up to 200 taps a side: a 256-point window then still yields 57 x 56 outputs, and the FFT form stays ahead of the direct
-    // sum (whose cost grows with the tap count) until ~220
-    return bh <= 200 && bw <= 200 && bh * bw >= ctx->opt_fft_min_taps;
+    // up to 400 taps a side: a 512-point window then still yields 113 x 112 outputs (boxes over 200 taps on an axis take the
+    // 512-point window there, see fft_window)
+    return bh <= kFftMaxTaps && bw <= kFftMaxTaps && bh * bw >= ctx->opt_fft_min_taps;
 }
 
-// Window width for a tap box bw wide on a frame W wide: 256 or 512 columns, whichever covers a row of the frame with fewer
-// scratch columns (windows x nx).  Rows per window stay 256: pass 2 then still skips the rows without valid outputs, and
-// a 512-point column transform does not fit the register file.  Chosen from the frame width alone, so every row shard of a
-// frame (and every call on it) uses the same shape and the kernel spectra are built once.
-void fft_window(const r2f_ctx* ctx, int bw, int W, int* ny, int* nx) {
-    *ny = kFftN;
-    if (ctx->opt_fft_window) {
-        *nx = ctx->opt_fft_window;
-        return;
+// Window shape for a bh x bw tap box on a W x H frame: of {256, 512} rows x {256, 512} columns the one whose three passes
+// move the fewest scratch bytes (an 87-tap disc keeps 44 % of a 256 x 256 window and 69 % of a 512 x 512 one).  Chosen from
+// the GLOBAL frame, so every row shard of a frame (and every call on it) uses the same shape and the kernel spectra are
+// built once.  stencil_fft_window / stencil_fft_window_rows force an axis (ignored for a box over 200 taps on that axis,
+// which needs the 512-point window).
+void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, int* ny, int* nx) {
+    double best = -1.0;
+    for (int y = 256; y <= 512; y *= 2) {
+        if (bh > 200 ? y != 512 : (ctx->opt_fft_window_rows && y != ctx->opt_fft_window_rows)) continue;
+        for (int x = 256; x <= 512; x *= 2) {
+            if (bw > 200 ? x != 512 : (ctx->opt_fft_window && x != ctx->opt_fft_window)) continue;
+            const int vy = y - bh + 1, vx = (x - bw + 1) & ~3;
+            const double n = (double)y * x, part = n * vy / y;
+            // per window: pass 1 (floats in, image out), pass 2 (image in, valid rows out), pass 3 (valid rows in, floats out);
+            // two windows share one complex image.  The 512-row pass 2 moves its bytes ~1.3 x slower (r2f_fft.hip).
+            const double p2 = y == 512 ? 1.3 : 1.0;
+            const double bytes = 4.0 * n + 8.0 * n + p2 * (8.0 * n + 8.0 * part) + 8.0 * part + 4.0 * vy * vx;
+            const double cost = (double)((W + vx - 1) / vx) * ((H + vy - 1) / vy) * bytes;
+            if (best < 0.0 || cost < best) best = cost, *ny = y, *nx = x;
+        }
     }
-    const int v256 = (256 - bw + 1) & ~3, v512 = (512 - bw + 1) & ~3;
-    *nx = (long long)((W + v512 - 1) / v512) * 512 < (long long)((W + v256 - 1) / v256) * 256 ? 512 : 256;
 }
 
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
@@ -487,7 +499,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     tap_box(set, chans[0], b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
     int ny = 256, nx = 256;
-    fft_window(ctx, bw, W, &ny, &nx);
+    fft_window(ctx, bh, bw, W, H, &ny, &nx);
     const size_t img = (size_t)ny * nx;
     if (!ctx->fft_tw.p) {
         // W_256^k, k < 256, then W_512^k, k < 256
@@ -504,7 +516,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     memset(&a, 0, sizeof a);
     a.tw = static_cast<const double2*>(ctx->fft_tw.p);
     a.tw512 = a.tw + kFftN;
-    a.nx = nx;
+    a.ny = ny, a.nx = nx;
     a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
     a.ax = set.kw / 2 - b[2];
     a.vy = ny - bh + 1;
@@ -778,6 +790,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_window")) {
         if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window must be 0, 256 or 512");
         ctx->opt_fft_window = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_window_rows")) {
+        if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window_rows must be 0, 256 or 512");
+        ctx->opt_fft_window_rows = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_min_taps")) {

@@ -188,6 +188,46 @@ __device__ __forceinline__ void fft512(cplx (&v)[16], const cplx w1, double* tbu
     }
 }
 
+// The same transform with the index maps exchanged (the transposed flow graph): on entry v[i] of lane l holds element
+// 256 (l & 1) + 16 i + (l >> 1) -- what fft512 leaves -- and on return v[j] holds output element l + 32 j.  Pass 2 runs
+// fft512 forward, multiplies in place, and comes back through this one: no re-ordering in between.
+template <bool INV>
+__device__ __forceinline__ void fft512_rev(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
+    constexpr double kC32[16] = {1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058};
+    constexpr double kS32[16] = {0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891};
+    const int l = lane & 31;
+    const bool odd = l & 1;
+    // radix-2 across the lane pair, decimation in frequency: even lane S[i] = X[i] + X[16 + i] (-> even outputs),
+    // odd lane D[i] = (X[i] - X[16 + i]) W_32^i (-> odd outputs)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const cplx o = make_double2(swap_lane1(v[i].x), swap_lane1(v[i].y));
+        v[i] = odd ? csub(o, v[i]) : cadd(v[i], o);
+    }
+    if (odd) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v[i] = ctw<INV>(v[i], make_double2(kC32[i], -kS32[i]));
+    }
+    dft16<INV>(v);  // lane (p, h), register m: B[2 m + h][p]
+    double* t = tbuf + (lane >> 5) * kTLine512;
+    double* wr = t + (l >> 1) * kTPitch512 + (l & 1);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wr[2 * m] = v[m].x;
+    __builtin_amdgcn_wave_barrier();
+    double re[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) re[p] = t[p * kTPitch512 + l];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wr[2 * m] = v[m].y;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) v[p] = make_double2(re[p], t[p * kTPitch512 + l]);
+    __builtin_amdgcn_wave_barrier();
+    twiddle_powers<INV>(v, w1);
+    dft16<INV>(v);
+}
+
 // window origin (first input row / column) and validity of window `t` of the launch
 __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, int& wx) {
     if (t >= a.ntiles) return false;
@@ -247,7 +287,7 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     if (R2F_FFT_EXP & 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
-    } else if (a.raw) {  // the zero-padded kernel image itself: a plain 256 x nx plane, no reflection
+    } else if (a.raw) {  // the zero-padded kernel image itself: a plain ny x nx plane, no reflection
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2((double)src[(long long)r * NX + l + LPL * m], 0.0);
     } else {
@@ -297,7 +337,7 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
         else
             fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
     }
-    cplx* s1 = a.s1 + (long long)pair * kN * NX;
+    cplx* s1 = a.s1 + (long long)pair * a.ny * NX;
     if (R2F_FFT_EXP & 2) {
         if (v[3].x == 1.2345e300) s1[0] = v[5];  // keep the transform alive without storing
         return;
@@ -344,6 +384,37 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
         if (l + 16 * q < a.vy) at(s1, sidx(l + 16 * q, k, NBX)) = v[q];  // pass 3 never reads the rows past the valid outputs
 }
 
+// 512-row windows: 32 lanes per column, 8 columns per workgroup, 2 per wave; forward by fft512, back by fft512_rev.
+// Spectrum rows are in fft512's output order (the kernel spectrum is built by the same pass, mode 1).  A wave touches two
+// of the four interleaved columns of the scratch layout, i.e. 32-byte pieces: measured ~25 % slower per byte than the
+// 256-row pass (the host's window choice prices that in; tall kernels have no alternative).  (Pairs as the fast grid index,
+// to share spectrum blocks between the workgroups in flight, was slower for every shape: 7.04 -> 7.46 ms at 256 x 256.)
+template <int NBX>
+__device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const int mode, double* fsm) {
+    const int lane = threadIdx.x & 63, l = lane & 31;
+    const int pair = blockIdx.y, k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    cplx* s1 = a.s1 + (long long)pair * 512 * (NBX * 16);
+    cplx v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = at(s1, sidx(l + 32 * m, k, NBX));
+    const cplx w1 = a.tw512[l];
+    double* tbuf = wave_tbuf(fsm);
+    fft512<false>(v, w1, tbuf, lane);
+    const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
+    const int f0 = 256 * (l & 1) + (l >> 1);  // spectrum row of register q: f0 + 16 q
+    if (mode == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(f0 + 16 * q, k, NBX)));
+    fft512_rev<true>(v, w1, tbuf, lane);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (l + 32 * q < a.vy) at(s1, sidx(l + 32 * q, k, NBX)) = v[q];  // pass 3 never reads the rows past the valid outputs
+}
+
 #ifndef R2F_FFT_WPE2
 #define R2F_FFT_WPE2 2
 #endif
@@ -354,6 +425,15 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_x512_kernel(const FftConvArgs a, const int mode) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     fft_cols_body<32>(a, mode, fsm);
+}
+
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_y512_kernel(const FftConvArgs a, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_cols_y512_body<16>(a, mode, fsm);
+}
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_y512_x512_kernel(const FftConvArgs a, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    fft_cols_y512_body<32>(a, mode, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -371,7 +451,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
     const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
     const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const cplx* s1 = a.s1 + (long long)pair * kN * NX;
+    const cplx* s1 = a.s1 + (long long)pair * a.ny * NX;
     cplx v[16];
     if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
@@ -393,7 +473,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     }
     const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc, ch = a.chan[ci];
     float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
-    constexpr double scale = 1.0 / ((double)NX * kN);
+    const double scale = 1.0 / ((double)NX * a.ny);  // a power of two
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         int wy, wx;
@@ -456,18 +536,27 @@ hipError_t fft_init_attributes() { return hipSuccess; }
 
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     if (a.nx == 512)
-        hipLaunchKernelGGL(fft_rows_fwd_x512_kernel, dim3(kN / RowGeom<true>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+        hipLaunchKernelGGL(fft_rows_fwd_x512_kernel, dim3(a.ny / RowGeom<true>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
     else
-        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(kN / RowGeom<false>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(a.ny / RowGeom<false>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    const dim3 grid(a.nx / 16, a.npairs);
-    if (a.nx == 512)
-        hipLaunchKernelGGL(fft_cols_x512_kernel, grid, dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
-    else
-        hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(kFftThreads), fft_lds_bytes(), s, a, mode);
+    const dim3 block(kFftThreads);
+    if (a.ny == 512) {
+        const dim3 grid(a.nx / 8, a.npairs);
+        if (a.nx == 512)
+            hipLaunchKernelGGL(fft_cols_y512_x512_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+        else
+            hipLaunchKernelGGL(fft_cols_y512_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+    } else {
+        const dim3 grid(a.nx / 16, a.npairs);
+        if (a.nx == 512)
+            hipLaunchKernelGGL(fft_cols_x512_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+        else
+            hipLaunchKernelGGL(fft_cols_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+    }
     return hipGetLastError();
 }
 

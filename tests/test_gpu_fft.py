@@ -43,17 +43,25 @@ def uses_fft(ctx, which):
     return [c["fft"] for c in ctx.stencil_stats(which)]
 
 
-@pytest.mark.parametrize("window", [256, 512])
-@pytest.mark.parametrize("shape", [(300, 417), (64, 64), (1, 7), (9, 1), (257, 256), (173, 344), (601, 130), (200, 1100)])
+WINDOWS = [(256, 256), (256, 512), (512, 256), (512, 512)]  # rows x columns
+
+
+def force_window(ctx, window):
+    ctx.set_option("stencil_fft_window_rows", window[0])
+    ctx.set_option("stencil_fft_window", window[1])
+
+
+@pytest.mark.parametrize("window", WINDOWS)
+@pytest.mark.parametrize("shape", [(300, 417), (64, 64), (1, 7), (9, 1), (257, 256), (173, 344), (601, 130), (200, 1100), (900, 70)])
 def test_fft_form_matches_oracle_and_direct_form(ctx, shape, window):
-    ctx.set_option("stencil_fft_window", window)
+    force_window(ctx, window)
     rng = np.random.default_rng(shape[0])
     img = rng.uniform(0.0, 2.0, shape + (3,)).astype(np.float32)
     img[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = 500.0  # a specular next to shadows: the fp32-FFT killer
     k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 x 87, blue plane = identity
     a = run(ctx, 0, img, k, 1)
     assert uses_fft(ctx, 0) == [1, 1, 0]
-    assert [c["window"] for c in ctx.stencil_stats(0)] == [(256, window), (256, window), None]
+    assert [c["window"] for c in ctx.stencil_stats(0)] == [window, window, None]
     b = run(ctx, 0, img, k, 0)
     ref = st.convolve_2d(img, k)
     assert_close(a, ref, 2e-6, 1e-2, "fft form")  # fp64 inside: an order of magnitude tighter than the fp32 direct sum needs
@@ -64,7 +72,7 @@ def test_fft_form_matches_oracle_and_direct_form(ctx, shape, window):
 def test_eligibility_limits(ctx):
     img = np.random.default_rng(1).uniform(0, 1, (140, 150, 3)).astype(np.float32)
     rng = np.random.default_rng(2)
-    for n, expect in ((19, 0), (21, 1), (129, 1), (171, 1), (199, 1), (201, 0)):  # >= 400 taps and at most 200 x 200
+    for n, expect in ((19, 0), (21, 1), (129, 1), (171, 1), (199, 1), (201, 1)):  # >= 400 taps (and at most 400 x 400, below)
         k = rng.uniform(-0.2, 1.0, (n, n, 1)).astype(np.float32)
         k /= k.sum()
         out = run(ctx, 1, img, k, 1)
@@ -81,10 +89,29 @@ def test_eligibility_limits(ctx):
     assert_close(out, st.convolve_2d(img, np.repeat(k / k.sum(), 3, axis=2)), 1e-5, 1e-2, "3 x 87 by FFT")
 
 
-@pytest.mark.parametrize("window", [256, 512])
+@pytest.mark.parametrize("box, window", [((201, 201), (512, 512)), ((301, 25), (512, None)), ((25, 301), (None, 512)),
+                                         ((399, 399), (512, 512)), ((400, 30), (512, None)), ((401, 25), None)])
+def test_boxes_over_200_taps_take_the_512_point_window_on_that_axis(ctx, box, window):
+    """Up to 400 taps a side; the 256-point window (also when forced) cannot hold more than 200."""
+    rng = np.random.default_rng(box[0])
+    img = rng.uniform(0, 1, (230, 240, 3)).astype(np.float32)
+    k = rng.uniform(-0.1, 1.0, box + (1,)).astype(np.float32)
+    k /= k.sum()
+    force_window(ctx, (256, 256))
+    out = run(ctx, 1, img, k, 1)
+    got = ctx.stencil_stats(1)[0]
+    if window is None:
+        assert got["fft"] == 0
+    else:
+        assert got["fft"] == 1
+        assert got["window"] == tuple(w or 256 for w in window)
+    assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-2, f"{box} taps")
+
+
+@pytest.mark.parametrize("window", WINDOWS)
 def test_arbitrary_taps_and_anchor(ctx, window):
     """Nothing symmetric, negative taps, an off-centre bounding box: the anchor stays cv.filter2D's (kh/2, kw/2)."""
-    ctx.set_option("stencil_fft_window", window)
+    force_window(ctx, window)
     rng = np.random.default_rng(3)
     img = rng.uniform(0, 1, (200, 310, 3)).astype(np.float32)
     k = np.zeros((61, 45, 3), np.float32)
@@ -94,7 +121,9 @@ def test_arbitrary_taps_and_anchor(ctx, window):
     assert_close(out, st.convolve_2d(img, k), 1e-5, 1.0, "arbitrary taps")
 
 
-def test_row_range_with_halo_rows_equals_the_whole_frame_to_rounding(ctx):
+@pytest.mark.parametrize("rows", [256, 512])
+def test_row_range_with_halo_rows_equals_the_whole_frame_to_rounding(ctx, rows):
+    ctx.set_option("stencil_fft_window_rows", rows)
     rng = np.random.default_rng(4)
     H, W = 700, 260
     img = rng.uniform(0, 2, (H, W, 3)).astype(np.float32)
@@ -111,9 +140,9 @@ def test_row_range_with_halo_rows_equals_the_whole_frame_to_rounding(ctx):
         assert np.abs(part - whole[y0:y1]).max() <= 5e-7  # other windows, same fp64 arithmetic: at most an ulp of fp32
 
 
-@pytest.mark.parametrize("window", [256, 512])
+@pytest.mark.parametrize("window", WINDOWS)
 def test_batching_does_not_change_a_bit(ctx, window):
-    ctx.set_option("stencil_fft_window", window)
+    force_window(ctx, window)
     rng = np.random.default_rng(5)
     img = rng.uniform(0, 2, (520, 530, 3)).astype(np.float32)
     k = ok.mtf_kernel(stocks()[0].mtf, 341.33)  # 35 x 35 x 3: 9 windows per channel
@@ -122,24 +151,36 @@ def test_batching_does_not_change_a_bit(ctx, window):
         np.testing.assert_array_equal(run(ctx, 1, img, k, 1, stencil_fft_batch=batch), ref)
 
 
-def test_window_width_follows_the_frame_width_and_spectra_follow_the_window(ctx):
-    """The default picks the width that covers a frame row with fewer scratch columns; switching it rebuilds the spectra."""
+def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
+    """The default picks the shape whose passes move the fewest scratch bytes; switching it rebuilds the spectra."""
     rng = np.random.default_rng(8)
-    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 taps: 168 valid columns of 256, 424 of 512
-    cols = np.nonzero(k[..., 0].any(axis=0))[0]
-    bw = int(cols[-1] - cols[0] + 1)
-    v256, v512 = (256 - bw + 1) & ~3, (512 - bw + 1) & ~3
+    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 taps
+    nz = np.nonzero(k[..., 0])
+    bh, bw = int(nz[0].max() - nz[0].min() + 1), int(nz[1].max() - nz[1].min() + 1)
+
+    def want(H, W):
+        best = None
+        for y in (256, 512):
+            for x in (256, 512):
+                vy, vx = y - bh + 1, (x - bw + 1) & ~3
+                n = y * x
+                part, p2 = n * vy / y, (1.3 if y == 512 else 1.0)
+                cost = -(-W // vx) * -(-H // vy) * (4.0 * n + 8.0 * n + p2 * (8.0 * n + 8.0 * part) + 8.0 * part + 4.0 * vy * vx)
+                if best is None or cost < best[0]:
+                    best = (cost, (y, x))
+        return best[1]
+
     seen = set()
-    for W in (160, 300, v512, v512 + 6, 600, 1700):
-        want = 512 if -(-W // v512) * 512 < -(-W // v256) * 256 else 256
-        seen.add(want)
-        img = rng.uniform(0, 2, (40, W, 3)).astype(np.float32)
+    for H, W in ((40, 160), (40, 300), (40, 430), (300, 160), (400, 420), (180, 1700), (700, 100)):
+        seen.add(want(H, W))
+        img = rng.uniform(0, 2, (H, W, 3)).astype(np.float32)
         out = run(ctx, 0, img, k, 1)
-        assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(256, want)] * 2, W
-        assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-2, f"width {W}")
-    assert seen == {256, 512}
-    with pytest.raises(Exception):
-        ctx.set_option("stencil_fft_window", 384)
+        assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [want(H, W)] * 2, (H, W)
+        assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-2, f"frame {H} x {W}")
+    assert len(seen) >= 3, seen
+    for name in ("stencil_fft_window", "stencil_fft_window_rows"):
+        with pytest.raises(Exception):
+            ctx.set_option(name, 384)
 
 
 def test_kernel_change_rebuilds_the_spectrum(ctx):

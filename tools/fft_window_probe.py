@@ -24,12 +24,13 @@ def timeit(fn, iters=5):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
     return best
 print(os.path.basename(_lib.LIB_PATH))
-for window in (256, 512):
-    ctx.set_option("stencil_fft_window", window)
+for window in ((256, 256), (256, 512), (512, 256), (512, 512), (0, 0)):
+    ctx.set_option("stencil_fft_window_rows", window[0])
+    ctx.set_option("stencil_fft_window", window[1])
     for streams in (2,):
         ctx.set_option("stencil_fft_streams", streams)
         t = timeit(lambda: ctx.render(img, params, out_f32=out))
-        print(f"window {window:3d} streams {streams}: render {t:.3f} ms", [c['window'] for c in ctx.stencil_stats(0)][:1],
+        print(f"window {window} streams {streams}: render {t:.3f} ms", [c['window'] for c in ctx.stencil_stats(0)][:1],
               [c['window'] for c in ctx.stencil_stats(1)][:1])
     ctx.set_option("kernel_timing", 7)
     for cls in range(3): ctx.kernel_timing(cls)
