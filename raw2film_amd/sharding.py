@@ -2,15 +2,16 @@
 
 RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GPU
     (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
-    Pixels are independent except for the two stencils, so a frame costs two neighbour
-    exchanges and no reduction:
-        S0+S1 on own rows -> exposure E            exchange r_h rows of E  (halation halo)
-        S2+S3+S4 on own rows -> density D          exchange r_m rows of D  (MTF halo)
+    Pixels are independent except for the two stencils, so a frame costs ONE neighbour
+    exchange (two with single_exchange=False) and no reduction:
+        S0+S1 on own rows -> exposure E            exchange r_h + r_m rows of E  (both stencils' halo)
+        S2+S3+S4 on own rows + r_m -> density D    [or: exchange r_m rows of D  (MTF halo)]
         S5 -> S6 (hash noise at GLOBAL coordinates, no exchange) -> S8 -> own output rows
         [S7 highlight burn, when on: one all-reduce (SUM) of the ~50 x 75 low-res cell sums between S6 and S8]
-    Each exchange is one send + one receive per neighbour, batched (`batch_isend_irecv`, i.e.
-    ncclGroupStart/End): at 100 MP that is 43 / 17 rows x 12288 px x 3 planes x 4 B = 6.3 / 2.5 MB
-    per direction -- latency-bound, every pair on its own xGMI link.  Global top/bottom edges are
+    The exchange is one send + one receive per neighbour and plane, batched (`batch_isend_irecv`, i.e.
+    ncclGroupStart/End): at 100 MP that is 60 rows x 12288 px x 3 planes x 4 B = 8.8 MB per direction
+    -- latency-bound, every pair on its own xGMI link.  S0+S1 runs on the rows the neighbours wait for
+    first and on the interior rows while the halos travel.  Global top/bottom edges are
     reflected (BORDER_REFLECT_101) inside the kernels.  Because every stage accumulates taps in a
     tile-independent order, the sharded result is bit-identical to the single-GPU result.
 
@@ -166,12 +167,14 @@ class RowShardedRenderer:
         self.side_stream = torch.cuda.Stream(device=backend.device) if self.side_grain else None
 
     # ------------------------------------------------------------------ neighbour exchange
-    def _exchange(self, buf, buf_gy0: int, above: int, below: int):
+    def _exchange(self, buf, buf_gy0: int, above: int, below: int, wait: bool = True):
         """Fill the halo rows of `buf` (global rows [buf_gy0, ...)) from the neighbours' own rows.
-        Rank k sends its first `below_of_prev` rows up and its last `above_of_next` rows down."""
+        Rank k sends its first `below_of_prev` rows up and its last `above_of_next` rows down.
+        wait=False: the transfers are only started (RCCL runs them on its own stream, ordered after what the current
+        stream holds now); hand the return value to `_exchange_finish` before the halo rows are read."""
         p, dist, torch = self.plan, self.dist, self.torch
         if p.world == 1 or (above == 0 and below == 0):
-            return
+            return None
         ops, recvs = [], []
         own0 = p.r0 - buf_gy0  # buffer row of the first own row
         # RCCL moves device buffers directly and orders them against the current stream.  gloo (CPU tests,
@@ -205,9 +208,20 @@ class RowShardedRenderer:
                 add_send(own0 + p.rows - above, above, self._peer(p.rank + 1))
             if below:
                 add_recv(own0 + p.rows, below, self._peer(p.rank + 1))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if not wait:
+            return reqs, recvs
+        self._exchange_finish((reqs, recvs))
+        return None
+
+    @staticmethod
+    def _exchange_finish(pending):
+        """Second half of `_exchange(..., wait=False)`: the halo rows are in place (ordered against the current stream)."""
+        if pending is None:
+            return
+        reqs, recvs = pending
+        for req in reqs:
+            req.wait()
         for tmp, block in recvs:
             block.copy_(tmp)
 
@@ -238,8 +252,21 @@ class RowShardedRenderer:
             cur, cur_lo = self.Dplain, p.r0
         else:
             if self.halation:
-                be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
-                self._exchange(self.E, self.e_lo, *p.halo_e)
+                above, below = p.halo_e
+                if p.world > 1 and (above or below) and p.rows >= above + below:
+                    # the rows the neighbours wait for first, then the interior while the halos travel
+                    lo_band = p.r0 + (below if p.rank > 0 else 0)
+                    hi_band = p.r1 - (above if p.rank < p.world - 1 else 0)
+                    if lo_band > p.r0:
+                        be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, lo_band, H)
+                    if hi_band < p.r1:
+                        be.front(image_rows, p.r0, 0, self.E, self.e_lo, hi_band, p.r1, H)
+                    pending = self._exchange(self.E, self.e_lo, above, below, wait=False)
+                    be.front(image_rows, p.r0, 0, self.E, self.e_lo, lo_band, hi_band, H)
+                    self._exchange_finish(pending)
+                else:
+                    be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
+                    self._exchange(self.E, self.e_lo, above, below)
                 if self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
                     be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H)
                 else:
