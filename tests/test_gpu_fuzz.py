@@ -25,6 +25,7 @@ def _cases(n=int(os.environ.get("R2F_FUZZ_CASES", "24"))):  # R2F_FUZZ_CASES=400
             hal_size=float(rng.choice([0.5, 1.0, 1.7])), strength=float(rng.choice([0.0, 0.0, 0.6])),
             grain_size=float(rng.choice([2.0, 6.0, 12.0])), layout=str(rng.choice(["hwc3", "hwc4", "chw"])),
             burn=float(rng.choice([0.0, 0.0, 0.5])), nr=int(rng.choice([0, 0, 2])), seed=int(rng.integers(0, 2**31)),
+            win_rows=int(rng.choice([0, 256, 512])), win_cols=int(rng.choice([0, 256, 512])),  # FFT window shape (0: by cost)
         ))
     return out
 
@@ -60,6 +61,8 @@ def test_random_configuration(ctx, c):
         p.highlight_burn, p.burn_scale, p.d_ref = c["burn"], 20.0, float(stock.d_ref[1])
     ref = st.render(img_o, p)
     params = setup_ctx(ctx, p)
+    ctx.set_option("stencil_fft_window_rows", c["win_rows"])
+    ctx.set_option("stencil_fft_window", c["win_cols"])
     if c["burn"]:
         params.flags |= 32
         params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 20.0)[0], c["burn"], float(stock.d_ref[1])
