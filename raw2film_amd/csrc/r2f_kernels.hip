@@ -441,8 +441,11 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 #endif
     // S6a: hash noise for the tile + halo, straight into LDS.  Coordinates are clamped to the
     // frame like the shader's texture reads (grain.wgsl:63-75); the hash sees GLOBAL coordinates.
-    for (int idx = threadIdx.x; idx < ((R2F_TAIL_EXP & 1) ? 0 : rows * RS); idx += NT) {
-        const int r = idx / RS, c = idx - r * RS;
+    // (row, column) of element idx advance with it: one division per thread, not one per element
+    const int step_r = NT / RS, step_c = NT - step_r * RS;
+    int r = (int)threadIdx.x / RS, c = (int)threadIdx.x - r * RS;
+    for (int idx = threadIdx.x; idx < ((R2F_TAIL_EXP & 1) ? 0 : rows * RS); idx += NT, r += step_r, c += step_c) {
+        if (c >= RS) c -= RS, ++r;
         float nr = 0.f, ng = 0.f, nb = 0.f;
         if (c < cols_valid) {
             const int sx = clampi(tile_x0 - g0.ax + c, 0, a.W - 1);

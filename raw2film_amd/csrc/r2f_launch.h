@@ -194,7 +194,10 @@ extern const StencilVariant kStencilVariants[kNumStencilVariants];
 #ifndef R2F_TAIL_BY
 #define R2F_TAIL_BY 32
 #endif
-constexpr int kTailBX = R2F_TAIL_BX, kTailBY = R2F_TAIL_BY, kTailQ = 2;  // grain/tail tile 64 x 64, 512 threads
+#ifndef R2F_TAIL_Q
+#define R2F_TAIL_Q 2
+#endif
+constexpr int kTailBX = R2F_TAIL_BX, kTailBY = R2F_TAIL_BY, kTailQ = R2F_TAIL_Q;  // grain/tail tile 64 x 64, 512 threads
 constexpr size_t kMaxLds = 160 * 1024;
 
 size_t stencil_lds_bytes(const StencilVariant& v, const DevStencil* st, int nchan);

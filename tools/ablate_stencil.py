@@ -14,7 +14,7 @@ if "--build" in sys.argv:
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "tools", "ablate"), exist_ok=True)
-    src = [os.path.join(root, "raw2film_amd", "csrc", f) for f in ("r2f_kernels.hip", "r2f_api.hip")]
+    src = [os.path.join(root, "raw2film_amd", "csrc", f) for f in ("r2f_kernels.hip", "r2f_fft.hip", "r2f_api.hip")]
     for macro, values, stem in (("R2F_EXP", (1, 2, 3, 4), "lib_exp"), ("R2F_TAIL_EXP", (1, 2, 4, 7), "lib_tail")):
         for n in values:
             out = os.path.join(root, "tools", "ablate", f"{stem}{n}.so")

@@ -17,6 +17,6 @@ def timeit(fn, iters=5):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
     return best
-for batch in (32, 64, 96, 128, 192, 256, 384, 512, 1024, 4096):
+for batch in (64, 96, 128, 160, 192, 224, 256, 320, 384, 512):
     ctx.set_option("stencil_fft_batch", batch)
     print(f"batch {batch:5d} ({batch} MB of scratch): render {timeit(lambda: ctx.render(img, params, out_f32=out)):.3f} ms")
