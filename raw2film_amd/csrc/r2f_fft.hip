@@ -1,32 +1,32 @@
-// Overlap-save FFT form of a large per-channel stencil (S2 halation), fp64.
+// Overlap-save FFT form of the large per-channel stencils (S2 halation, S5 MTF), fp64.
 //
 // The reference's own CPU path runs cv.filter2D's DFT branch for kernels larger than 11 x 11; in fp32 that carries an error
 // relative to the tile's energy (a shadow pixel next to a specular highlight misses the 1e-5 bar), in fp64 it is exact to
 // ~1e-13 and costs ~400 flops per pixel instead of the 2 x 5 721 of the direct sum.  MI355X's fp64 vector rate (78 TFLOP/s)
 // makes that the cheaper exact algorithm for the 87 x 87 disc.
 //
-// Unit of work: a PAIR of 256 x 256 input windows of one channel packed as real + imaginary part of one complex image (the
-// kernel is real, so the correlation of the complex image is the pair of correlations -- no Hermitian bookkeeping at all).
-// Window (ty, tx) produces the outputs [ty, ty + 256 - kh] x [tx, tx + 256 - kw] from the input rows ty - ay .. + 255.
-// One scratch image S(r, k) (complex128, 1 MB, column-blocked layout, see sidx) per pair:
+// Unit of work: a PAIR of ny x nx input windows of one channel (ny, nx = 256 or 512, FftConvArgs) packed as real +
+// imaginary part of one complex image (the kernel is real, so the correlation of the complex image is the pair of
+// correlations -- no Hermitian bookkeeping at all).  Window (ty, tx) produces the outputs [ty, ty + ny - kh] x
+// [tx, tx + nx - kw] from the input rows ty - ay .. + ny - 1.  One scratch image S(r, k) (complex128, 1 MB per 256 x 256,
+// column-blocked layout, see sidx) per pair:
 //
 //   pass 1  rows:     load (reflect-101 on the global frame), forward FFT along x                      -> S[r][k]
 //   pass 2  columns:  forward FFT along r, multiply by conj(K^)[r'][k], inverse FFT along r', in place  -> S[r][k]
-//   pass 3  rows:     inverse FFT along k, scale 2^-16, crop to the valid outputs, [log + density curve], store
+//   pass 3  rows:     inverse FFT along k, scale 1 / (ny nx), crop to the valid outputs, [log + density curve], store
 //
 // A 256-point line is transformed by 16 lanes holding 16 elements each (element n = lane + 16 m): a 16-point DFT in
 // registers, the twiddles W_256^(lane p), a 16 x 16 transpose through LDS, a second 16-point DFT -- natural order in and
 // out, one LDS round trip per transform.  (The first version ran four radix-4 stages through LDS and was bound by
 // ds_write_b128 issue: 0.6 ms per 1 024 pairs in pass 2.)  A wave carries 4 lines; lines of a wave are 4 neighbouring rows
-// (passes 1, 3: 256-byte segments per access) or 4 neighbouring columns (pass 2: a gather of 64-byte pieces, the other half
-// of each 128-byte line belongs to the next wave of the same workgroup).
+// (passes 1, 3: 256-byte segments per access) or 4 neighbouring columns (pass 2: 1 KB contiguous per access).
 //
-// Windows are 256 rows by 256 or 512 columns (FftConvArgs::nx; the host picks the width that moves the fewest scratch
-// bytes for the stencil and the frame: an 87-tap disc keeps 66 % of a 256-wide window's columns but 83 % of a 512-wide
-// one's).  A 512-point row is transformed by 32 lanes holding 16 elements each (fft512: 512 = 32 x 16, the same two
-// register DFTs around an LDS transpose, plus one radix-2 step across neighbouring lanes by DPP), so the row passes keep
-// their register budget and a wave carries 2 rows instead of 4; pass 2 only sees twice as many columns.  Rows per window
-// stay 256: pass 2 then still skips the rows without valid outputs.
+// A 512-point line is transformed by 32 lanes holding 16 elements each (fft512: 512 = 32 x 16, the same two register DFTs
+// around an LDS transpose, plus one radix-2 step across neighbouring lanes by DPP), so every pass keeps the register budget
+// of the 256-point version and a wave carries 2 lines instead of 4.  Its output order differs from its input order, which
+// the row passes absorb in their addressing; the column pass of 512-row windows comes back through fft512_rev, the
+// transposed flow graph.  The host picks the window shape that moves the fewest scratch bytes for the stencil and the
+// frame (an 87-tap disc keeps 66 % of a 256-wide window's columns but 83 % of a 512-wide one's); cfg 4: 256 x 512.
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
@@ -148,14 +148,16 @@ __device__ __forceinline__ double swap_lane1(double x) {
 constexpr int kTPitch512 = 34;                // transpose tile row pitch of a 512-point line: 32 + 2 (conflict-free both ways)
 constexpr int kTLine512 = 16 * kTPitch512;    // 544 doubles per line; a wave's 2 lines fill the same 1 088 doubles as 4 x 272
 
+// W_32^k = (kC32[k], -kS32[k]), k < 16: the radix-2 step of the 512-point transforms
+constexpr double kC32[16] = {1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196023, 0.38268343236508984, 0.19509032201612833, 0.0, -0.19509032201612833, -0.38268343236508984, -0.5555702330196023, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304};
+constexpr double kS32[16] = {0.0, 0.19509032201612833, 0.38268343236508984, 0.5555702330196023, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304, 1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196023, 0.38268343236508984, 0.19509032201612833};
+
 // 512-point transform of the line whose element (l + 32 j) sits in v[j] of lane l (l = lane & 31): 512 = 32 x 16.  A 16-point
 // DFT over j, the twiddles W_512^(l p), a transpose after which the lane pair (2 p, 2 p + 1) holds the even / odd l of
 // output residue p, a second 16-point DFT, and one radix-2 step across the pair.  On return v[i] of lane l holds output
 // element 256 (l & 1) + 16 i + (l >> 1).  w1 = exp(-2 pi i l / 512).  tbuf: this WAVE's transpose buffer.
 template <bool INV>
 __device__ __forceinline__ void fft512(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
-    constexpr double kC32[16] = {1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058};
-    constexpr double kS32[16] = {0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891};
     dft16<INV>(v);
     twiddle_powers<INV>(v, w1);
     const int l = lane & 31;
@@ -193,8 +195,6 @@ __device__ __forceinline__ void fft512(cplx (&v)[16], const cplx w1, double* tbu
 // fft512 forward, multiplies in place, and comes back through this one: no re-ordering in between.
 template <bool INV>
 __device__ __forceinline__ void fft512_rev(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
-    constexpr double kC32[16] = {1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058};
-    constexpr double kS32[16] = {0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891};
     const int l = lane & 31;
     const bool odd = l & 1;
     // radix-2 across the lane pair, decimation in frequency: even lane S[i] = X[i] + X[16 + i] (-> even outputs),
@@ -258,7 +258,7 @@ __device__ __forceinline__ const cplx& at(const cplx* base, unsigned idx) {
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 1
-// grid (256 / rows per workgroup, pairs).  X512 = false: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
+// grid (ny / rows per workgroup, pairs).  X512 = false: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
 // X512 = true: 32 lanes per (512-point) row, 8 rows per workgroup, 2 per wave.
 #ifndef R2F_FFT_EXP
 #define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
