@@ -179,6 +179,15 @@ def main():
         step()
     torch.cuda.synchronize()
     extra = [proc.ctx.kernel_timing(cls) for cls in range(3)]
+    # ... and the column pass with the GPU to itself (one internal stream): what a launch does when no other kernel shares
+    # the CUs and the memory system with it
+    proc.ctx.set_option("kernel_timing", 2)
+    proc.ctx.set_option("stencil_fft_streams", 1)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    solo = proc.ctx.kernel_timing(1)
+    proc.ctx.set_option("stencil_fft_streams", 2)
     proc.ctx.set_option("kernel_timing", 0)
     if effects and "halation" in stage_ms:
         hal_ms = float(stage_ms["halation"])
@@ -223,6 +232,9 @@ def main():
                                "event pair around a ~50 us launch also spans its dispatch gap (~5 us), so kernel_ms reads ~10 % "
                                "above rocprofv3's kernel-only average (profiles/r01_kernel_stats.csv): the quoted frac is the "
                                "conservative one",
+                "alone": (lambda ms, n, b: {"kernel_ms": ms / n, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                            "note": "the same launches (twice the pairs each) with one internal stream, two extra "
+                                                    "steps after the timed ones: no other kernel on the GPU"})(*solo) if solo[1] else None,
                 "stencil_stages": (lambda b, ms: {"algorithmic_bytes_per_step": b, "ms_per_step": ms, "GB/s": b / (ms * 1e-3) / 1e9,
                                                   "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                   "note": "all three passes of halation + MTF (window floats in, scratch "
