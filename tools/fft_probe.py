@@ -1,4 +1,4 @@
-import os, sys
+import sys
 import torch
 sys.path.insert(0, "/root/repo")
 from raw2film_amd import HipProcessor, filmstock

@@ -2,7 +2,6 @@
 import argparse
 import os
 import sys
-import time
 
 import numpy as np
 import torch
