@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg4_100mp", choices=["cfg4_100mp", "cfg3_45mp", "cfg2_24mp", "cfg5_batch"])
     ap.add_argument("--frames", type=int, default=64, help="cfg5_batch: frames per step, dealt round-robin to the ranks")
+    ap.add_argument("--frame", default="noise", choices=["noise", "smooth"],
+                    help="synthetic frame statistics: independent pixels (headline; worst case for the LUT gathers) or photograph-like")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--side-grain", action="store_true", help="A/B: make the grain field on a side stream while the stencils run")
     ap.add_argument("--direct-stencils", action="store_true", help="A/B: run the stencils in their direct fp32 form instead of fp64 FFTs")
@@ -105,7 +107,7 @@ def main():
     r0, r1 = renderer.plan.r0, renderer.plan.r1
 
     # this rank's rows of the synthetic frame, resident in HBM before the clock starts
-    frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}")
+    frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}", kind=args.frame)
     out = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device=frame.device)
 
     # time every stage with events on the launch stream, inside the timed steps (the dominant one feeds `roofline`)
@@ -156,7 +158,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32 (pointwise stages, grain) + f64 (FFT stencils)" if not args.direct_stencils else "f32",
-        "data": "synthetic",
+        "data": "synthetic" if args.frame == "noise" else "synthetic (smooth, photograph-like frame: not the headline input)",
         "config": {
             "workload": f"{args.config}: " + (f"{args.frames} x " if batch else "") + f"{W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 frame, 36x24 mm, "
                         + ("full pipeline S0-S8: 3x3 + 2-D LUT + halation 87x87 + log/curve + MTF 35x35 + grain 9x9 + tetrahedral 3-D LUT"

@@ -87,6 +87,7 @@ struct r2f_ctx {
     int opt_xcd_remap = 2;  // 0 = launch order, 1 = one contiguous row-major run of tiles per XCD, 2 = that run walked in column bands
     int opt_ablate = 0;
     int opt_sym = 1;      // use the mirror-symmetric entry form when a channel's taps allow it
+    int opt_front_blocks = 6;  // front kernel with the curve in LDS: workgroups per CU in its grid (3 are resident at 48 KB each)
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
 };
 
@@ -792,6 +793,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         ctx->opt_fft_window = value;
         return R2F_OK;
     }
+    if (!strcmp(name, "front_blocks_per_cu")) {
+        if (value < 1 || value > 64) return fail(ctx, R2F_EINVAL, "front_blocks_per_cu must be in [1, 64]");
+        ctx->opt_front_blocks = value;
+        return R2F_OK;
+    }
     if (!strcmp(name, "stencil_fft_window_rows")) {
         if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window_rows must be 0, 256 or 512");
         ctx->opt_fft_window_rows = value;
@@ -934,6 +940,7 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
         return fail(ctx, R2F_EINVAL, "front: bad upto");
     }
     a.vec = vec ? 1 : 0;
+    a.blocks_per_cu = ctx->opt_front_blocks;
     R2F_HIP(ctx, launch_front(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }

@@ -25,6 +25,7 @@ struct FrontArgs {
     float lut3d_scale;
     int lut3d_mode;
     int vec;  // 1: W % 4 == 0 and all bases 16-byte aligned -> float4 paths
+    int blocks_per_cu;  // curve-in-LDS variant: workgroups in the grid per CU (each copies the curve cells once, then walks rows)
 };
 
 struct StencilArgs {

@@ -24,15 +24,29 @@ def synthetic_frame(H: int, W: int, seed: int = 1234) -> np.ndarray:
     return np.clip(img, 0.0, 65504.0).astype(np.float32)
 
 
-def synthetic_frame_device(H: int, W: int, seed: int = 1234, device="cuda", layout="hwc"):
+def synthetic_frame_device(H: int, W: int, seed: int = 1234, device="cuda", layout="hwc", kind="noise"):
     """Same distribution generated on the GPU (for frames too large to build on the host quickly).
-    Not bit-identical to `synthetic_frame`; used for throughput runs only."""
+    Not bit-identical to `synthetic_frame`; used for throughput runs only.
+
+    kind="noise": every pixel independent (the headline frames: the worst case for the LUT gathers, neighbouring
+    pixels share no texel).  kind="smooth": the same luminance / colour statistics drawn on a 64 x coarser grid and
+    interpolated, plus 2 % per-pixel noise -- what the LUT stages see on a photograph (bench.py --frame smooth)."""
     import torch
 
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    lum = 0.18 * torch.exp2(1.5 * torch.randn((H, W, 1), generator=g, device=device))
-    img = lum * (0.6 + 0.8 * torch.rand((H, W, 3), generator=g, device=device))
+    if kind == "smooth":
+        h, w = max(H // 64, 2), max(W // 64, 2)
+        stops = torch.nn.functional.interpolate(1.5 * torch.randn((1, 1, h, w), generator=g, device=device), size=(H, W),
+                                                mode="bicubic", align_corners=False)[0].permute(1, 2, 0)
+        tint = torch.nn.functional.interpolate(0.6 + 0.8 * torch.rand((1, 3, h, w), generator=g, device=device), size=(H, W),
+                                               mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+        img = 0.18 * torch.exp2(stops) * tint * (1.0 + 0.02 * torch.randn((H, W, 3), generator=g, device=device))
+    elif kind == "noise":
+        lum = 0.18 * torch.exp2(1.5 * torch.randn((H, W, 1), generator=g, device=device))
+        img = lum * (0.6 + 0.8 * torch.rand((H, W, 3), generator=g, device=device))
+    else:
+        raise ValueError(f"unknown synthetic frame kind {kind!r}")
     spec = torch.rand((H, W), generator=g, device=device) < 0.001
     img[spec] = 16.0
     img = img.clamp_(0.0, 65504.0).contiguous()
