@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--frame", default="noise", choices=["noise", "smooth"],
                     help="synthetic frame statistics: independent pixels (headline; worst case for the LUT gathers) or photograph-like")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip the two extra steps that time the FFT column pass with one internal stream (tools/profile_round.sh: "
+                         "keeps the profiled launches all of one size)")
     ap.add_argument("--side-grain", action="store_true", help="A/B: make the grain field on a side stream while the stencils run")
     ap.add_argument("--direct-stencils", action="store_true", help="A/B: run the stencils in their direct fp32 form instead of fp64 FFTs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -183,13 +186,15 @@ def main():
     extra = [proc.ctx.kernel_timing(cls) for cls in range(3)]
     # ... and the column pass with the GPU to itself (one internal stream): what a launch does when no other kernel shares
     # the CUs and the memory system with it
-    proc.ctx.set_option("kernel_timing", 2)
-    proc.ctx.set_option("stencil_fft_streams", 1)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    solo = proc.ctx.kernel_timing(1)
-    proc.ctx.set_option("stencil_fft_streams", 2)
+    solo = (0.0, 0, 0.0)
+    if not args.no_alone:
+        proc.ctx.set_option("kernel_timing", 2)
+        proc.ctx.set_option("stencil_fft_streams", 1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        solo = proc.ctx.kernel_timing(1)
+        proc.ctx.set_option("stencil_fft_streams", 2)
     proc.ctx.set_option("kernel_timing", 0)
     if effects and "halation" in stage_ms:
         hal_ms = float(stage_ms["halation"])

@@ -10,9 +10,9 @@ export TMPDIR=/tmp
 TAG=${1:-r01}
 OUT=gpurun_out/profile_$TAG
 rm -rf $OUT; mkdir -p $OUT/summary
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alone > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alone > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alone > $OUT/pmc_write.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 out, tag = "$OUT", "$TAG"
@@ -21,7 +21,7 @@ for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"{out}/summary/{tag}_kernel_stats.csv", "w") as fh:
-    fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline (7 renders of the 100 MP frame)\n")
+    fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alone (9 renders of the 100 MP frame: 2 warm-up + 5 timed + 2 for the\n# per-pass breakdown)\n")
     fh.write("# torch's frame-generation kernels are folded into one line\n")
     fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     other = [0, 0.0]
