@@ -2,6 +2,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw2film_amd import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from raw2film_amd import HipProcessor, filmstock
 from raw2film_amd.hip_processor import REC709_TO_XYZ
 from raw2film_amd.synthetic import synthetic_frame_device
@@ -18,6 +21,6 @@ def timeit(fn, iters=9):
     return min(ts)
 for kind in ("noise", "smooth"):
     img = synthetic_frame_device(H, W, kind=kind)
-    for bpc in (1, 2, 3, 4, 6, 8, 16):
+    for bpc in (3, 6, 12):
         ctx.set_option("front_blocks_per_cu", bpc)
         print(f"{kind:6s} blocks/CU {bpc:2d}: %.3f ms" % timeit(lambda: ctx.render(img, params, out_f32=out)))
