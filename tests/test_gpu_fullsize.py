@@ -87,6 +87,27 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
     ctx.set_option("stencil_fft", 1)
 
 
+@pytest.mark.parametrize("rows, cols", [(256, 256), (512, 256), (512, 512)])
+def test_the_100mp_render_does_not_depend_on_the_fft_window_shape(full, rows, cols):
+    """The fixture rendered with the window shape the cost model picks (256 x 512 here); any other shape tiles the frame
+    differently but computes the same correlation: the results agree to an fp32 ulp on a handful of pixels."""
+    ctx, params, p, frame, out = full
+    assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(256, 512)] * 2
+    ctx.set_option("stencil_fft_window_rows", rows)
+    ctx.set_option("stencil_fft_window", cols)
+    try:
+        other, _ = ctx.render(frame, params)
+        assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(rows, cols)] * 2
+        assert [c["window"] for c in ctx.stencil_stats(1)] == [(rows, cols)] * 3
+        diff = (other - out).abs()
+        assert float((diff / out.abs().clamp_min(0.1)).max()) <= 5e-7
+        assert float((diff > 0).float().mean()) <= 1e-3
+    finally:
+        ctx.set_option("stencil_fft_window_rows", 0)
+        ctx.set_option("stencil_fft_window", 0)
+        ctx.render(frame, params)  # spectra back to the default shape for the tests that follow
+
+
 def test_a_constant_100mp_frame_stays_constant(full):
     """Every stencil sums to 1, so with grain off a flat frame must come out flat, at the value the pointwise chain gives."""
     ctx, params, p, frame, out = full
