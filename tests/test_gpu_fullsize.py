@@ -108,6 +108,48 @@ def test_the_100mp_render_does_not_depend_on_the_fft_window_shape(full, rows, co
         ctx.render(frame, params)  # spectra back to the default shape for the tests that follow
 
 
+def test_impulse_responses_at_full_size_reproduce_the_stencil(full):
+    """Size-independent property of the FFT stencils at the full frame: isolated impulses (at window seams of both window
+    widths, mid-frame and 70 px from the corners) come out as the flipped taps, to an fp32 ulp of the largest tap -- no
+    leakage from the circular correlation, no seam between windows; and the stage is linear in its input."""
+    ctx = full[0]
+    rng = np.random.default_rng(11)
+    k = np.zeros((61, 45, 1), np.float32)
+    k[:, :, 0] = rng.normal(0.0, 1.0, (61, 45))  # nothing symmetric, signed: 2 745 taps -> FFT form
+    ctx.set_kernel(1, k)
+    src = torch.zeros((3, H_FULL, W_FULL), dtype=torch.float32, device="cuda")
+    spots = [(4096, 6144, 1.0), (195, 211, 2.0), (196, 468, -1.5), (70, 70, 0.5), (H_FULL - 71, W_FULL - 71, 3.0),
+             (2 * 196 + 3, 3 * 212 - 1, 1.25), (5000, 467, 1.0), (5000, 468, -2.0)]
+    def row(y, c):  # the three channels get the impulse on different rows
+        return y + 40 * c if y < H_FULL // 2 else y - 40 * c
+
+    for c in range(3):
+        for y, x, v in spots:
+            src[c, row(y, c), x] = v * (c + 1)
+    dst = torch.empty_like(src)
+    ctx.stage_stencil(1, src, dst, y0=0, y1=H_FULL, H_global=H_FULL)
+    assert [c["fft"] for c in ctx.stencil_stats(1)] == [1, 1, 1]
+    flipped = torch.from_numpy(np.ascontiguousarray(k[::-1, ::-1, 0])).cuda()
+    tol = 2e-7 * float(np.abs(k).max()) * 6.0  # |v| <= 3 x 2 for the overlapping pair below
+    expect = torch.zeros_like(src)
+    for c in range(3):
+        for y, x, v in spots:
+            yy, xx = row(y, c), x
+            # out(yy + ay - i, xx + ax - j) = v k[i][j] with the anchor (30, 22): rows yy - 30 .. yy + 30, columns xx - 22 .. xx + 22
+            expect[c, yy - 30:yy + 31, xx - 22:xx + 23] += v * (c + 1) * flipped
+    assert float((dst - expect).abs().max()) <= tol
+    # linearity: a second input and a combination of the two
+    other = torch.zeros_like(src)
+    other[:, 1000:1200, 3000:3300] = torch.rand((3, 200, 300), device="cuda")
+    d2 = torch.empty_like(src)
+    ctx.stage_stencil(1, other, d2, y0=0, y1=H_FULL, H_global=H_FULL)
+    d3 = torch.empty_like(src)
+    ctx.stage_stencil(1, 0.5 * src - 2.0 * other, d3, y0=0, y1=H_FULL, H_global=H_FULL)
+    assert float((d3 - (0.5 * dst - 2.0 * d2)).abs().max()) <= 5e-5  # fp32 rounding of the three results (sums of ~2 700 taps of |w| ~ 1)
+    del src, dst, expect, other, d2, d3
+    ctx.set_kernel(1, full[2].mtf_kernel)
+
+
 def test_a_constant_100mp_frame_stays_constant(full):
     """Every stencil sums to 1, so with grain off a flat frame must come out flat, at the value the pointwise chain gives."""
     ctx, params, p, frame, out = full
