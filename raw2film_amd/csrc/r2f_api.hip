@@ -87,6 +87,11 @@ struct r2f_ctx {
     int opt_xcd_remap = 2;  // 0 = launch order, 1 = one contiguous row-major run of tiles per XCD, 2 = that run walked in column bands
     int opt_ablate = 0;
     int opt_sym = 1;      // use the mirror-symmetric entry form when a channel's taps allow it
+    // the grain stencil as weight pairs for grain_stencil_fixed (small square symmetric kernels), built on first use
+    DeviceBuf grain_fixed_w;
+    bool grain_fixed_valid = false;
+    int grain_fixed_r = 0, grain_fixed_same = 0;
+    int opt_grain_fixed = 1;  // 0: always the generic entry list (A/B)
     int opt_front_blocks = 6;  // front kernel with the curve in LDS: workgroups per CU in its grid (3 are resident at 48 KB each)
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
 };
@@ -745,6 +750,7 @@ void r2f_destroy(r2f_ctx* ctx) {
         }
     for (auto& t : ctx->tile_order) t.buf.release();
     ctx->lanczos_buf.release();
+    ctx->grain_fixed_w.release();
     ctx->fft_tw.release();
     ctx->fft_s1.release();
     ctx->fft_kimg.release();
@@ -791,6 +797,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_window")) {
         if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window must be 0, 256 or 512");
         ctx->opt_fft_window = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "grain_fixed")) {
+        ctx->opt_grain_fixed = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "front_blocks_per_cu")) {
@@ -889,6 +899,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.host.assign(k, k + (size_t)kh * kw * kc);
     s.built_q = 0;
     for (int c = 0; c < 3; ++c) ctx->fft_kf_valid[which][c] = false;
+    if (which == R2F_KERNEL_GRAIN) ctx->grain_fixed_valid = false;
     return R2F_OK;
 }
 
@@ -1013,6 +1024,46 @@ static bool burn_geometry(const r2f_params* p, int H, int W, int* h_lo, int* w_l
 
 // density == nullptr && planes_out: the grain field alone (K_g * noise) -> planes_out.
 // gfield: a grain field computed that way is applied pointwise instead of being generated here.
+// The grain stencil in the form grain_stencil_fixed wants, when it has one: every channel's non-zero taps fill the same
+// square (2 R + 1)^2 box around the anchor, R = 1 .. 6, left-right mirror symmetric, and the device geometry built for the
+// tail tile has the expected padding.  grain_fixed_r = 0 otherwise (the generic entry list runs).
+static int ensure_grain_fixed(r2f_ctx* ctx) {
+    if (ctx->grain_fixed_valid) return R2F_OK;
+    StencilSet& set = ctx->stencil[R2F_KERNEL_GRAIN];
+    ctx->grain_fixed_valid = true;
+    ctx->grain_fixed_r = 0;
+    int b[4];
+    tap_box(set, 0, b);
+    const int n = b[1] - b[0] + 1, R = n / 2;
+    bool ok = (n & 1) && R >= 1 && R <= 6 && b[3] - b[2] + 1 == n && b[0] + R == set.kh / 2 && b[2] + R == set.kw / 2;
+    for (int c = 0; c < 3 && ok; ++c) {
+        int o[4];
+        tap_box(set, c, o);
+        const DevStencil& d = set.dev[c];
+        ok = !memcmp(o, b, sizeof b) && d.sym && d.ay == R && d.ax == (R <= 2 ? 2 : 6) && d.kh == n;
+    }
+    if (!ok) return R2F_OK;
+    const int per = (2 * R + 2) * (R + 1);
+    std::vector<float> w((size_t)3 * per * 2, 0.f);
+    bool same = true;
+    for (int c = 0; c < 3; ++c) {
+        const int kc = set.kc == 1 ? 0 : c;
+        auto tap = [&](int i, int j) { return set.host[((size_t)(b[0] + i) * set.kw + b[2] + j) * set.kc + kc]; };
+        for (int i = 0; i < 2 * R + 2; ++i)
+            for (int j = 0; j <= R; ++j) {
+                float* pair = &w[((size_t)c * per + (size_t)i * (R + 1) + j) * 2];
+                pair[0] = i <= 2 * R ? tap(i, j) : 0.f;  // output row 0 of the lane: kernel row i
+                pair[1] = i >= 1 ? tap(i - 1, j) : 0.f;  // output row 1: kernel row i - 1
+            }
+        same = same && !memcmp(&w[(size_t)c * per * 2], &w[0], (size_t)per * 2 * sizeof(float));
+    }
+    int rc = upload(ctx, ctx->grain_fixed_w, w.data(), w.size() * sizeof(float));
+    if (rc) return rc;
+    ctx->grain_fixed_r = R;
+    ctx->grain_fixed_same = same ? 1 : 0;
+    return R2F_OK;
+}
+
 static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* planes_out,
                     const float* burn_map, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global,
                     void* stream, const r2f_planes* gfield = nullptr) {
@@ -1092,6 +1143,11 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         rc = ensure_stencil(ctx, R2F_KERNEL_GRAIN, kTailQ, 4 * kTailBX, kTailQ * kTailBY, 0, true);
         if (rc) return rc;
         for (int c = 0; c < 3; ++c) a.gk[c] = ctx->stencil[R2F_KERNEL_GRAIN].dev[c];
+        rc = ensure_grain_fixed(ctx);
+        if (rc) return rc;
+        a.fixed_r = ctx->opt_grain_fixed ? ctx->grain_fixed_r : 0;
+        a.fixed_same = ctx->grain_fixed_same;
+        a.fixed_w = static_cast<const float*>(ctx->grain_fixed_w.p);
         if (tail_lds_bytes(a.gk, a.mono) > kMaxLds)
             return fail(ctx, R2F_ETOOLARGE, "grain stencil %dx%d does not fit the LDS noise tile", a.gk[0].kh, a.gk[0].kw);
         a.grain_lut = ctx->grain_lut;

@@ -599,6 +599,40 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
     }
 }
 
+// ---- small square mirror-symmetric stencils, fully unrolled (the tail kernel's grain stencil) -----------------------
+// 3 x 3 ... 13 x 13 taps (R = 1 ... 6), Q = 2 rows per lane.  The generic entry machinery above is built for stencils of
+// dozens of row steps: for a 9 x 9 one it reads every 8-float block twice (two entries per row step), fetches its weights
+// with two scalar loads per row step that the short loop cannot hide, and keeps a row partial.  Here every input row is
+// read once (its 4 + 2 R floats, as aligned 16-byte blocks), the weight PAIRS (tap of output row 0, tap of output row 1)
+// come from one wave-uniform table that the unrolled code loads ahead, and the mirrored columns are summed before the
+// packed FMAs.  Taps are consumed input row by input row, outer columns to the centre: the same order for every pixel, so
+// results do not depend on the tile or shard a pixel falls in.
+// lds: the lane's first input row and pixel column (plane + ty * 2 * RS + 4 * tx); the tile's column 0 is the image column
+// tile_x0 - AX with AX = 2 (R <= 2) or 6, the host's padding of r to 2 mod 4.  wp: [(2 R + 2)][R + 1] pairs.
+template <int R>
+__device__ __forceinline__ void grain_stencil_fixed(const float* lds, const int RS, const float2v R2F_CONSTANT* wp,
+                                                    float2v (&acc)[1][4]) {
+    constexpr int AX = R <= 2 ? 2 : 6, O = AX - R, NB = (O + 2 * R + 4 + 3) / 4;
+#pragma unroll
+    for (int i = 0; i < 2 * R + 2; ++i) {
+        float x[4 * NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float4v v = *reinterpret_cast<const float4v*>(lds + i * RS + 4 * b);
+            x[4 * b] = v.x, x[4 * b + 1] = v.y, x[4 * b + 2] = v.z, x[4 * b + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c <= R; ++c) {
+            const float2v wv = wp[i * (R + 1) + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float sum = c < R ? x[O + p + c] + x[O + p + 2 * R - c] : x[O + p + R];
+                acc[0][p] = __builtin_elementwise_fma(wv, float2v{sum, sum}, acc[0][p]);
+            }
+        }
+    }
+}
+
 // Accumulate the row steps [row_begin, row_end) of one phase, whose first entry is e0.
 template <int Q>
 __device__ __forceinline__ void stencil_accumulate(const float* lds, const DevStencil& st, int row_begin, int row_end,

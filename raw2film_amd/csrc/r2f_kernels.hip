@@ -425,7 +425,8 @@ __global__ __launch_bounds__(256) void single_tap_kernel(const TapArgs a) {
 // CMF / CML: compile-time live masks of the grain stencil's first / last entry per row step (-1: evaluate every tap column).
 // A 9 x 9 grain stencil occupies 5 of the 8 tap columns of its two entries; with the masks known at compile time the other
 // three cost nothing (run-time masks, i.e. branches, had cost more than they saved here).
-template <int CMF, int CML>
+// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (grain_stencil_fixed) instead of the generic entry list.
+template <int CMF, int CML, int FR = 0>
 __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = kTailBX * kTailBY, TW = 4 * kTailBX, TH = kTailQ * kTailBY, Q = kTailQ;
@@ -475,6 +476,18 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
             for (int p = 0; p < 4; ++p) G[c][j][p] = (float2v){0.f, 0.f};
         const float* plane = smem + (mono ? 0 : c * plane_sz);
         if (R2F_TAIL_EXP & 2) continue;
+        if (FR > 0) {
+            static_assert(FR == 0 || kTailQ == 2, "grain_stencil_fixed is written for 2 rows per lane");
+            if (c > 0 && mono && a.fixed_same) {  // one noise plane, one set of taps: the field of channel 0
+#pragma unroll
+                for (int p = 0; p < 4; ++p) G[c][0][p] = G[0][0][p];
+            } else {
+                constexpr int R = FR > 0 ? FR : 1;
+                grain_stencil_fixed<R>(plane + ty * Q * RS + 4 * tx, RS,
+                                       (const float2v R2F_CONSTANT*)a.fixed_w + c * (2 * R + 2) * (R + 1), G[c]);
+            }
+            continue;
+        }
         if (a.gk[c].sym)
             stencil_accumulate_sym<Q, false, CMF, CML>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
         else
@@ -923,6 +936,12 @@ hipError_t init_kernel_attributes() {
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 1>))
     R2F_SET_LDS((tail_kernel<-1, -1>))
+    R2F_SET_LDS((tail_kernel<-1, -1, 1>))
+    R2F_SET_LDS((tail_kernel<-1, -1, 2>))
+    R2F_SET_LDS((tail_kernel<-1, -1, 3>))
+    R2F_SET_LDS((tail_kernel<-1, -1, 4>))
+    R2F_SET_LDS((tail_kernel<-1, -1, 5>))
+    R2F_SET_LDS((tail_kernel<-1, -1, 6>))
     R2F_SET_LDS((tail_kernel<12, 7>))
     R2F_SET_LDS((tail_kernel<14, 7>))
     R2F_SET_LDS((tail_kernel<8, 7>))
@@ -1002,6 +1021,21 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     b.cells_off = (int)tail_plane_floats(a.gk, a.mono);
     b.cells_in_lds = tail_lds_bytes(a.gk, a.mono, 1, a.grain_lut.m) <= 80 * 1024 ? 1 : 0;  // keep two workgroups per CU
     const size_t lds = tail_lds_bytes(a.gk, a.mono, b.cells_in_lds, a.grain_lut.m);
+    switch (a.fixed_r) {  // small square mirror-symmetric stencils: the unrolled form
+#define R2F_TAIL_FIXED(R)                                                   \
+    case R:                                                                \
+        hipLaunchKernelGGL((tail_kernel<-1, -1, R>), grid, block, lds, s, b); \
+        return hipGetLastError();
+        R2F_TAIL_FIXED(1)
+        R2F_TAIL_FIXED(2)
+        R2F_TAIL_FIXED(3)
+        R2F_TAIL_FIXED(4)
+        R2F_TAIL_FIXED(5)
+        R2F_TAIL_FIXED(6)
+#undef R2F_TAIL_FIXED
+        default:
+            break;
+    }
     // the union of the live masks over the three channels picks the instantiation (any superset is correct)
     int mf = 0, ml = 0;
     bool all_sym = true;

@@ -562,3 +562,42 @@ def test_grain_field_split_equals_the_fused_tail_bit_for_bit(ctx):
             assert torch.equal(part, fused[y0:y1])
         ref = st.apply_lut_tetrahedral(st.apply_grain(dens, p.grain_lut, p.grain_kernel, p.seed, grain == 1), p.lut_3d, 0.25)
         assert_close(split.cpu().numpy(), ref, 1e-5, 1e-1, "split tail vs oracle")
+
+
+@pytest.mark.parametrize("n", [3, 5, 7, 9, 11, 13, 15])
+@pytest.mark.parametrize("mono, per_channel", [(False, False), (True, False), (False, True)])
+def test_small_square_grain_stencils_unrolled_form_against_the_oracle_and_the_entry_list(ctx, n, mono, per_channel):
+    """Square mirror-symmetric grain stencils up to 13 x 13 take the fully unrolled form (grain_stencil_fixed), 15 x 15 and
+    anything irregular the generic entry list; both reproduce the oracle's field (K_g * N at global coordinates) and each
+    other to rounding, with shared or per-channel taps, colour or monochrome noise, on row ranges of any origin."""
+    rng = np.random.default_rng(n)
+    H, W = 150, 203
+    k = rng.uniform(0.1, 1.0, (n, n, 3 if per_channel else 1)).astype(np.float32)
+    k = (k + k[:, ::-1]) / 2  # left-right mirror symmetric, like sfl's grain kernels; nothing special vertically
+    k /= np.sqrt((k ** 2).sum(axis=(0, 1), keepdims=True))
+    ctx.set_kernel(2, k if per_channel else k[..., 0])
+    ctx.set_grain_lut(stocks()[0].get_grain_curve(341.33, adx=False, bw_grain=False))  # the field does not use it; the stage wants one
+    params = ctx.make_params(seed=4321, grain=True, grain_mono=mono)
+    noise = st.gaussian_noise(np.arange(W)[None, :], np.arange(H)[:, None], 4321, mono)
+    # grain.wgsl:63-75: the field reads the noise with coordinates clamped to the frame
+    r = n // 2
+    padded = np.pad(noise, ((r, r), (r, r), (0, 0)), mode="edge").astype(np.float64)
+    ref = np.zeros((H, W, 3))
+    for c in range(3):
+        kc = k[..., c if per_channel else 0].astype(np.float64)
+        for i in range(n):
+            for j in range(n):
+                ref[..., c] += kc[i, j] * padded[i:i + H, j:j + W, c]
+    fields = {}
+    for fixed in (1, 0):
+        ctx.set_option("grain_fixed", fixed)
+        F = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        for y0, y1 in ((0, 37), (37, 38), (38, H)):  # the tile grid follows y0: every pixel must not care
+            ctx.stage_grain_field(F, params, dst_gy0=0, y0=y0, y1=y1, H_global=H)
+        fields[fixed] = from_planes(F)
+        assert np.abs(fields[fixed] - ref).max() <= 2e-5, (fixed, n)  # |field| ~ 1..4, the noise itself is good to 1e-5
+        whole = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_grain_field(whole, params, dst_gy0=0, y0=0, y1=H, H_global=H)
+        np.testing.assert_array_equal(from_planes(whole), fields[fixed])  # bit for bit whatever the row range
+    ctx.set_option("grain_fixed", 1)
+    assert np.abs(fields[1] - fields[0]).max() <= 4e-6  # two summation orders of the same 2-D sum
