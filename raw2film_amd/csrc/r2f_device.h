@@ -457,21 +457,12 @@ __device__ __forceinline__ void tap_fma_sym(const typename WVec<4 * Q>::type& w,
 // FIRST: the entry starts the row partial (multiply instead of fma).  MASKED: only the tap columns whose bit is set in
 // `mask` are evaluated -- the first and last entry of a row step usually hold padding columns or the rim of a disc
 // (all-zero weights); `mask` is wave-uniform (it comes from the row-step record), so each test is a scalar branch.
-// CM >= 0: the mask is a compile-time constant (the tail kernel is instantiated for the masks small grain stencils have), so the
-// dead tap columns cost nothing at all -- not even a branch.
-template <int Q, bool FIRST, bool MASKED, int CM = -1>
+template <int Q, bool FIRST, bool MASKED>
 __device__ __forceinline__ void entry_fma_sym(const typename WVec<4 * Q>::type& w, const float4v& la, const float4v& lb,
                                               const float4v& ra, const float4v& rb, float2v (&part)[Q / 2][4], const int mask) {
     const float lw[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
     const float rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    if (CM >= 0) {
-        constexpr int M = CM < 0 ? 15 : CM;
-        constexpr int first_live = (M & 1) ? 0 : (M & 2) ? 1 : (M & 4) ? 2 : 3;
-        if (M & 1) tap_fma_sym<Q, 0, FIRST && first_live == 0>(w, lw, rw, part);
-        if (M & 2) tap_fma_sym<Q, 1, FIRST && first_live == 1>(w, lw, rw, part);
-        if (M & 4) tap_fma_sym<Q, 2, FIRST && first_live == 2>(w, lw, rw, part);
-        if (M & 8) tap_fma_sym<Q, 3, FIRST && first_live == 3>(w, lw, rw, part);
-    } else if (!MASKED) {
+    if (!MASKED) {
         tap_fma_sym<Q, 0, FIRST>(w, lw, rw, part);
         tap_fma_sym<Q, 1, false>(w, lw, rw, part);
         tap_fma_sym<Q, 2, false>(w, lw, rw, part);
@@ -502,7 +493,7 @@ struct SymOperands {
 #define R2F_EXP 0  // development switch (tools/ablate_stencil.py): bit 0 no LDS reads, 1 no weight loads, 2 no FMAs
 #endif
 
-template <int Q, bool FIRST, bool MASKED, int CM = -1>
+template <int Q, bool FIRST, bool MASKED>
 __device__ __forceinline__ void entry_step_sym(const float* lds, const int noff, const int noffr,
                                                const typename WVec<4 * Q>::type R2F_CONSTANT* wstream, const int wmul, int& e,
                                                const SymOperands<Q>& cur, SymOperands<Q>& nxt, float2v (&part)[Q / 2][4],
@@ -532,16 +523,15 @@ __device__ __forceinline__ void entry_step_sym(const float* lds, const int noff,
         else
             part[0][0] += float2v{cur.w[0] + cur.w[4 * Q - 1], cur.la.x + cur.lb.w + cur.ra.x + cur.rb.w};
     } else
-        entry_fma_sym<Q, FIRST, MASKED, CM>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part, mask);
+        entry_fma_sym<Q, FIRST, MASKED>(cur.w, cur.la, cur.lb, cur.ra, cur.rb, part, mask);
     ++e;
 }
 
 // Row step = first entry (masked), middle entries (all four tap columns), last entry (masked).  The two operand sets
 // alternate entry by entry; the current entry sits in set A at the top of every row step.  MASKS = false evaluates every
 // tap column of every entry (the tail kernel's 9x9 grain stencil: two entries per row step, the branches cost more than
-// the padding columns they skip -- 2.0 vs 1.8 ms).
-// CMF / CML >= 0: compile-time live masks of the first / last entry of every row step (supersets of the per-row masks).
-template <int Q, bool MASKS, int CMF = -1, int CML = -1>
+// the padding columns they skip -- 2.0 vs 1.8 ms; small square grain stencils now take grain_stencil_fixed anyway).
+template <int Q, bool MASKS>
 __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const DevStencil& st, int row_begin, int row_end,
                                                        int e0, float2v (&acc)[Q / 2][4]) {
     typedef typename WVec<4 * Q>::type wvec;
@@ -565,15 +555,7 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
             const bool only = cnt <= 1;
             const int no = only ? ri_n.y : off, nor = only ? ri_n.z : offr;
             off += 4, offr -= 4;
-            if (CMF >= 0) {
-                if (only)
-                    entry_step_sym<Q, true, false, (CMF >= 0 ? (CMF & CML) : -1)>(lds, no, nor, wstream, wmul, e, A, B, part, 15,
-                                                                                  info + r + 2, &ri_nn);
-                else
-                    entry_step_sym<Q, true, false, CMF>(lds, no, nor, wstream, wmul, e, A, B, part, 15, info + r + 2, &ri_nn);
-            } else {
-                entry_step_sym<Q, true, MASKS>(lds, no, nor, wstream, wmul, e, A, B, part, m_first, info + r + 2, &ri_nn);
-            }
+            entry_step_sym<Q, true, MASKS>(lds, no, nor, wstream, wmul, e, A, B, part, m_first, info + r + 2, &ri_nn);
         }
         int i = 1;
         for (; i + 2 < cnt; i += 2) {  // two middle entries: i (set B) and i + 1 (set A); entry i + 2 exists in this row step
@@ -583,10 +565,10 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
         }
         if (i + 1 < cnt) {  // two entries left: a middle one (set B), then the last (set A)
             entry_step_sym<Q, false, false>(lds, off, offr, wstream, wmul, e, B, A, part);
-            entry_step_sym<Q, false, MASKS, CML>(lds, ri_n.y, ri_n.z, wstream, wmul, e, A, B, part, m_last);
+            entry_step_sym<Q, false, MASKS>(lds, ri_n.y, ri_n.z, wstream, wmul, e, A, B, part, m_last);
             A = B;
         } else if (i < cnt) {  // one entry left: the last (set B)
-            entry_step_sym<Q, false, MASKS, CML>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part, m_last);
+            entry_step_sym<Q, false, MASKS>(lds, ri_n.y, ri_n.z, wstream, wmul, e, B, A, part, m_last);
         } else {  // cnt == 1
             A = B;
         }
@@ -615,20 +597,35 @@ __device__ __forceinline__ void grain_stencil_fixed(const float* lds, const int 
     constexpr int AX = R <= 2 ? 2 : 6, O = AX - R, NB = (O + 2 * R + 4 + 3) / 4;
 #pragma unroll
     for (int i = 0; i < 2 * R + 2; ++i) {
-        float x[4 * NB];
+        // the row as aligned register pairs xp[k] = (x[2k], x[2k+1]): a mirrored pair of columns has indices of equal parity,
+        // so two neighbouring pixels' sums are one v_pk_add_f32, and a packed FMA picks its pixel with op_sel (no copies)
+        float2v xp[2 * NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float4v v = *reinterpret_cast<const float4v*>(lds + i * RS + 4 * b);
-            x[4 * b] = v.x, x[4 * b + 1] = v.y, x[4 * b + 2] = v.z, x[4 * b + 3] = v.w;
+            xp[2 * b] = float2v{v.x, v.y};
+            xp[2 * b + 1] = float2v{v.z, v.w};
         }
 #pragma unroll
         for (int c = 0; c <= R; ++c) {
             const float2v wv = wp[i * (R + 1) + c];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float sum = c < R ? x[O + p + c] + x[O + p + 2 * R - c] : x[O + p + R];
-                acc[0][p] = __builtin_elementwise_fma(wv, float2v{sum, sum}, acc[0][p]);
+            const int a0 = O + c, b0 = O + 2 * R - c;  // columns of pixel 0's left and mirrored tap (the centre: a0 == b0)
+            float2v s[4];                              // s[p]: pixel p's sum in both halves
+            if ((a0 & 1) == 0) {
+                const float2v s01 = c < R ? xp[a0 >> 1] + xp[b0 >> 1] : xp[a0 >> 1];
+                const float2v s23 = c < R ? xp[(a0 >> 1) + 1] + xp[(b0 >> 1) + 1] : xp[(a0 >> 1) + 1];
+                s[0] = float2v{s01.x, s01.x}, s[1] = float2v{s01.y, s01.y};
+                s[2] = float2v{s23.x, s23.x}, s[3] = float2v{s23.y, s23.y};
+            } else {
+                const float l0 = xp[a0 >> 1].y, r0 = xp[b0 >> 1].y;                    // columns a0, b0 (odd)
+                const float l3 = xp[(a0 + 3) >> 1].x, r3 = xp[(b0 + 3) >> 1].x;        // columns a0 + 3, b0 + 3 (even)
+                const float2v s12 = c < R ? xp[(a0 + 1) >> 1] + xp[(b0 + 1) >> 1] : xp[(a0 + 1) >> 1];
+                const float s0 = c < R ? l0 + r0 : l0, s3 = c < R ? l3 + r3 : l3;
+                s[0] = float2v{s0, s0}, s[1] = float2v{s12.x, s12.x};
+                s[2] = float2v{s12.y, s12.y}, s[3] = float2v{s3, s3};
             }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[0][p] = __builtin_elementwise_fma(wv, s[p], acc[0][p]);
         }
     }
 }

@@ -422,11 +422,10 @@ __global__ __launch_bounds__(256) void single_tap_kernel(const TapArgs a) {
 }
 
 // ------------------------------------------------------------------------------ tail (grain)
-// CMF / CML: compile-time live masks of the grain stencil's first / last entry per row step (-1: evaluate every tap column).
-// A 9 x 9 grain stencil occupies 5 of the 8 tap columns of its two entries; with the masks known at compile time the other
-// three cost nothing (run-time masks, i.e. branches, had cost more than they saved here).
-// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (grain_stencil_fixed) instead of the generic entry list.
-template <int CMF, int CML, int FR = 0>
+// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (grain_stencil_fixed: square mirror-symmetric kernels up to 13 x 13);
+// FR = 0: the generic entry list, every tap column of every entry (run-time masks, i.e. branches, cost more than the
+// padding columns they skip in a stencil of two entries per row step).
+template <int FR>
 __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = kTailBX * kTailBY, TW = 4 * kTailBX, TH = kTailQ * kTailBY, Q = kTailQ;
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
             continue;
         }
         if (a.gk[c].sym)
-            stencil_accumulate_sym<Q, false, CMF, CML>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
+            stencil_accumulate_sym<Q, false>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
         else
             stencil_accumulate<Q>(plane + ty * Q * RS + 4 * tx, a.gk[c], 0, a.gk[c].n_rowsteps, 0, G[c]);
     }
@@ -935,19 +934,13 @@ hipError_t init_kernel_attributes() {
     R2F_SET_LDS((stencil_kernel<32, 16, 4, 1>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 1>))
-    R2F_SET_LDS((tail_kernel<-1, -1>))
-    R2F_SET_LDS((tail_kernel<-1, -1, 1>))
-    R2F_SET_LDS((tail_kernel<-1, -1, 2>))
-    R2F_SET_LDS((tail_kernel<-1, -1, 3>))
-    R2F_SET_LDS((tail_kernel<-1, -1, 4>))
-    R2F_SET_LDS((tail_kernel<-1, -1, 5>))
-    R2F_SET_LDS((tail_kernel<-1, -1, 6>))
-    R2F_SET_LDS((tail_kernel<12, 7>))
-    R2F_SET_LDS((tail_kernel<14, 7>))
-    R2F_SET_LDS((tail_kernel<8, 7>))
-    R2F_SET_LDS((tail_kernel<15, 7>))
-    R2F_SET_LDS((tail_kernel<7, 7>))
-    R2F_SET_LDS((tail_kernel<6, 6>))
+    R2F_SET_LDS((tail_kernel<0>))
+    R2F_SET_LDS((tail_kernel<1>))
+    R2F_SET_LDS((tail_kernel<2>))
+    R2F_SET_LDS((tail_kernel<3>))
+    R2F_SET_LDS((tail_kernel<4>))
+    R2F_SET_LDS((tail_kernel<5>))
+    R2F_SET_LDS((tail_kernel<6>))
     R2F_SET_LDS(front_kernel<true>)
 #undef R2F_SET_LDS
     return hipSuccess;
@@ -1021,11 +1014,11 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     b.cells_off = (int)tail_plane_floats(a.gk, a.mono);
     b.cells_in_lds = tail_lds_bytes(a.gk, a.mono, 1, a.grain_lut.m) <= 80 * 1024 ? 1 : 0;  // keep two workgroups per CU
     const size_t lds = tail_lds_bytes(a.gk, a.mono, b.cells_in_lds, a.grain_lut.m);
-    switch (a.fixed_r) {  // small square mirror-symmetric stencils: the unrolled form
-#define R2F_TAIL_FIXED(R)                                                   \
-    case R:                                                                \
-        hipLaunchKernelGGL((tail_kernel<-1, -1, R>), grid, block, lds, s, b); \
-        return hipGetLastError();
+    switch (a.fixed_r) {  // small square mirror-symmetric stencils take the unrolled form
+#define R2F_TAIL_FIXED(R)                                              \
+    case R:                                                           \
+        hipLaunchKernelGGL((tail_kernel<R>), grid, block, lds, s, b); \
+        break;
         R2F_TAIL_FIXED(1)
         R2F_TAIL_FIXED(2)
         R2F_TAIL_FIXED(3)
@@ -1034,25 +1027,9 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
         R2F_TAIL_FIXED(6)
 #undef R2F_TAIL_FIXED
         default:
+            hipLaunchKernelGGL((tail_kernel<0>), grid, block, lds, s, b);
             break;
     }
-    // the union of the live masks over the three channels picks the instantiation (any superset is correct)
-    int mf = 0, ml = 0;
-    bool all_sym = true;
-    for (int c = 0; c < 3; ++c) mf |= a.gk[c].mask_first_or, ml |= a.gk[c].mask_last_or, all_sym = all_sym && a.gk[c].sym;
-#define R2F_TAIL_CASE(F, L)                                                        \
-    if (all_sym && mf == (F) && ml == (L)) {                                       \
-        hipLaunchKernelGGL((tail_kernel<F, L>), grid, block, lds, s, b);           \
-        return hipGetLastError();                                                  \
-    }
-    R2F_TAIL_CASE(12, 7)  // 9 x 9   (r = 4, padded to 6)
-    R2F_TAIL_CASE(14, 7)  // 11 x 11
-    R2F_TAIL_CASE(8, 7)   // 7 x 7
-    R2F_TAIL_CASE(15, 7)  // 13 x 13
-    R2F_TAIL_CASE(7, 7)   // 5 x 5: one entry per row step
-    R2F_TAIL_CASE(6, 6)   // 3 x 3
-#undef R2F_TAIL_CASE
-    hipLaunchKernelGGL((tail_kernel<-1, -1>), grid, block, lds, s, b);
     return hipGetLastError();
 }
 
