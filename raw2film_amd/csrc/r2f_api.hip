@@ -92,6 +92,9 @@ struct r2f_ctx {
     bool grain_fixed_valid = false;
     int grain_fixed_r = 0, grain_fixed_same = 0;
     int opt_grain_fixed = 1;  // 0: always the generic entry list (A/B)
+    DeviceBuf stencil_fixed_w[3];  // the same for the direct stencil kernel (stencil_fixed<R, 4>), per stencil
+    bool stencil_fixed_valid[3] = {false, false, false};
+    int opt_stencil_fixed = 1;
     int opt_front_blocks = 6;  // front kernel with the curve in LDS: workgroups per CU in its grid (3 are resident at 48 KB each)
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
 };
@@ -460,7 +463,59 @@ void tap_box(const StencilSet& s, int c, int box[4]) {
     box[0] = i_lo, box[1] = i_hi, box[2] = j_lo, box[3] = j_hi;
 }
 
+// R if the channels `chans` of a stencil all fill the same square (2 R + 1)^2 box of non-zero taps around the anchor,
+// 1 <= R <= max_r, left-right mirror symmetric, and their device form has the geometry stencil_fixed expects; else 0.
+int fixed_stencil_radius(const StencilSet& set, const int* chans, int nch, int max_r) {
+    if (nch <= 0) return 0;
+    int b[4];
+    tap_box(set, chans[0], b);
+    const int n = b[1] - b[0] + 1, R = n / 2;
+    if (!((n & 1) && R >= 1 && R <= max_r && b[3] - b[2] + 1 == n && b[0] + R == set.kh / 2 && b[2] + R == set.kw / 2)) return 0;
+    for (int i = 0; i < nch; ++i) {
+        int o[4];
+        tap_box(set, chans[i], o);
+        const DevStencil& d = set.dev[chans[i]];
+        if (memcmp(o, b, sizeof b) || !d.sym || d.ay != R || d.ax != fixed_stencil_ax(R) || d.kh != n || d.n_phases != 1) return 0;
+    }
+    return R;
+}
+
+// stencil_fixed<R, Q>'s weight table for the three channels: [(2 R + Q)][R + 1][Q / 2] pairs each, pair j of input row i =
+// (K[i - 2 j][c], K[i - 2 j - 1][c]) over the left half c <= R of the box, zero outside the kernel.  Channels whose box is
+// not the first channel's (never launched through the table) are left zero.  *same: the three tables are identical.
+std::vector<float> fixed_stencil_weights(const StencilSet& set, int R, int Q, bool* same) {
+    const int n = 2 * R + 1, per = (2 * R + Q) * (R + 1) * (Q / 2);
+    std::vector<float> w((size_t)3 * per * 2, 0.f);
+    int ref = -1;
+    *same = true;
+    for (int c = 0; c < 3; ++c) {
+        int b[4];
+        tap_box(set, c, b);
+        if (b[1] - b[0] + 1 != n || b[3] - b[2] + 1 != n) {
+            *same = false;
+            continue;
+        }
+        const int kc = set.kc == 1 ? 0 : c;
+        auto tap = [&](int i, int j) {
+            return i >= 0 && i <= 2 * R ? set.host[((size_t)(b[0] + i) * set.kw + b[2] + j) * set.kc + kc] : 0.f;
+        };
+        for (int i = 0; i < 2 * R + Q; ++i)
+            for (int j = 0; j <= R; ++j)
+                for (int h = 0; h < Q / 2; ++h) {
+                    float* pair = &w[((size_t)c * per + ((size_t)i * (R + 1) + j) * (Q / 2) + h) * 2];
+                    pair[0] = tap(i - 2 * h, j);      // output row 2 h of the lane
+                    pair[1] = tap(i - 2 * h - 1, j);  // output row 2 h + 1
+                }
+        if (ref < 0)
+            ref = c;
+        else
+            *same = *same && !memcmp(&w[(size_t)c * per * 2], &w[(size_t)ref * per * 2], (size_t)per * 2 * sizeof(float));
+    }
+    return w;
+}
+
 constexpr int kFftMaxTaps = 400;
+constexpr int kFixedMaxR = 11;  // the unrolled direct form beats the FFT form up to 23 x 23 (tools/fft_probe.py), ties at 25 x 25
 
 // Does channel c of stencil `which` take the overlap-save FFT form?
 bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
@@ -470,7 +525,11 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
     // up to 400 taps a side: a 512-point window then still yields 113 x 112 outputs (boxes over 200 taps on an axis take the
     // 512-point window there, see fft_window)
-    return bh <= kFftMaxTaps && bw <= kFftMaxTaps && bh * bw >= ctx->opt_fft_min_taps;
+    if (!(bh <= kFftMaxTaps && bw <= kFftMaxTaps && bh * bw >= ctx->opt_fft_min_taps)) return false;
+    // square mirror-symmetric stencils up to 23 x 23 are faster in the unrolled direct form (needs the device form: callers
+    // run ensure_stencil first)
+    if (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 && s.built_q && fixed_stencil_radius(s, &c, 1, kFixedMaxR)) return false;
+    return true;
 }
 
 // Window shape for a bh x bw tap box on a W x H frame: of {256, 512} rows x {256, 512} columns the one whose three passes
@@ -712,6 +771,23 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
         if (rc) return rc;
     }
     a.ablate = ctx->opt_ablate;
+    // small square mirror-symmetric stencils (below the FFT threshold: up to 19 x 19) take the unrolled form
+    a.fixed_r = 0;
+    a.fixed_w = nullptr;
+    if (variant == 0 && ctx->opt_stencil_fixed && ctx->opt_ablate == 0) {
+        const int R = fixed_stencil_radius(set, a.chan, a.nchan, kFixedMaxR);
+        if (R) {
+            if (!ctx->stencil_fixed_valid[which]) {
+                bool same;
+                const std::vector<float> w = fixed_stencil_weights(set, R, kStencilVariants[0].Q, &same);
+                rc = upload(ctx, ctx->stencil_fixed_w[which], w.data(), w.size() * sizeof(float));
+                if (rc) return rc;
+                ctx->stencil_fixed_valid[which] = true;
+            }
+            a.fixed_r = R;
+            a.fixed_w = static_cast<const float*>(ctx->stencil_fixed_w[which].p);
+        }
+    }
     R2F_HIP(ctx, launch_stencil(a, variant, s));
     return R2F_OK;
 }
@@ -751,6 +827,7 @@ void r2f_destroy(r2f_ctx* ctx) {
     for (auto& t : ctx->tile_order) t.buf.release();
     ctx->lanczos_buf.release();
     ctx->grain_fixed_w.release();
+    for (auto& b : ctx->stencil_fixed_w) b.release();
     ctx->fft_tw.release();
     ctx->fft_s1.release();
     ctx->fft_kimg.release();
@@ -797,6 +874,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_window")) {
         if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window must be 0, 256 or 512");
         ctx->opt_fft_window = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fixed")) {
+        ctx->opt_stencil_fixed = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "grain_fixed")) {
@@ -900,6 +981,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.built_q = 0;
     for (int c = 0; c < 3; ++c) ctx->fft_kf_valid[which][c] = false;
     if (which == R2F_KERNEL_GRAIN) ctx->grain_fixed_valid = false;
+    ctx->stencil_fixed_valid[which] = false;
     return R2F_OK;
 }
 
@@ -1024,44 +1106,19 @@ static bool burn_geometry(const r2f_params* p, int H, int W, int* h_lo, int* w_l
 
 // density == nullptr && planes_out: the grain field alone (K_g * noise) -> planes_out.
 // gfield: a grain field computed that way is applied pointwise instead of being generated here.
-// The grain stencil in the form grain_stencil_fixed wants, when it has one: every channel's non-zero taps fill the same
-// square (2 R + 1)^2 box around the anchor, R = 1 .. 6, left-right mirror symmetric, and the device geometry built for the
-// tail tile has the expected padding.  grain_fixed_r = 0 otherwise (the generic entry list runs).
+// The grain stencil in the form stencil_fixed<R, 2> wants, when it has one (fixed_stencil_radius); grain_fixed_r = 0
+// otherwise (the generic entry list runs).
 static int ensure_grain_fixed(r2f_ctx* ctx) {
     if (ctx->grain_fixed_valid) return R2F_OK;
     StencilSet& set = ctx->stencil[R2F_KERNEL_GRAIN];
     ctx->grain_fixed_valid = true;
-    ctx->grain_fixed_r = 0;
-    int b[4];
-    tap_box(set, 0, b);
-    const int n = b[1] - b[0] + 1, R = n / 2;
-    bool ok = (n & 1) && R >= 1 && R <= 6 && b[3] - b[2] + 1 == n && b[0] + R == set.kh / 2 && b[2] + R == set.kw / 2;
-    for (int c = 0; c < 3 && ok; ++c) {
-        int o[4];
-        tap_box(set, c, o);
-        const DevStencil& d = set.dev[c];
-        ok = !memcmp(o, b, sizeof b) && d.sym && d.ay == R && d.ax == (R <= 2 ? 2 : 6) && d.kh == n;
-    }
-    if (!ok) return R2F_OK;
-    const int per = (2 * R + 2) * (R + 1);
-    std::vector<float> w((size_t)3 * per * 2, 0.f);
-    bool same = true;
-    for (int c = 0; c < 3; ++c) {
-        const int kc = set.kc == 1 ? 0 : c;
-        auto tap = [&](int i, int j) { return set.host[((size_t)(b[0] + i) * set.kw + b[2] + j) * set.kc + kc]; };
-        for (int i = 0; i < 2 * R + 2; ++i)
-            for (int j = 0; j <= R; ++j) {
-                float* pair = &w[((size_t)c * per + (size_t)i * (R + 1) + j) * 2];
-                pair[0] = i <= 2 * R ? tap(i, j) : 0.f;  // output row 0 of the lane: kernel row i
-                pair[1] = i >= 1 ? tap(i - 1, j) : 0.f;  // output row 1: kernel row i - 1
-            }
-        same = same && !memcmp(&w[(size_t)c * per * 2], &w[0], (size_t)per * 2 * sizeof(float));
-    }
-    int rc = upload(ctx, ctx->grain_fixed_w, w.data(), w.size() * sizeof(float));
-    if (rc) return rc;
-    ctx->grain_fixed_r = R;
+    const int chans[3] = {0, 1, 2};
+    ctx->grain_fixed_r = fixed_stencil_radius(set, chans, 3, 6);
+    if (!ctx->grain_fixed_r) return R2F_OK;
+    bool same = false;
+    const std::vector<float> w = fixed_stencil_weights(set, ctx->grain_fixed_r, kTailQ, &same);
     ctx->grain_fixed_same = same ? 1 : 0;
-    return R2F_OK;
+    return upload(ctx, ctx->grain_fixed_w, w.data(), w.size() * sizeof(float));
 }
 
 static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* planes_out,

@@ -581,22 +581,26 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
     }
 }
 
-// ---- small square mirror-symmetric stencils, fully unrolled (the tail kernel's grain stencil) -----------------------
-// 3 x 3 ... 13 x 13 taps (R = 1 ... 6), Q = 2 rows per lane.  The generic entry machinery above is built for stencils of
-// dozens of row steps: for a 9 x 9 one it reads every 8-float block twice (two entries per row step), fetches its weights
-// with two scalar loads per row step that the short loop cannot hide, and keeps a row partial.  Here every input row is
-// read once (its 4 + 2 R floats, as aligned 16-byte blocks), the weight PAIRS (tap of output row 0, tap of output row 1)
-// come from one wave-uniform table that the unrolled code loads ahead, and the mirrored columns are summed before the
-// packed FMAs.  Taps are consumed input row by input row, outer columns to the centre: the same order for every pixel, so
-// results do not depend on the tile or shard a pixel falls in.
-// lds: the lane's first input row and pixel column (plane + ty * 2 * RS + 4 * tx); the tile's column 0 is the image column
-// tile_x0 - AX with AX = 2 (R <= 2) or 6, the host's padding of r to 2 mod 4.  wp: [(2 R + 2)][R + 1] pairs.
-template <int R>
-__device__ __forceinline__ void grain_stencil_fixed(const float* lds, const int RS, const float2v R2F_CONSTANT* wp,
-                                                    float2v (&acc)[1][4]) {
-    constexpr int AX = R <= 2 ? 2 : 6, O = AX - R, NB = (O + 2 * R + 4 + 3) / 4;
+// ---- small square mirror-symmetric stencils, fully unrolled -------------------------------------------------------
+// (2 R + 1)^2 taps, Q = 2 rows per lane (the tail kernel's grain stencil, R <= 6) or 4 (the direct stencil kernel below the
+// FFT threshold, R <= 11).  The generic entry machinery above is built for stencils of dozens of row steps: for a 9 x 9 one
+// it reads every 8-float block twice (two entries per row step), fetches its weights with two scalar loads per row step
+// that the short loop cannot hide, and keeps a row partial.  Here every input row is read once (its 4 + 2 R floats, as
+// aligned 16-byte blocks), the weight PAIRS (taps of output rows 2 j and 2 j + 1) come from one wave-uniform table that the
+// unrolled code loads ahead, and the mirrored columns are summed before the packed FMAs.  Taps are consumed input row by
+// input row, outer columns to the centre: the same order for every pixel, so results do not depend on the tile or shard a
+// pixel falls in.
+// lds: the lane's first input row and pixel column (tile + ty * Q * RS + 4 * tx); the tile's column 0 is the image column
+// tile_x0 - AX with AX = 2, 6, 10 or 14 (the host's padding of r to 2 mod 4).  wp: [(2 R + Q)][R + 1][Q / 2] pairs; pair j of
+// input row i = (K[i - 2 j][c], K[i - 2 j - 1][c]), zero outside the kernel.
+constexpr int fixed_stencil_ax(int R) { return R <= 2 ? 2 : (R <= 6 ? 6 : (R <= 10 ? 10 : 14)); }
+
+template <int R, int Q>
+__device__ __forceinline__ void stencil_fixed(const float* lds, const int RS, const float2v R2F_CONSTANT* wp,
+                                              float2v (&acc)[Q / 2][4]) {
+    constexpr int AX = fixed_stencil_ax(R), O = AX - R, NB = (O + 2 * R + 4 + 3) / 4;
 #pragma unroll
-    for (int i = 0; i < 2 * R + 2; ++i) {
+    for (int i = 0; i < 2 * R + Q; ++i) {
         // the row as aligned register pairs xp[k] = (x[2k], x[2k+1]): a mirrored pair of columns has indices of equal parity,
         // so two neighbouring pixels' sums are one v_pk_add_f32, and a packed FMA picks its pixel with op_sel (no copies)
         float2v xp[2 * NB];
@@ -608,7 +612,6 @@ __device__ __forceinline__ void grain_stencil_fixed(const float* lds, const int 
         }
 #pragma unroll
         for (int c = 0; c <= R; ++c) {
-            const float2v wv = wp[i * (R + 1) + c];
             const int a0 = O + c, b0 = O + 2 * R - c;  // columns of pixel 0's left and mirrored tap (the centre: a0 == b0)
             float2v s[4];                              // s[p]: pixel p's sum in both halves
             if ((a0 & 1) == 0) {
@@ -625,7 +628,12 @@ __device__ __forceinline__ void grain_stencil_fixed(const float* lds, const int 
                 s[2] = float2v{s12.y, s12.y}, s[3] = float2v{s3, s3};
             }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[0][p] = __builtin_elementwise_fma(wv, s[p], acc[0][p]);
+            for (int j = 0; j < Q / 2; ++j) {
+                if (i - 2 * j < 0 || i - 2 * j - 1 > 2 * R) continue;  // both taps of the pair lie outside the kernel
+                const float2v wv = wp[(i * (R + 1) + c) * (Q / 2) + j];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[j][p] = __builtin_elementwise_fma(wv, s[p], acc[j][p]);
+            }
         }
     }
 }

@@ -323,7 +323,9 @@ __device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, 
 
 // amdgpu_waves_per_eu(4): two 512-thread workgroups per CU (4 waves per SIMD) is the operating point the LDS budget is
 // built around, so the register allocator must stay within 128 VGPRs.
-template <int BX, int BY, int Q, int EPI>
+// FR > 0: every channel of the launch is a square mirror-symmetric (2 FR + 1)^2 stencil in one LDS phase: the fully unrolled
+// stencil_fixed instead of the entry list.
+template <int BX, int BY, int Q, int EPI, int FR = 0>
 __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) void stencil_kernel(const StencilArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = BX * BY, TW = 4 * BX, TH = Q * BY;
@@ -349,8 +351,17 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[j][p] = (float2v){0.f, 0.f};
 
+    if (FR > 0) {
+        constexpr int R = FR > 0 ? FR : 1;
+        if (a.ablate != 1)
+            fill_tile_reflect<NT>(smem, RS, TH + 2 * R, TW + st.kw - 1, src, a.src.gy0, a.src.rows, a.W, a.H_global, tile_y0 - st.ay,
+                                  tile_x0 - st.ax);
+        __syncthreads();
+        if (a.ablate != 2)
+            stencil_fixed<R, Q>(lds_lane, RS, (const float2v R2F_CONSTANT*)a.fixed_w + ch * (2 * R + Q) * (R + 1) * (Q / 2), acc);
+    }
     const int R2F_CONSTANT* phases = (const int R2F_CONSTANT*)st.phases;
-    for (int ph = 0; ph < st.n_phases; ++ph) {
+    for (int ph = 0; ph < (FR > 0 ? 0 : st.n_phases); ++ph) {
         const int m0 = phases[4 * ph], lds_rows = phases[4 * ph + 1];
         const int row_begin = phases[4 * ph + 2], e0 = phases[4 * ph + 3];
         const int row_end = phases[4 * ph + 6];
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(256) void single_tap_kernel(const TapArgs a) {
 }
 
 // ------------------------------------------------------------------------------ tail (grain)
-// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (grain_stencil_fixed: square mirror-symmetric kernels up to 13 x 13);
+// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (stencil_fixed: square mirror-symmetric kernels up to 13 x 13);
 // FR = 0: the generic entry list, every tap column of every entry (run-time masks, i.e. branches, cost more than the
 // padding columns they skip in a stencil of two entries per row step).
 template <int FR>
@@ -476,14 +487,14 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
         const float* plane = smem + (mono ? 0 : c * plane_sz);
         if (R2F_TAIL_EXP & 2) continue;
         if (FR > 0) {
-            static_assert(FR == 0 || kTailQ == 2, "grain_stencil_fixed is written for 2 rows per lane");
+
             if (c > 0 && mono && a.fixed_same) {  // one noise plane, one set of taps: the field of channel 0
 #pragma unroll
                 for (int p = 0; p < 4; ++p) G[c][0][p] = G[0][0][p];
             } else {
                 constexpr int R = FR > 0 ? FR : 1;
-                grain_stencil_fixed<R>(plane + ty * Q * RS + 4 * tx, RS,
-                                       (const float2v R2F_CONSTANT*)a.fixed_w + c * (2 * R + 2) * (R + 1), G[c]);
+                stencil_fixed<R, Q>(plane + ty * Q * RS + 4 * tx, RS,
+                                    (const float2v R2F_CONSTANT*)a.fixed_w + c * (2 * R + Q) * (R + 1) * (Q / 2), G[c]);
             }
             continue;
         }
@@ -934,6 +945,28 @@ hipError_t init_kernel_attributes() {
     R2F_SET_LDS((stencil_kernel<32, 16, 4, 1>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 0>))
     R2F_SET_LDS((stencil_kernel<16, 8, 4, 1>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 1>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 1>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 2>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 2>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 3>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 3>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 4>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 4>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 5>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 5>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 6>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 6>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 7>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 7>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 8>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 8>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 9>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 9>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 10>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 10>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 0, 11>))
+    R2F_SET_LDS((stencil_kernel<32, 16, 4, 1, 11>))
     R2F_SET_LDS((tail_kernel<0>))
     R2F_SET_LDS((tail_kernel<1>))
     R2F_SET_LDS((tail_kernel<2>))
@@ -972,6 +1005,31 @@ hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
     const StencilVariant& v = kStencilVariants[variant];
     const size_t lds = stencil_lds_bytes(v, a.st, 3);  // any subset of the channels may be in a.chan
     dim3 block(v.BX * v.BY), grid((a.W + v.TW() - 1) / v.TW(), (a.y1 - a.y0 + v.TH() - 1) / v.TH(), a.nchan);
+    if (variant == 0 && a.fixed_r > 0) {  // small square mirror-symmetric stencils: the unrolled form
+#define R2F_STENCIL_FIXED(R)                                                                        \
+    case R:                                                                                        \
+        if (a.epilogue == 1)                                                                       \
+            hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 1, R>), grid, block, lds, s, a);         \
+        else                                                                                       \
+            hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0, R>), grid, block, lds, s, a);         \
+        return hipGetLastError();
+        switch (a.fixed_r) {
+            R2F_STENCIL_FIXED(1)
+            R2F_STENCIL_FIXED(2)
+            R2F_STENCIL_FIXED(3)
+            R2F_STENCIL_FIXED(4)
+            R2F_STENCIL_FIXED(5)
+            R2F_STENCIL_FIXED(6)
+            R2F_STENCIL_FIXED(7)
+            R2F_STENCIL_FIXED(8)
+            R2F_STENCIL_FIXED(9)
+            R2F_STENCIL_FIXED(10)
+            R2F_STENCIL_FIXED(11)
+            default:
+                break;
+        }
+#undef R2F_STENCIL_FIXED
+    }
     const int key = variant * 2 + (a.epilogue == 1 ? 1 : 0);
     switch (key) {
         case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0>), grid, block, lds, s, a); break;

@@ -41,6 +41,10 @@ struct StencilArgs {
     int xcd_remap;     // 0 none, 1 arithmetic (contiguous run per XCD), 2 table `order`
     const int* order;  // xcd_remap == 2: tile index (bx + gx * by) of every linear workgroup id of one channel
     int ablate;  // profiling aid: 1 = skip the tile fill, 2 = skip the accumulation (results invalid)
+    // fixed_r = R in 1..11: every channel of the launch is a square mirror-symmetric (2 R + 1)^2 stencil laid out as stencil_fixed
+    // expects (variant 0 only); fixed_w: 3 channels x (2 R + 4) x (R + 1) x 2 weight pairs
+    int fixed_r;
+    const float* fixed_w;
 };
 
 // S7: the blurred low-res highlight map and how to up-sample it (ndimage.zoom(order=1) + edge pad, effects.py:381-388)
@@ -90,7 +94,7 @@ struct TailArgs {
     int cells_in_lds, cells_off;  // set by the launcher: grain-LUT cells copied to LDS at float offset cells_off
     DevPlanes gfield;             // grain == 0 && has_gfield: a precomputed grain field is applied pointwise (lut3d_kernel)
     int has_gfield;
-    // fixed_r = R in 1..6: the grain stencil is a square mirror-symmetric (2 R + 1)^2 box laid out as grain_stencil_fixed expects;
+    // fixed_r = R in 1..6: the grain stencil is a square mirror-symmetric (2 R + 1)^2 box laid out as stencil_fixed expects;
     // fixed_w: 3 channels x (2 R + 2) x (R + 1) weight pairs; fixed_same: the three channels share their taps
     int fixed_r, fixed_same;
     const float* fixed_w;

@@ -210,7 +210,8 @@ def test_mirror_symmetric_fast_path(ctx):
     H, W = 100, 150
     img = rng.uniform(0.0, 2.0, (H, W, 3)).astype(np.float32)
     src = to_planes(img)
-    ctx.set_option("stencil_fft", 0)  # this test is about the two direct forms
+    ctx.set_option("stencil_fft", 0)  # this test is about the two entry-list forms of the direct kernel
+    ctx.set_option("stencil_fixed", 0)
 
     def run(k, sym):
         ctx.set_option("stencil_sym", sym)
@@ -234,6 +235,59 @@ def test_mirror_symmetric_fast_path(ctx):
     k[3, 20, 0] = np.nextafter(k[3, 20, 0], np.float32(1))  # break the symmetry of the red plane by one ulp
     np.testing.assert_array_equal(run(k, 1)[..., 0], run(k, 0)[..., 0])
     ctx.set_option("stencil_fft", 1)
+    ctx.set_option("stencil_fixed", 1)
+
+
+@pytest.mark.parametrize("n", [3, 5, 9, 13, 15, 17, 21, 23, 25])
+@pytest.mark.parametrize("epilogue", [0, 1])
+def test_small_square_stencils_unrolled_direct_form(ctx, n, epilogue):
+    """Square mirror-symmetric stencils up to 23 x 23 run the direct kernel's fully unrolled form (stencil_fixed) -- also
+    where the FFT form would be eligible (21 x 21, 23 x 23) --, 25 x 25 the FFT form: against the oracle, against the entry
+    list, per-channel taps, with and without the halation epilogue, on row ranges with halo rows of any origin."""
+    rng = np.random.default_rng(100 + n)
+    H, W = 150, 203
+    k = rng.uniform(-0.05, 1.0, (n, n, 3)).astype(np.float32)
+    k = (k + k[:, ::-1]) / 2
+    k /= k.sum(axis=(0, 1), keepdims=True)
+    img = rng.uniform(0.01, 2.0, (H, W, 3)).astype(np.float32)
+    img[rng.integers(0, H, 20), rng.integers(0, W, 20)] = 16.0
+    which = 0 if epilogue else 1
+    if epilogue:
+        ctx.set_curve1d(stocks()[0].get_density_curve(push_pull=0.0, color_masking=1.0))
+    ref = st.convolve_2d(img, k)
+    if epilogue:
+        ref = st.multi_channel_interp(st.log_clip(ref), stocks()[0].get_density_curve(push_pull=0.0, color_masking=1.0))
+    r = n // 2
+
+    def run(fixed):
+        ctx.set_option("stencil_fixed", fixed)
+        ctx.set_kernel(which, k)
+        params = ctx.make_params()
+        out = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        for y0, y1 in ((0, 41), (41, 42), (42, H)):
+            lo, hi = max(y0 - r, 0), min(y1 + r, H)
+            src = to_planes(img[lo:hi])
+            if epilogue:
+                ctx.stage_halation(src, out, params, src_gy0=lo, dst_gy0=0, y0=y0, y1=y1, H_global=H)
+            else:
+                ctx.stage_mtf(src, out, params, src_gy0=lo, dst_gy0=0, y0=y0, y1=y1, H_global=H)
+        whole = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        if epilogue:
+            ctx.stage_halation(to_planes(img), whole, params, y0=0, y1=H, H_global=H)
+        else:
+            ctx.stage_mtf(to_planes(img), whole, params, y0=0, y1=H, H_global=H)
+        fft = [c["fft"] for c in ctx.stencil_stats(which)]
+        return from_planes(out), from_planes(whole), fft
+
+    a, a_whole, fft = run(1)
+    assert fft == ([1, 1, 1] if n == 25 else [0, 0, 0])
+    assert_close(a, ref, 1e-5, 1e-2, f"{n} x {n} unrolled")
+    if n <= 23:
+        np.testing.assert_array_equal(a, a_whole)  # direct forms: bit for bit whatever the row range
+    b, _, fft_b = run(0)
+    assert fft_b == ([1, 1, 1] if n >= 21 else [0, 0, 0])  # without the unrolled form the FFT threshold is 400 taps
+    assert_close(b, ref, 1e-5, 1e-2, f"{n} x {n} entry list / FFT")
+    ctx.set_option("stencil_fixed", 1)
 
 
 @pytest.mark.parametrize("scale", [14.22, 166.67, 341.33])

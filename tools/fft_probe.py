@@ -15,7 +15,7 @@ def timeit(fn, iters=5):
     return best
 rng = np.random.default_rng(0)
 ctx.set_option("stencil_fft_min_taps", 1)
-for n in (9, 11, 13, 15, 17, 19, 21, 23, 27, 35):
+for n in (17, 19, 21, 23, 25, 27):
     k = rng.uniform(0.0, 1.0, (n, n, 3)).astype(np.float32)
     k = (k + k[:, ::-1]) / 2  # left-right mirror symmetric like the MTF stencils (the direct form's fast path)
     k /= k.sum(axis=(0, 1), keepdims=True)
@@ -24,4 +24,8 @@ for n in (9, 11, 13, 15, 17, 19, 21, 23, 27, 35):
     for fft in (0, 1):
         ctx.set_option("stencil_fft", fft)
         t[fft] = timeit(lambda: ctx.stage_stencil(1, src, dst, y0=0, y1=H, H_global=H))
-    print(f"{n:2d} x {n:2d} ({n * n:4d} taps): direct {t[0]:.3f} ms   fft {t[1]:.3f} ms   {'FFT' if t[1] < t[0] else 'direct'}")
+    ctx.set_option("stencil_fft", 0)
+    ctx.set_option("stencil_fixed", 0)  # the generic entry list instead of the unrolled small-stencil form
+    tg = timeit(lambda: ctx.stage_stencil(1, src, dst, y0=0, y1=H, H_global=H))
+    ctx.set_option("stencil_fixed", 1)
+    print(f"{n:2d} x {n:2d} ({n * n:4d} taps): direct {t[0]:.3f} ms (entry list {tg:.3f})   fft {t[1]:.3f} ms   {'FFT' if t[1] < t[0] else 'direct'}")
