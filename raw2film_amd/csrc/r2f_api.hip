@@ -1113,7 +1113,7 @@ static int ensure_grain_fixed(r2f_ctx* ctx) {
     StencilSet& set = ctx->stencil[R2F_KERNEL_GRAIN];
     ctx->grain_fixed_valid = true;
     const int chans[3] = {0, 1, 2};
-    ctx->grain_fixed_r = fixed_stencil_radius(set, chans, 3, 6);
+    ctx->grain_fixed_r = fixed_stencil_radius(set, chans, 3, 9);
     if (!ctx->grain_fixed_r) return R2F_OK;
     bool same = false;
     const std::vector<float> w = fixed_stencil_weights(set, ctx->grain_fixed_r, kTailQ, &same);

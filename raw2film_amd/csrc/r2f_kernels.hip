@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void single_tap_kernel(const TapArgs a) {
 }
 
 // ------------------------------------------------------------------------------ tail (grain)
-// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (stencil_fixed: square mirror-symmetric kernels up to 13 x 13);
+// FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (stencil_fixed: square mirror-symmetric kernels up to 19 x 19);
 // FR = 0: the generic entry list, every tap column of every entry (run-time masks, i.e. branches, cost more than the
 // padding columns they skip in a stencil of two entries per row step).
 template <int FR>
@@ -974,6 +974,9 @@ hipError_t init_kernel_attributes() {
     R2F_SET_LDS((tail_kernel<4>))
     R2F_SET_LDS((tail_kernel<5>))
     R2F_SET_LDS((tail_kernel<6>))
+    R2F_SET_LDS((tail_kernel<7>))
+    R2F_SET_LDS((tail_kernel<8>))
+    R2F_SET_LDS((tail_kernel<9>))
     R2F_SET_LDS(front_kernel<true>)
 #undef R2F_SET_LDS
     return hipSuccess;
@@ -1083,6 +1086,9 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
         R2F_TAIL_FIXED(4)
         R2F_TAIL_FIXED(5)
         R2F_TAIL_FIXED(6)
+        R2F_TAIL_FIXED(7)
+        R2F_TAIL_FIXED(8)
+        R2F_TAIL_FIXED(9)
 #undef R2F_TAIL_FIXED
         default:
             hipLaunchKernelGGL((tail_kernel<0>), grid, block, lds, s, b);

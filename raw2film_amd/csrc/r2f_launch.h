@@ -94,7 +94,7 @@ struct TailArgs {
     int cells_in_lds, cells_off;  // set by the launcher: grain-LUT cells copied to LDS at float offset cells_off
     DevPlanes gfield;             // grain == 0 && has_gfield: a precomputed grain field is applied pointwise (lut3d_kernel)
     int has_gfield;
-    // fixed_r = R in 1..6: the grain stencil is a square mirror-symmetric (2 R + 1)^2 box laid out as stencil_fixed expects;
+    // fixed_r = R in 1..9: the grain stencil is a square mirror-symmetric (2 R + 1)^2 box laid out as stencil_fixed expects;
     // fixed_w: 3 channels x (2 R + 2) x (R + 1) weight pairs; fixed_same: the three channels share their taps
     int fixed_r, fixed_same;
     const float* fixed_w;

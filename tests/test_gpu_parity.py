@@ -618,10 +618,10 @@ def test_grain_field_split_equals_the_fused_tail_bit_for_bit(ctx):
         assert_close(split.cpu().numpy(), ref, 1e-5, 1e-1, "split tail vs oracle")
 
 
-@pytest.mark.parametrize("n", [3, 5, 7, 9, 11, 13, 15])
+@pytest.mark.parametrize("n", [3, 5, 7, 9, 11, 13, 15, 19, 21])
 @pytest.mark.parametrize("mono, per_channel", [(False, False), (True, False), (False, True)])
 def test_small_square_grain_stencils_unrolled_form_against_the_oracle_and_the_entry_list(ctx, n, mono, per_channel):
-    """Square mirror-symmetric grain stencils up to 13 x 13 take the fully unrolled form (grain_stencil_fixed), 15 x 15 and
+    """Square mirror-symmetric grain stencils up to 19 x 19 take the fully unrolled form (stencil_fixed<R, 2>), 21 x 21 and
     anything irregular the generic entry list; both reproduce the oracle's field (K_g * N at global coordinates) and each
     other to rounding, with shared or per-channel taps, colour or monochrome noise, on row ranges of any origin."""
     rng = np.random.default_rng(n)
@@ -649,9 +649,9 @@ def test_small_square_grain_stencils_unrolled_form_against_the_oracle_and_the_en
         for y0, y1 in ((0, 37), (37, 38), (38, H)):  # the tile grid follows y0: every pixel must not care
             ctx.stage_grain_field(F, params, dst_gy0=0, y0=y0, y1=y1, H_global=H)
         fields[fixed] = from_planes(F)
-        assert np.abs(fields[fixed] - ref).max() <= 2e-5, (fixed, n)  # |field| ~ 1..4, the noise itself is good to 1e-5
+        assert np.abs(fields[fixed] - ref).max() <= 5e-6 * np.abs(ref).max(), (fixed, n)  # the noise itself is good to 1e-5 of |n| < 6
         whole = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
         ctx.stage_grain_field(whole, params, dst_gy0=0, y0=0, y1=H, H_global=H)
         np.testing.assert_array_equal(from_planes(whole), fields[fixed])  # bit for bit whatever the row range
     ctx.set_option("grain_fixed", 1)
-    assert np.abs(fields[1] - fields[0]).max() <= 4e-6  # two summation orders of the same 2-D sum
+    assert np.abs(fields[1] - fields[0]).max() <= 1e-6 * np.abs(ref).max()  # two summation orders of the same 2-D sum
