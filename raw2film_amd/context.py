@@ -344,7 +344,7 @@ class HipContext:
         return out
 
     def stencil_stats(self, which: int):
-        """Per channel: dict(entries, rowsteps, phases, sym, kh, kw, q, fft, window) of the device form of stencil `which`
+        """Per channel: dict(entries, rowsteps, phases, sym, unrolled, kh, kw, q, fft, window) of the device form of stencil `which`
         (bench.py); fft = 1: the channel takes the FFT form, window = (rows, columns) of its last launch or None."""
         out = (C.c_int * 24)()
         self._check(self._lib.r2f_stencil_stats(self._h, int(which), out))
@@ -353,6 +353,8 @@ class HipContext:
         for c in range(3):
             d = dict(zip(keys, out[8 * c:8 * c + 7]))
             word = out[8 * c + 7]
+            d["unrolled"] = d["sym"] >> 1  # R of the fully unrolled (2 R + 1)^2 direct form, 0: the entry list
+            d["sym"] &= 1
             d["fft"] = word & 1
             d["window"] = ((word >> 1) // 1024, (word >> 1) % 1024) if word >> 1 else None
             stats.append(d)

@@ -475,7 +475,17 @@ int fixed_stencil_radius(const StencilSet& set, const int* chans, int nch, int m
         int o[4];
         tap_box(set, chans[i], o);
         const DevStencil& d = set.dev[chans[i]];
-        if (memcmp(o, b, sizeof b) || !d.sym || d.ay != R || d.ax != fixed_stencil_ax(R) || d.kh != n || d.n_phases != 1) return 0;
+        // the device form pairs mirrored taps (and pads the box) from 9 x 9 up; below that the box is built as it is
+        if (memcmp(o, b, sizeof b) || d.sym != (R >= 4 ? 1 : 0) || d.ay != R || d.ax != fixed_stencil_ax(R) || d.kh != n ||
+            d.n_phases != 1)
+            return 0;
+        const int kc = set.kc == 1 ? 0 : chans[i];
+        for (int y = 0; y < n; ++y)  // left-right mirror symmetric, bit for bit
+            for (int x = 0; x < R; ++x) {
+                const float l = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
+                const float r = set.host[((size_t)(b[0] + y) * set.kw + b[2] + 2 * R - x) * set.kc + kc];
+                if (memcmp(&l, &r, sizeof l)) return 0;
+            }
     }
     return R;
 }
@@ -1090,7 +1100,12 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
     for (int c = 0; c < 3; ++c) {
         const DevStencil& d = set.dev[c];
         int* o = out + 8 * c;
-        o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym;
+        // bit 0: mirrored taps are paired in the entry list; bits 1..: R when the channel takes the unrolled stencil_fixed form
+        // (the grain stencil: all three channels together, and the geometry of the tail tile, which this call may not have built)
+        const int all[3] = {0, 1, 2};
+        const int fr = which == R2F_KERNEL_GRAIN ? (ctx->opt_grain_fixed ? fixed_stencil_radius(set, all, 3, 9) : 0)
+                                                 : (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 ? fixed_stencil_radius(set, &c, 1, kFixedMaxR) : 0);
+        o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym | (fr << 1);
         o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q;
         o[7] = fft_eligible(ctx, set, c) ? 1 | ((ctx->fft_kf_valid[which][c] ? ctx->fft_kf_dims[which][c] : 0) << 1) : 0;
     }

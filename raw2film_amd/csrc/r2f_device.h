@@ -588,17 +588,18 @@ __device__ __forceinline__ void stencil_accumulate_sym(const float* lds, const D
 // that the short loop cannot hide, and keeps a row partial.  Here every input row is read once (its 4 + 2 R floats, as
 // aligned 16-byte blocks), the weight PAIRS (taps of output rows 2 j and 2 j + 1) come from one wave-uniform table that the
 // unrolled code loads ahead, and the mirrored columns are summed before the packed FMAs.  Taps are consumed input row by
-// input row, outer columns to the centre: the same order for every pixel, so results do not depend on the tile or shard a
-// pixel falls in.
+// input row (each row a partial, added to the total), outer columns to the centre: the same order for every pixel, so
+// results do not depend on the tile or shard a pixel falls in.
 // lds: the lane's first input row and pixel column (tile + ty * Q * RS + 4 * tx); the tile's column 0 is the image column
-// tile_x0 - AX with AX = 2, 6, 10 or 14 (the host's padding of r to 2 mod 4).  wp: [(2 R + Q)][R + 1][Q / 2] pairs; pair j of
+// tile_x0 - AX: AX = R below 9 x 9 (the host builds those boxes unpadded), else 6, 10 or 14 (its padding of r to 2 mod 4).  wp: [(2 R + Q)][R + 1][Q / 2] pairs; pair j of
 // input row i = (K[i - 2 j][c], K[i - 2 j - 1][c]), zero outside the kernel.
-constexpr int fixed_stencil_ax(int R) { return R <= 2 ? 2 : (R <= 6 ? 6 : (R <= 10 ? 10 : 14)); }
+constexpr int fixed_stencil_ax(int R) { return R < 4 ? R : (R <= 6 ? 6 : (R <= 10 ? 10 : 14)); }
 
 template <int R, int Q>
 __device__ __forceinline__ void stencil_fixed(const float* lds, const int RS, const float2v R2F_CONSTANT* wp,
                                               float2v (&acc)[Q / 2][4]) {
     constexpr int AX = fixed_stencil_ax(R), O = AX - R, NB = (O + 2 * R + 4 + 3) / 4;
+    float2v part[Q / 2][4];
 #pragma unroll
     for (int i = 0; i < 2 * R + Q; ++i) {
         // the row as aligned register pairs xp[k] = (x[2k], x[2k+1]): a mirrored pair of columns has indices of equal parity,
@@ -632,8 +633,16 @@ __device__ __forceinline__ void stencil_fixed(const float* lds, const int RS, co
                 if (i - 2 * j < 0 || i - 2 * j - 1 > 2 * R) continue;  // both taps of the pair lie outside the kernel
                 const float2v wv = wp[(i * (R + 1) + c) * (Q / 2) + j];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) acc[j][p] = __builtin_elementwise_fma(wv, s[p], acc[j][p]);
+                for (int p = 0; p < 4; ++p) part[j][p] = c == 0 ? wv * s[p] : __builtin_elementwise_fma(wv, s[p], part[j][p]);
             }
+        }
+        // one input row = one row partial, added to the total: the rounding error grows with rows + columns, not with their
+        // product (a single FMA chain over the 529 taps of a 23 x 23 stencil was 3x further from the oracle)
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j) {
+            if (i - 2 * j < 0 || i - 2 * j - 1 > 2 * R) continue;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[j][p] += part[j][p];
         }
     }
 }

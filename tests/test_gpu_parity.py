@@ -277,6 +277,7 @@ def test_small_square_stencils_unrolled_direct_form(ctx, n, epilogue):
         else:
             ctx.stage_mtf(to_planes(img), whole, params, y0=0, y1=H, H_global=H)
         fft = [c["fft"] for c in ctx.stencil_stats(which)]
+        assert [c["unrolled"] for c in ctx.stencil_stats(which)] == [n // 2 if fixed and n <= 23 else 0] * 3
         return from_planes(out), from_planes(whole), fft
 
     a, a_whole, fft = run(1)
@@ -645,6 +646,7 @@ def test_small_square_grain_stencils_unrolled_form_against_the_oracle_and_the_en
     fields = {}
     for fixed in (1, 0):
         ctx.set_option("grain_fixed", fixed)
+        assert [c["unrolled"] for c in ctx.stencil_stats(2)] == [n // 2 if fixed and n <= 19 else 0] * 3
         F = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
         for y0, y1 in ((0, 37), (37, 38), (38, H)):  # the tile grid follows y0: every pixel must not care
             ctx.stage_grain_field(F, params, dst_gy0=0, y0=y0, y1=y1, H_global=H)
