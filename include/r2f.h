@@ -114,7 +114,13 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
  *     gpu_processor.py:1763-1862; used by the multi-GPU row tiler and by the parity tests.
  * A call computes global rows [y0, y1) of an H_global x W frame.  Source rows outside
  * [0, H_global) are reflected (BORDER_REFLECT_101, as cv.filter2D does on the CPU path);
- * every reflected source row must lie inside the source buffer's [gy0, gy0+rows). --- */
+ * every reflected source row must lie inside the source buffer's [gy0, gy0+rows).
+ * The stencil stages (r2f_stage_halation, r2f_stage_mtf, r2f_stage_stencil, r2f_stage_chroma_nr_v) are OUT OF PLACE: a
+ * destination plane that shares bytes with a source plane is refused with R2F_EINVAL (tiles and FFT batches read halo rows
+ * that others would already have overwritten).  r2f_stage_grain is pointwise on the density and may run exactly in place
+ * (same base, stride and first row); any other overlap is refused.
+ * Every entry point binds the context's device for the duration of the call and restores the caller's current device on
+ * return, so several contexts (one per GPU) can be driven from one thread. --- */
 
 /* S0+S1 (+S3+S4 (+S8)) pointwise.  `in` holds global rows [in_gy0, in_gy0+in_rows).
  * upto=EXPOSURE/DENSITY writes planes `dst`; upto=OUTPUT writes out_* (rows indexed from out_gy0). */

@@ -34,29 +34,40 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into raw2film_amd/libr2f_hip.so; returns its path."""
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [
-        _hipcc(),
-        "-O3",
-        "-std=c++17",
-        f"--offload-arch={ARCH}",
-        "-fPIC",
-        "-shared",
-        "-Wall",
-        "-Wno-unused-function",
-        "-o",
-        LIB_PATH + ".tmp",
-    ] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
+def _compile_one(hipcc: str, src: str, obj: str, defines: list[str]) -> tuple[str, int, str]:
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", "-c", "-o", obj,
+           os.path.join(CSRC, src)] + defines
     res = subprocess.run(cmd, capture_output=True, text=True)
+    return " ".join(cmd), res.returncode, res.stdout + res.stderr
+
+
+def build(force: bool = False, verbose: bool = False, defines: list[str] | None = None, out: str | None = None) -> str:
+    """Compile every HIP source for gfx950 (one hipcc per source, in parallel) and link them into
+    raw2film_amd/libr2f_hip.so; returns its path.  `defines` (-D...) and `out` build development variants elsewhere."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    target = out or LIB_PATH
+    if not force and not defines and not out and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "_obj" + ("" if not out else "_" + os.path.basename(out)))
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    with ThreadPoolExecutor(len(SOURCES)) as pool:
+        results = list(pool.map(lambda so: _compile_one(hipcc, so[0], so[1], list(defines or [])), zip(SOURCES, objs)))
+    for cmd, rc, log in results:
+        if verbose:
+            print(cmd, flush=True)
+        if rc != 0:
+            raise RuntimeError(f"hipcc failed ({rc}): {cmd}\n{log}")
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target + ".tmp"] + objs
+    if verbose:
+        print(" ".join(link), flush=True)
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":

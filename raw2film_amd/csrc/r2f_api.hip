@@ -117,6 +117,31 @@ int fail(r2f_ctx* ctx, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, R2F_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+
+// Every entry point that touches HIP binds the context's device for the duration of the call and puts the caller's
+// current device back on return: two contexts on two GPUs can be driven from one thread (and torch's notion of the current
+// device is left alone).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        status = hipGetDevice(&prev);
+        if (status == hipSuccess && prev != device) {
+            status = hipSetDevice(device);
+            switched = status == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define R2F_GUARD(ctx)                  \
+    DeviceGuard guard_((ctx)->device); \
+    if (guard_.status != hipSuccess) return fail(ctx, R2F_EHIP, "cannot bind device %d: %s", (ctx)->device, hipGetErrorString(guard_.status))
+
 // Tables change only when a render parameter changes (the reference's caching rule), so the upload path
 // is allowed to be slow: wait for every render still in flight on any stream before overwriting a table
 // that those kernels may be reading, then copy synchronously.
@@ -372,6 +397,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 bool planes_vec_ok(const r2f_planes* pl, int W) {
     return W % 4 == 0 && aligned16(pl->data) && pl->plane_stride % 4 == 0;
+}
+
+// Does any plane of `a` (rows x W floats, plane_stride apart) share bytes with any plane of `b`?
+bool planes_overlap(const r2f_planes* a, const r2f_planes* b, int W) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const float* a0 = a->data + i * a->plane_stride;
+            const float* b0 = b->data + j * b->plane_stride;
+            const float* a1 = a0 + (int64_t)a->rows * W;
+            const float* b1 = b0 + (int64_t)b->rows * W;
+            if (reinterpret_cast<uintptr_t>(a0) < reinterpret_cast<uintptr_t>(b1) &&
+                reinterpret_cast<uintptr_t>(b0) < reinterpret_cast<uintptr_t>(a1))
+                return true;
+        }
+    return false;
 }
 
 DevPlanes to_dev(const r2f_planes* pl) {
@@ -728,6 +768,8 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
         if (rc) return rc;
     }
     if (epilogue == 1 && !ctx->curve.cells) return fail(ctx, R2F_EINVAL, "density curve not set (r2f_set_curve1d)");
+    if (planes_overlap(src, dst, W))  // tiles (and FFT batches) read halo rows that others have already overwritten
+        return fail(ctx, R2F_EINVAL, "stencil %d: source and destination planes overlap (the stencil stages are out of place)", which);
     StencilArgs a;
     for (int c = 0; c < 3; ++c) {
         a.st[c] = set.dev[c];
@@ -814,7 +856,8 @@ int r2f_create(int device, r2f_ctx** out) {
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return R2F_EHIP;
-    if (hipSetDevice(device) != hipSuccess) return R2F_EHIP;
+    DeviceGuard guard(device);  // the caller's current device is restored on return
+    if (guard.status != hipSuccess) return R2F_EHIP;
     if (init_kernel_attributes() != hipSuccess || fft_init_attributes() != hipSuccess) return R2F_EHIP;
     r2f_ctx* ctx = new r2f_ctx();
     ctx->device = device;
@@ -824,7 +867,7 @@ int r2f_create(int device, r2f_ctx** out) {
 
 void r2f_destroy(r2f_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     ctx->lut2d_buf.release();
     ctx->lut3d_buf.release();
     ctx->curve_buf.release();
@@ -942,7 +985,7 @@ int r2f_set_matrix3x3(r2f_ctx* ctx, const float* m) {
 int r2f_set_lut2d(r2f_ctx* ctx, const float* lut, int n) {
     if (!ctx) return R2F_EINVAL;
     if (!lut || n < 2) return fail(ctx, R2F_EINVAL, "lut2d: need (n, n, 3) with n >= 2");
-    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    R2F_GUARD(ctx);
     std::vector<float4> tex((size_t)n * n);
     for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(lut[3 * i], lut[3 * i + 1], lut[3 * i + 2], 0.f);
     int rc = upload(ctx, ctx->lut2d_buf, tex.data(), tex.size() * sizeof(float4));
@@ -955,7 +998,7 @@ int r2f_set_lut2d(r2f_ctx* ctx, const float* lut, int n) {
 int r2f_set_lut3d(r2f_ctx* ctx, const float* lut, int n) {
     if (!ctx) return R2F_EINVAL;
     if (!lut || n < 2 || n > 256) return fail(ctx, R2F_EINVAL, "lut3d: need (n, n, n, 3) with 2 <= n <= 256");
-    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    R2F_GUARD(ctx);
     std::vector<float4> tex((size_t)n * n * n);
     for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(lut[3 * i], lut[3 * i + 1], lut[3 * i + 2], 0.f);
     int rc = upload(ctx, ctx->lut3d_buf, tex.data(), tex.size() * sizeof(float4));
@@ -967,13 +1010,13 @@ int r2f_set_lut3d(r2f_ctx* ctx, const float* lut, int n) {
 
 int r2f_set_curve1d(r2f_ctx* ctx, const float* lut4xm, int m) {
     if (!ctx) return R2F_EINVAL;
-    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    R2F_GUARD(ctx);
     return upload_curve(ctx, ctx->curve_buf, ctx->curve, lut4xm, m);
 }
 
 int r2f_set_grain_lut(r2f_ctx* ctx, const float* lut4xm, int m) {
     if (!ctx) return R2F_EINVAL;
-    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    R2F_GUARD(ctx);
     return upload_curve(ctx, ctx->grain_lut_buf, ctx->grain_lut, lut4xm, m);
 }
 
@@ -981,7 +1024,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     if (!ctx) return R2F_EINVAL;
     if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "set_kernel: which must be 0..2");
     if (!k || kh < 1 || kw < 1 || (kc != 1 && kc != 3)) return fail(ctx, R2F_EINVAL, "set_kernel: need (kh, kw, 1|3)");
-    R2F_HIP(ctx, hipSetDevice(ctx->device));
+    R2F_GUARD(ctx);
     StencilSet& s = ctx->stencil[which];
     s.present = true;
     s.kh = kh;
@@ -1000,6 +1043,7 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
                     const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
                     int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (y1 <= y0) return R2F_OK;
     if (!in || W <= 0 || y0 < in_gy0 || y1 > in_gy0 + in_rows || in_layout < 0 || in_layout > 2)
         return fail(ctx, R2F_EINVAL, "front: bad input geometry");
@@ -1051,6 +1095,7 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
 int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density, int y0,
                        int y1, int W, int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     return run_stencil(ctx, R2F_KERNEL_HALATION, exposure, density, y0, y1, W, H_global, 1, p->log_eps,
                        static_cast<hipStream_t>(stream));
 }
@@ -1058,18 +1103,21 @@ int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* expo
 int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1,
                   int W, int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     return run_stencil(ctx, R2F_KERNEL_MTF, din, dout, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
 }
 
 int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W,
                       int H_global, void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "stencil: which must be 0..2");
     return run_stencil(ctx, which, src, dst, y0, y1, W, H_global, 0, 0.f, static_cast<hipStream_t>(stream));
 }
 
 int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes) {
     if (!ctx || cls < 0 || cls > 2 || !total_ms || !launches || !bytes) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     double sum = 0.0;
     for (auto& ev : ctx->timing_ev[cls]) {
         R2F_HIP(ctx, hipEventSynchronize(ev.second));
@@ -1089,6 +1137,7 @@ int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, do
 
 int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
     if (!ctx || !out) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (which < 0 || which > 2) return fail(ctx, R2F_EINVAL, "stencil: which must be 0..2");
     StencilSet& set = ctx->stencil[which];
     if (!set.present) return fail(ctx, R2F_EINVAL, "stencil %d not set (r2f_set_kernel)", which);
@@ -1183,6 +1232,11 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         if (!a.grain) return fail(ctx, R2F_EINVAL, "grain stage called with the grain flag off");
         rc = check_rows(ctx, "grain dst", planes_out, y0, y1);
         if (rc) return rc;
+        // pointwise on the density, so exactly in place (same base, stride and first row) is fine; anything else that
+        // overlaps would have one pixel's store land on another pixel's load
+        if (!field_only && planes_overlap(density, planes_out, W) &&
+            !(density->data == planes_out->data && density->plane_stride == planes_out->plane_stride && density->gy0 == planes_out->gy0))
+            return fail(ctx, R2F_EINVAL, "grain: source and destination planes overlap without being the same buffer");
         a.to_planes = field_only ? 2 : 1;
         a.dst = to_dev(planes_out);
         vec = vec && planes_vec_ok(planes_out, W);
@@ -1231,12 +1285,14 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
 int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const float* burn_map, float* out_f32,
                    uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     return run_tail(ctx, p, density, nullptr, burn_map, out_f32, out_u8, out_gy0, y0, y1, W, H_global, stream);
 }
 
 int r2f_stage_grain_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* field, int y0, int y1, int W, int H_global,
                           void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!field) return fail(ctx, R2F_EINVAL, "grain field: null destination");
     return run_tail(ctx, p, nullptr, field, nullptr, nullptr, nullptr, 0, y0, y1, W, H_global, stream);
 }
@@ -1244,6 +1300,7 @@ int r2f_stage_grain_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* f
 int r2f_stage_tail_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* field, float* out_f32,
                          uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!field) return fail(ctx, R2F_EINVAL, "tail: null grain field");
     return run_tail(ctx, p, density, nullptr, nullptr, out_f32, out_u8, out_gy0, y0, y1, W, H_global, stream, field);
 }
@@ -1251,6 +1308,7 @@ int r2f_stage_tail_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* de
 int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1, int W,
                     int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!dout) return fail(ctx, R2F_EINVAL, "grain: null destination");
     return run_tail(ctx, p, din, dout, nullptr, nullptr, nullptr, 0, y0, y1, W, H_global, stream);
 }
@@ -1258,6 +1316,7 @@ int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, co
 int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* cell_sums, int y0, int y1, int W,
                         int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     int h_lo, w_lo;
     if (!cell_sums || !burn_geometry(p, H_global, W, &h_lo, &w_lo)) return fail(ctx, R2F_EINVAL, "burn sums: bad arguments");
     if (y0 < 0 || y1 > H_global || y1 < y0) return fail(ctx, R2F_EINVAL, "burn sums: bad rows");
@@ -1281,6 +1340,7 @@ int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* den
 int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums, float* burn_map, float* scratch, int W,
                        int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     int h_lo, w_lo;
     if (!cell_sums || !burn_map || !scratch || !burn_geometry(p, H_global, W, &h_lo, &w_lo))
         return fail(ctx, R2F_EINVAL, "burn map: bad arguments");
@@ -1306,6 +1366,7 @@ int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums
 int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
                     void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!in || in_layout < 0 || in_layout > 2 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || out_h > H || out_w > W)
         return fail(ctx, R2F_EINVAL, "resize_area: the target must be a non-empty frame no larger than the source");
     int rc = check_rows(ctx, "resize dst", dst, 0, out_h);
@@ -1325,6 +1386,7 @@ int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, c
 int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const double* m_dst_to_src, const r2f_planes* dst,
                     int out_h, int out_w, int oy, int ox, void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!in || !m_dst_to_src || in_layout < 0 || in_layout > 2 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
         return fail(ctx, R2F_EINVAL, "warp_affine: bad arguments");
     int rc = check_rows(ctx, "warp dst", dst, 0, out_h);
@@ -1387,6 +1449,7 @@ int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef) {
 
 int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!src_hwc || !dst_hwc || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
         return fail(ctx, R2F_EINVAL, "resize_lanczos4: bad arguments");
     const size_t n_ofs = (size_t)out_w + out_h, n_coef = 8 * n_ofs;
@@ -1446,6 +1509,7 @@ static int chroma_weights(r2f_ctx* ctx, int size, ChromaArgs& a) {
 int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy0, int in_rows, const r2f_planes* dst, int size,
                           int y0, int y1, int W, void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (y1 <= y0) return R2F_OK;
     if (!in || W <= 0 || y0 < in_gy0 || y1 > in_gy0 + in_rows || in_layout < 0 || in_layout > 2)
         return fail(ctx, R2F_EINVAL, "chroma_nr: bad input geometry");
@@ -1472,6 +1536,7 @@ int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy
 int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes* dst, int size, int y0, int y1, int W,
                           int H_global, void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (y1 <= y0) return R2F_OK;
     if (W <= 0 || y0 < 0 || y1 > H_global) return fail(ctx, R2F_EINVAL, "chroma_nr: bad geometry");
     ChromaArgs a;
@@ -1482,6 +1547,7 @@ int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes*
     if (rc) return rc;
     rc = check_rows(ctx, "chroma_nr src", src, std::max(y0 - size, 0), std::min(y1 + size, H_global));
     if (rc) return rc;
+    if (planes_overlap(src, dst, W)) return fail(ctx, R2F_EINVAL, "chroma_nr: source and destination planes overlap (out of place only)");
     a.src = to_dev(src);
     a.dst = to_dev(dst);
     a.y0 = y0;
@@ -1496,6 +1562,7 @@ int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes*
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1, int W,
                     void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     NoiseArgs a;
     a.hash = hash_planes;
     a.noise = noise_planes;
@@ -1510,6 +1577,7 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
 
 int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint32_t* counts, void* stream) {
     if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (!counts || H < 0 || W < 0 || (!image_hwc && H > 0 && W > 0)) return fail(ctx, R2F_EINVAL, "histogram: bad arguments");
     if (!aligned16(image_hwc)) return fail(ctx, R2F_EINVAL, "histogram: image must be 16-byte aligned");
     R2F_HIP(ctx, launch_histogram_u8(image_hwc, (long long)H * W * 3, counts, static_cast<hipStream_t>(stream)));
@@ -1538,6 +1606,7 @@ size_t r2f_workspace_bytes(const r2f_params* p, int H, int W) {
 int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32, uint8_t* out_u8, int H,
                int W, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
     if (H <= 0 || W <= 0) return fail(ctx, R2F_EINVAL, "render: empty frame");
     const size_t need = r2f_workspace_bytes(p, H, W);
     if (need > workspace_bytes || (need && !workspace)) return fail(ctx, R2F_EINVAL, "render: workspace too small (%zu needed)", need);

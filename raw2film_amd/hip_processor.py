@@ -5,10 +5,12 @@ Mirrors `CpuProcessor.process` (cpu_processor.py:269-414) / `GpuProcessor.proces
 keyword names and defaults, unknown keywords swallowed, LUTs / stencils rebuilt and
 re-uploaded only when their parameter dict changes (cpu_processor.py:104-105,157-158,...).
 
-Scope: the post-decode per-pixel path, plus the index-only geometry around it (aspect crop, zoom,
-quarter turns before; canvas after), the pre-path chroma NR and the highlight burn (S7).  RAW decoding, lens
-correction, free rotation and the `max_scale` resize belong to the rows SURVEY.md section 8f lists as "next";
-asking for them raises NotImplementedError instead of silently rendering something else.
+Scope: the post-decode per-pixel path plus what sits either side of it: aspect crop, zoom,
+quarter turns, free rotation, the preview / `max_scale` down-scale and the pre-path chroma NR before; the highlight
+burn (S7) inside; uint8, the LANCZOS4 way back from `max_scale`, canvas and histogram after.  RAW decoding and lens
+correction (lensfun) are out of scope: a call that would need them -- `lens_correction=True` WITH a camera and a lens, the
+only case in which the reference corrects anything (effects.py:22-30) -- raises NotImplementedError instead of silently
+rendering something else.
 
 `src` is therefore a decoded frame: a float32 (H, W, 3|4) array / CUDA tensor in linear CIE XYZ
 (what `raw_to_linear` returns, raw_conversion.py:33-53), or the path of a `.npy` file holding one.
@@ -157,6 +159,11 @@ class HipProcessor:
                                canvas_ratio=1.0, **kwargs):
         """PHASE 1 of the two-phase batch API (gpu_processor.py:715-783): pure host work, touches
         no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32."""
+        if lens_correction and cam is not None and lens is not None:
+            # the reference corrects only when both are given (cpu_processor.py:107-108, effects.py:22-30); lensfun is not
+            # part of the accelerated path, and rendering an uncorrected frame in its place would be a silent difference
+            raise NotImplementedError("lens correction (lensfunpy, effects.py:22-43) is outside the accelerated path: "
+                                      "pass lens_correction=False or no cam / lens")
         image = self._load_decoded(src)
         aspect = frame_width / frame_height
         warp = None

@@ -12,8 +12,11 @@ RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GP
     ncclGroupStart/End): at 100 MP that is 60 rows x 12288 px x 3 planes x 4 B = 8.8 MB per direction
     -- latency-bound, every pair on its own xGMI link.  S0+S1 runs on the rows the neighbours wait for
     first and on the interior rows while the halos travel.  Global top/bottom edges are
-    reflected (BORDER_REFLECT_101) inside the kernels.  Because every stage accumulates taps in a
-    tile-independent order, the sharded result is bit-identical to the single-GPU result.
+    reflected (BORDER_REFLECT_101) inside the kernels.  With the DIRECT stencils (`stencil_fft = 0`) every
+    stage sums its taps in a tile-independent order and the sharded result is bit-identical to the single-GPU
+    one.  The default fp64 FFT form anchors its overlap-save windows at the first row of the call, so a shard
+    tiles the frame differently from the whole-frame render: the fp64 rounding noise (~1e-13) differs, and after
+    the one rounding to fp32 a handful of pixels of a 100 MP frame may differ by one ulp (tests/test_gpu_fullsize.py).
 
 BatchSharder -- MANY frames (batch export, gui.py:2393-2514): frame i -> rank i mod world, no
     collectives; per rank a producer thread runs the host phase (`extract_image_data_cpu`) one
@@ -323,33 +326,59 @@ class BatchSharder:
         q: queue.Queue = queue.Queue(maxsize=1)
         results, skipped = {}, []
 
+        stop = threading.Event()  # this run is over (consumer gone); `self._cancel` is the caller's request
+
+        def halted():
+            return self._cancel.is_set() or stop.is_set()
+
+        def put(item) -> bool:
+            # never block forever on the depth-1 queue: give up as soon as the consumer has gone away
+            while not halted():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def producer():
             for idx, task in mine:
-                if self._cancel.is_set():
+                if halted():
                     break
                 try:
                     payload = prepare(task)
                 except Exception:  # noqa: BLE001 -- same "skip the frame" rule as upstream
                     payload = None
-                while not self._cancel.is_set():
-                    try:
-                        q.put((idx, task, payload), timeout=0.1)
-                        break
-                    except queue.Full:
-                        continue
-            q.put((None, None, None))
+                if not put((idx, task, payload)):
+                    break
+            put((None, None, None))
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
-        while not self._cancel.is_set():
-            idx, task, payload = q.get()
-            if idx is None:
-                break
-            if payload is None:
-                skipped.append(idx)
-                continue
-            results[idx] = execute(task, payload)
-            if progress is not None:
-                progress(idx, len(mine))
-        th.join(timeout=1.0)
+        try:
+            while not self._cancel.is_set():
+                try:
+                    idx, task, payload = q.get(timeout=0.1)
+                except queue.Empty:
+                    if not th.is_alive() and q.empty():
+                        break
+                    continue
+                if idx is None:
+                    break
+                if payload is None:
+                    skipped.append(idx)
+                    continue
+                results[idx] = execute(task, payload)
+                if progress is not None:
+                    progress(idx, len(mine))
+        finally:
+            # whatever ended the loop (cancel, the sentinel, an exception out of execute): stop the producer and drop what
+            # it still holds, so it neither decodes the rest of the batch nor sits on a ~400 MB payload
+            stop.set()
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            th.join(timeout=5.0)
         return results, skipped

@@ -64,8 +64,8 @@ def test_fft_form_matches_oracle_and_direct_form(ctx, shape, window):
     assert [c["window"] for c in ctx.stencil_stats(0)] == [window, window, None]
     b = run(ctx, 0, img, k, 0)
     ref = st.convolve_2d(img, k)
-    assert_close(a, ref, 2e-6, 1e-2, "fft form")  # fp64 inside: an order of magnitude tighter than the fp32 direct sum needs
-    assert_close(b, ref, 1e-5, 1e-2, "direct form")
+    assert_close(a, ref, 2e-6, 1e-3, "fft form")  # fp64 inside: an order of magnitude tighter than the fp32 direct sum needs
+    assert_close(b, ref, 1e-5, 1e-3, "direct form")
     np.testing.assert_array_equal(a[..., 2], b[..., 2])  # the identity plane runs the direct kernel either way
 
 
@@ -77,7 +77,7 @@ def test_eligibility_limits(ctx):
         k /= k.sum()
         out = run(ctx, 1, img, k, 1)
         assert uses_fft(ctx, 1) == [expect] * 3, n
-        assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-2, f"{n} taps")
+        assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-3, f"{n} taps")
     # rectangular boxes count too
     k = np.zeros((87, 87, 1), np.float32)
     k[42:45, :, 0] = rng.uniform(0, 1, (3, 87))  # 3 x 87 = 261 taps: direct
@@ -86,7 +86,7 @@ def test_eligibility_limits(ctx):
     ctx.set_option("stencil_fft_min_taps", 200)
     out = run(ctx, 1, img, k / k.sum(), 1)
     assert uses_fft(ctx, 1) == [1, 1, 1]
-    assert_close(out, st.convolve_2d(img, np.repeat(k / k.sum(), 3, axis=2)), 1e-5, 1e-2, "3 x 87 by FFT")
+    assert_close(out, st.convolve_2d(img, np.repeat(k / k.sum(), 3, axis=2)), 1e-5, 1e-3, "3 x 87 by FFT")
 
 
 @pytest.mark.parametrize("box, window", [((201, 201), (512, 512)), ((301, 25), (512, None)), ((25, 301), (None, 512)),
@@ -105,7 +105,7 @@ def test_boxes_over_200_taps_take_the_512_point_window_on_that_axis(ctx, box, wi
     else:
         assert got["fft"] == 1
         assert got["window"] == tuple(w or 256 for w in window)
-    assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-2, f"{box} taps")
+    assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-3, f"{box} taps")
 
 
 @pytest.mark.parametrize("window", WINDOWS)
@@ -176,7 +176,7 @@ def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
         img = rng.uniform(0, 2, (H, W, 3)).astype(np.float32)
         out = run(ctx, 0, img, k, 1)
         assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [want(H, W)] * 2, (H, W)
-        assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-2, f"frame {H} x {W}")
+        assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-3, f"frame {H} x {W}")
     assert len(seen) >= 3, seen
     for name in ("stencil_fft_window", "stencil_fft_window_rows"):
         with pytest.raises(Exception):
@@ -190,6 +190,6 @@ def test_kernel_change_rebuilds_the_spectrum(ctx):
     k2 = ok.compute_halation_kernel(341.33, halation_green_factor=1.0, halation_intensity=2.0)
     a = run(ctx, 0, img, k1, 1)
     b = run(ctx, 0, img, k2, 1)
-    assert_close(a, st.convolve_2d(img, k1), 2e-6, 1e-2, "first kernel")
-    assert_close(b, st.convolve_2d(img, k2), 2e-6, 1e-2, "second kernel")
+    assert_close(a, st.convolve_2d(img, k1), 2e-6, 1e-3, "first kernel")
+    assert_close(b, st.convolve_2d(img, k2), 2e-6, 1e-3, "second kernel")
     np.testing.assert_array_equal(run(ctx, 0, img, k1, 1), a)

@@ -50,7 +50,7 @@ def test_windows_of_the_100mp_render_match_the_oracle(full, y0, x0):
     x = st.apply_grain(x, p.grain_lut, p.grain_kernel, p.seed, False, row0=ya, H_global=H_FULL, col0=xa, W_global=W_FULL)
     ref = st.apply_lut_tetrahedral(x, p.lut_3d, 0.25)[y0 - ya:y0 - ya + n, x0 - xa:x0 - xa + n]
     got = out[y0:y0 + n, x0:x0 + n].cpu().numpy()
-    err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 0.1))
+    err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3))
     assert err <= 1e-5, err
 
 
@@ -79,7 +79,7 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
         if fft:
             ref = out[a:b]
             diff = (part - ref).abs()
-            assert float((diff / ref.abs().clamp_min(0.1)).max()) <= 5e-7, (a, b)
+            assert float((diff / ref.abs().clamp_min(1e-3)).max()) <= 5e-7, (a, b)
             assert float((diff > 0).float().mean()) <= 1e-3, (a, b)
         else:
             assert torch.equal(part, out[a:b]), (a, b)
@@ -100,7 +100,7 @@ def test_the_100mp_render_does_not_depend_on_the_fft_window_shape(full, rows, co
         assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(rows, cols)] * 2
         assert [c["window"] for c in ctx.stencil_stats(1)] == [(rows, cols)] * 3
         diff = (other - out).abs()
-        assert float((diff / out.abs().clamp_min(0.1)).max()) <= 5e-7
+        assert float((diff / out.abs().clamp_min(1e-3)).max()) <= 5e-7
         assert float((diff > 0).float().mean()) <= 1e-3
     finally:
         ctx.set_option("stencil_fft_window_rows", 0)
@@ -188,7 +188,86 @@ def test_bw_stock_with_unsharp_mask_and_mono_grain_at_full_size():
         x = st.apply_grain(x, p.grain_lut, p.grain_kernel, p.seed, True, row0=ya, H_global=H_FULL, col0=xa, W_global=W_FULL)
         ref = st.apply_lut_tetrahedral(x, p.lut_3d, 0.25)[halo:halo + n, halo:halo + n]
         got = out[y0:y0 + n, x0:x0 + n].cpu().numpy()
-        err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 0.1))
+        err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3))
         assert err <= 1e-5, err
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------- the other BASELINE shapes
+def _oracle_window(frame, p, H, W, y0, x0, n, halo, *, mono=False):
+    """The oracle on window + halo of a device frame (hash at global coordinates); returns the n x n window."""
+    ya, yb = max(y0 - halo, 0), min(y0 + n + halo, H)
+    xa, xb = max(x0 - halo, 0), min(x0 + n + halo, W)
+    crop = frame[ya:yb, xa:xb].cpu().numpy()
+    x = st.apply_2d_lut(st.apply_matrix3x3(crop, p.matrix), p.lut_2d)
+    if p.halation_kernel is not None:
+        x = st.halation(x, p.halation_kernel)
+    x = st.multi_channel_interp(st.log_clip(x), p.lut_1d)
+    if p.mtf_kernel is not None:
+        x = st.film_sharpness(x, p.mtf_kernel)
+    if p.grain_lut is not None:
+        x = st.apply_grain(x, p.grain_lut, p.grain_kernel, p.seed, mono, row0=ya, H_global=H, col0=xa, W_global=W)
+    return st.apply_lut_tetrahedral(x, p.lut_3d, 0.25)[y0 - ya:y0 - ya + n, x0 - xa:x0 - xa + n]
+
+
+def _check_windows(out, u8, frame, p, H, W, spots, n, halo):
+    bad = total = 0
+    for y0, x0 in spots:
+        ref = _oracle_window(frame, p, H, W, y0, x0, n, halo)
+        got = out[y0:y0 + n, x0:x0 + n].cpu().numpy()
+        err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3))
+        assert err <= 1e-5, (y0, x0, err)
+        d = np.abs(u8[y0:y0 + n, x0:x0 + n].cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
+        assert d.max() <= 1, (y0, x0)
+        bad += int((d > 0).sum())
+        total += d.size
+    assert bad / total <= 1e-4, (bad, total)
+
+
+def test_cfg2_24mp_lut_only_windows_match_the_oracle():
+    """BASELINE config 2 at its full size: 6000 x 4000, negative + print LUTs, effects off (one fused pointwise kernel)."""
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame_device
+    from test_gpu_parity import setup_ctx
+
+    W, H = 6000, 4000
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, W / 36.0, halation=False, mtf=False, grain=0)
+    ctx = HipContext(0)
+    try:
+        params = setup_ctx(ctx, p)
+        frame = synthetic_frame_device(H, W, seed=17)
+        out, u8 = ctx.render(frame, params, want_f32=True, want_u8=True)
+        _check_windows(out, u8, frame, p, H, W, [(0, 0), (1999, 2873), (H - 256, W - 256), (77, W - 300)], 256, 0)
+    finally:
+        ctx.close()
+
+
+def test_cfg3_45mp_full_pipeline_windows_match_the_oracle():
+    """BASELINE config 3 at its full size: 8256 x 5504, 59 / 23 / 7-tap stencils (halation by FFT, MTF in the unrolled direct
+    form), grain on."""
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame_device
+    from test_gpu_parity import setup_ctx
+
+    W, H = 8256, 5504
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, W / 36.0, seed=SEED)
+    ctx = HipContext(0)
+    try:
+        params = setup_ctx(ctx, p)
+        frame = synthetic_frame_device(H, W, seed=19)
+        out, u8 = ctx.render(frame, params, want_f32=True, want_u8=True)
+        halo = p.halation_kernel.shape[0] // 2 + p.mtf_kernel.shape[0] // 2 + p.grain_kernel.shape[0] // 2
+        _check_windows(out, u8, frame, p, H, W, [(0, 0), (2750, 4100), (H - 128, W - 128), (200, W - 250), (H - 140, 3)], 128, halo)
+    finally:
+        ctx.close()
+
+
+def test_cfg4_100mp_uint8_windows_match_the_oracle(full):
+    """The uint8 output of the 100 MP render (what export writes): <= 1 LSB on <= 1e-4 of the samples of the windows."""
+    ctx, params, p, frame, out = full
+    _, u8 = ctx.render(frame, params, want_f32=False, want_u8=True)
+    halo = 42 + 17 + 4
+    _check_windows(out, u8, frame, p, H_FULL, W_FULL, [(0, 0), (4000, 6000), (H_FULL - 96, W_FULL - 96)], 96, halo)

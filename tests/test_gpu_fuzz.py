@@ -77,5 +77,5 @@ def test_random_configuration(ctx, c):
         t, layout = ctx.chroma_nr(t, c["nr"], layout=layout), "chw"
     out, u8 = ctx.render(t, params, want_f32=True, want_u8=True, layout=layout)
     # chroma NR divides by the (blurred) y chromaticity: a 2e-6 difference there is amplified in X and Z
-    assert_close(out.cpu().numpy(), ref, 3e-5 if c["nr"] else 1e-5, 1e-1, str(c))
+    assert_close(out.cpu().numpy(), ref, 3e-5 if c["nr"] else 1e-5, 1e-3, str(c))
     assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1

@@ -6,6 +6,9 @@ Tolerances (north_star: 1e-5 relative fp32 per channel; hash bit-identical):
     turning an absolute 1e-7 rounding difference into a meaningless relative one);
   * PCG3D hash:      bit-exact uint32;
   * uint8 output:    <= 1 LSB on <= 1e-4 of the samples (truncation at fp32 rounding boundaries).
+The floor is the contract's 1e-3 for every density and display value; linear exposure (before the
+log) uses 1e-4.  Measured worst case of the whole path at that floor: 2.6e-6 (tools/parity_budget.py,
+profiles/r02_parity_budget.txt).
 """
 
 import numpy as np
@@ -83,12 +86,12 @@ def test_front_stages_and_layouts(ctx, layout, shape):
     assert_close(from_planes(E), p.stages["exposure"], 1e-5, 1e-4, "exposure")
     D = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
     ctx.stage_front(t, params, 1, dst=D)
-    assert_close(from_planes(D), p.stages["density"], 1e-5, 1e-1, "density")
+    assert_close(from_planes(D), p.stages["density"], 1e-5, 1e-3, "density")
     out, u8 = ctx.render(t, params, want_f32=True, want_u8=True)
-    assert_close(out.cpu().numpy(), ref_out, 1e-5, 1e-1, "output")
+    assert_close(out.cpu().numpy(), ref_out, 1e-5, 1e-3, "output")
     ref_u8 = st.to_uint8(ref_out)
     diff = np.abs(u8.cpu().numpy().astype(int) - ref_u8.astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4
 
 
 def test_tetrahedral_against_reference_golden_vectors(ctx, golden_dir):
@@ -117,7 +120,7 @@ def test_trilinear_mode(ctx):
     ref = st.render(img, p)
     params = setup_ctx(ctx, p)
     out, _ = ctx.render(dev(img), params)
-    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "trilinear output")
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, "trilinear output")
 
 
 # ------------------------------------------------------------------------------- stencils
@@ -165,7 +168,7 @@ def test_stencil_non_square_and_even_sizes(ctx):
     for i in range(6):
         for j in range(9):
             ref += k[i, j, 0] * pad[i:i + 40, j:j + 72]
-    assert_close(from_planes(dst), ref, 1e-5, 1e-2, "non-square stencil")
+    assert_close(from_planes(dst), ref, 1e-5, 1e-3, "non-square stencil")
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -221,21 +224,27 @@ def test_mirror_symmetric_fast_path(ctx):
         ctx.set_option("stencil_sym", 1)
         return from_planes(dst)
 
-    for k in (ok.compute_halation_kernel(341.33, halation_green_factor=0.3),   # r = 42 (even)
-              ok.compute_halation_kernel(229.33, halation_green_factor=0.3),   # r = 28
-              ok.compute_halation_kernel(60.0),                                 # r = 7 (odd -> padded)
-              ok.mtf_kernel(stocks()[0].mtf, 341.33), ok.mtf_kernel(stocks()[0].mtf, 229.33, 0.7, 1.0)):
-        a, b = run(k, 1), run(k, 0)
-        ref = st.convolve_2d(img, k)
-        assert_close(a, ref, 1e-5, 1e-2, "sym path")
-        assert_close(b, ref, 1e-5, 1e-2, "plain path")
-        assert np.abs(a - b).max() <= 2e-6
-        assert not np.array_equal(a, b), "the symmetric path was not taken"
-    k = ok.compute_halation_kernel(229.33, halation_green_factor=0.3).copy()
-    k[3, 20, 0] = np.nextafter(k[3, 20, 0], np.float32(1))  # break the symmetry of the red plane by one ulp
-    np.testing.assert_array_equal(run(k, 1)[..., 0], run(k, 0)[..., 0])
-    ctx.set_option("stencil_fft", 1)
-    ctx.set_option("stencil_fixed", 1)
+    try:
+        for k in (ok.compute_halation_kernel(341.33, halation_green_factor=0.3),   # r = 42 (even)
+                  ok.compute_halation_kernel(229.33, halation_green_factor=0.3),   # r = 28
+                  ok.compute_halation_kernel(60.0),                                 # r = 7 (odd -> padded)
+                  ok.mtf_kernel(stocks()[0].mtf, 341.33), ok.mtf_kernel(stocks()[0].mtf, 229.33, 0.7, 1.0)):
+            a, b = run(k, 1), run(k, 0)
+            ref = st.convolve_2d(img, k)
+            # The contract floor (1e-3) for non-negative taps.  The unsharp-masked MTF kernel has negative taps: an fp32
+            # direct sum is accurate relative to sum |w x|, not to the cancelled result, hence the 1e-2 floor for the
+            # DIRECT form of that kernel (forced here; the render path runs it as an fp64 FFT, tests/test_gpu_fft.py).
+            floor = 1e-3 if (k >= 0).all() else 1e-2
+            assert_close(a, ref, 1e-5, floor, "sym path")
+            assert_close(b, ref, 1e-5, floor, "plain path")
+            assert np.abs(a - b).max() <= 2e-6
+            assert not np.array_equal(a, b), "the symmetric path was not taken"
+        k = ok.compute_halation_kernel(229.33, halation_green_factor=0.3).copy()
+        k[3, 20, 0] = np.nextafter(k[3, 20, 0], np.float32(1))  # break the symmetry of the red plane by one ulp
+        np.testing.assert_array_equal(run(k, 1)[..., 0], run(k, 0)[..., 0])
+    finally:
+        ctx.set_option("stencil_fft", 1)
+        ctx.set_option("stencil_fixed", 1)
 
 
 @pytest.mark.parametrize("n", [3, 5, 9, 13, 15, 17, 21, 23, 25])
@@ -282,12 +291,12 @@ def test_small_square_stencils_unrolled_direct_form(ctx, n, epilogue):
 
     a, a_whole, fft = run(1)
     assert fft == ([1, 1, 1] if n == 25 else [0, 0, 0])
-    assert_close(a, ref, 1e-5, 1e-2, f"{n} x {n} unrolled")
+    assert_close(a, ref, 1e-5, 1e-3, f"{n} x {n} unrolled")
     if n <= 23:
         np.testing.assert_array_equal(a, a_whole)  # direct forms: bit for bit whatever the row range
     b, _, fft_b = run(0)
     assert fft_b == ([1, 1, 1] if n >= 21 else [0, 0, 0])  # without the unrolled form the FFT threshold is 400 taps
-    assert_close(b, ref, 1e-5, 1e-2, f"{n} x {n} entry list / FFT")
+    assert_close(b, ref, 1e-5, 1e-3, f"{n} x {n} entry list / FFT")
     ctx.set_option("stencil_fixed", 1)
 
 
@@ -302,7 +311,7 @@ def test_halation_stage(ctx, scale):
     E = to_planes(p.stages["exposure"])
     D = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
     ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H)
-    assert_close(from_planes(D), p.stages["density"], 1e-5, 1e-1, "halation+curve")
+    assert_close(from_planes(D), p.stages["density"], 1e-5, 1e-3, "halation+curve")
 
 
 def test_halation_bw_stock(ctx):
@@ -313,7 +322,7 @@ def test_halation_bw_stock(ctx):
     ref = st.render(img, p)
     params = setup_ctx(ctx, p)
     out, _ = ctx.render(dev(img), params)
-    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "bw halation output")
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, "bw halation output")
 
 
 @pytest.mark.parametrize("strength", [0.0, 0.7])
@@ -328,7 +337,7 @@ def test_mtf_stage(ctx, strength):
     D = to_planes(p.stages["density"])
     D2 = torch.empty_like(D)
     ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H)
-    assert_close(from_planes(D2), p.stages["mtf"], 1e-5, 1e-1, "mtf")
+    assert_close(from_planes(D2), p.stages["mtf"], 1e-5, 1e-3, "mtf")
 
 
 # ------------------------------------------------------------------------------- grain
@@ -366,7 +375,7 @@ def test_tail_grain(ctx, grain, grain_size):
     params = setup_ctx(ctx, p)
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     ctx.stage_tail(to_planes(p.stages["density"]), params, out_f32=out, y0=0, y1=H, H_global=H)
-    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "grain tail")
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, "grain tail")
 
 
 # ------------------------------------------------------------------------------- whole path
@@ -379,10 +388,10 @@ def test_full_pipeline(ctx, shape, scale):
     ref = st.render(img, p)
     params = setup_ctx(ctx, p)
     out, u8 = ctx.render(dev(img), params, want_f32=True, want_u8=True)
-    e = assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "full pipeline")
+    e = assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, "full pipeline")
     print(f"full pipeline {shape} scale {scale}: max err {e:.2e}")
     diff = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4
 
 
 def test_row_shards_match_whole_frame_bitwise(ctx):
@@ -440,7 +449,7 @@ def test_tiny_and_ragged_frames_full_pipeline(ctx, shape):
     ref = st.render(img, p)
     params = setup_ctx(ctx, p)
     out, u8 = ctx.render(dev(img), params, want_f32=True, want_u8=True)
-    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, f"tiny frame {shape}")
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, f"tiny frame {shape}")
     assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1
 
 
@@ -450,12 +459,12 @@ def test_black_frame_and_speculars(ctx):
     params = setup_ctx(ctx, p)
     black = np.zeros((40, 56, 3), np.float32)  # S < 1e-12 everywhere: exposure 0, log clipped at 1e-6
     out, _ = ctx.render(dev(black), params)
-    assert_close(out.cpu().numpy(), st.render(black, p), 1e-5, 1e-1, "black frame")
+    assert_close(out.cpu().numpy(), st.render(black, p), 1e-5, 1e-3, "black frame")
     hot = synthetic_frame(64, 96, seed=61)
     hot[10, 20] = 65504.0  # the largest value the decode path lets through (gpu_processor.py:275)
     hot[40:43, 60:63] = 4000.0
     out, _ = ctx.render(dev(hot), params)
-    assert_close(out.cpu().numpy(), st.render(hot, p), 1e-5, 1e-1, "speculars")
+    assert_close(out.cpu().numpy(), st.render(hot, p), 1e-5, 1e-3, "speculars")
 
 
 def test_empty_row_range_is_a_no_op_and_empty_frame_is_an_error(ctx):
@@ -481,7 +490,7 @@ def test_uint8_only_output(ctx):
     f32, u8 = ctx.render(dev(img), params, want_f32=False, want_u8=True)
     assert f32 is None and u8.dtype == torch.uint8
     d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(st.render(img, p)).astype(int))
-    assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-4
 
 
 # ------------------------------------------------------------------------------- S7 highlight burn
@@ -518,7 +527,7 @@ def test_burn_upsample_edges_like_scipy_zoom(ctx, shape):
     params.flags |= 32
     params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 20.0)[0], 0.5, float(neg.d_ref[1])
     out, _ = ctx.render(dev(img), params)
-    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, f"burn edges {shape}")
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, f"burn edges {shape}")
 
 
 @pytest.mark.parametrize("grain", [2, 0])
@@ -535,7 +544,7 @@ def test_full_pipeline_with_highlight_burn(ctx, grain):
     params.flags |= 32
     params.burn_cell, params.burn_strength, params.burn_d_ref = st.burn_geometry(H, W, 50.0)[0], 0.7, float(neg.d_ref[1])
     out, _ = ctx.render(dev(img), params)
-    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-1, "pipeline with burn")
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, "pipeline with burn")
 
 
 # ------------------------------------------------------------------------------- pre-path chroma NR
@@ -616,7 +625,7 @@ def test_grain_field_split_equals_the_fused_tail_bit_for_bit(ctx):
             ctx.stage_tail_field(D, Fp, params, field_gy0=y0, out_f32=part, out_gy0=y0, y0=y0, y1=y1, H_global=H)
             assert torch.equal(part, fused[y0:y1])
         ref = st.apply_lut_tetrahedral(st.apply_grain(dens, p.grain_lut, p.grain_kernel, p.seed, grain == 1), p.lut_3d, 0.25)
-        assert_close(split.cpu().numpy(), ref, 1e-5, 1e-1, "split tail vs oracle")
+        assert_close(split.cpu().numpy(), ref, 1e-5, 1e-3, "split tail vs oracle")
 
 
 @pytest.mark.parametrize("n", [3, 5, 7, 9, 11, 13, 15, 19, 21])

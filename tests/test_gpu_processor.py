@@ -27,7 +27,7 @@ def _xyz(H, W, seed=41):
 
 def _u8_close(a, b):
     d = np.abs(a.astype(int) - b.astype(int))
-    return d.max() <= 1 and (d > 0).mean() <= 2e-3
+    return d.max() <= 1 and (d > 0).mean() <= 1e-4
 
 
 def test_process_returns_uint8_like_the_cpu_processor(proc):

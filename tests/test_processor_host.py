@@ -238,3 +238,15 @@ def test_bundle_roundtrip(tmp_path):
     np.testing.assert_array_equal(b.get_input_lut(6500, 0, 0), neg.get_input_lut())
     np.testing.assert_array_equal(filmstock.create_lut(b, None), filmstock.create_lut(neg, prt))
     assert len(b.mtf) == 3 and b.rms_density is not None and b.name == "portra-bundle"
+
+
+def test_lens_correction_is_refused_only_when_the_reference_would_correct(proc):
+    """effects.lens_correction (effects.py:22-30) does something only with a camera AND a lens; cpu_processor.py:107-108 drops
+    both when lens_correction is False.  That one case is outside the accelerated path and must not render silently."""
+    frame = np.full((40, 60, 3), 0.2, np.float32)
+    ok = HipProcessor.extract_image_data_cpu(proc, frame, cam=None, lens=None, lens_correction=True)  # the GUI default
+    assert ok["image_array"].shape == (40, 60, 4)
+    HipProcessor.extract_image_data_cpu(proc, frame, cam="cam", lens=None, lens_correction=True)
+    HipProcessor.extract_image_data_cpu(proc, frame, cam="cam", lens="lens", lens_correction=False)
+    with pytest.raises(NotImplementedError, match="lens correction"):
+        HipProcessor.extract_image_data_cpu(proc, frame, cam="cam", lens="lens", lens_correction=True)

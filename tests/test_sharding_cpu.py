@@ -232,3 +232,45 @@ def test_batch_sharder_cancel():
 
     bs.run(list(range(100)), lambda t: t, execute)
     assert 2 <= len(done) < 100
+
+
+def test_batch_sharder_stops_its_producer_when_execute_raises_or_the_run_is_cancelled():
+    """The producer thread must not outlive run(): neither blocked on the depth-1 queue with a payload in its hands, nor
+    decoding the rest of the batch."""
+    import threading
+    import time
+
+    before = threading.active_count()
+    prepared = []
+
+    def prepare(t):
+        prepared.append(t)
+        return bytearray(1024)
+
+    def execute(t, payload):
+        if t == 3:
+            raise RuntimeError("device phase failed")
+        return t
+
+    bs = sharding.BatchSharder(0, 1)
+    with pytest.raises(RuntimeError, match="device phase failed"):
+        bs.run(list(range(1000)), prepare, execute)
+    time.sleep(0.3)
+    assert threading.active_count() == before  # producer gone
+    assert len(prepared) < 20  # it did not go on decoding the batch
+    # the object is still usable: an exception ends that run, it is not a cancel request
+    results, skipped = bs.run([10, 11], lambda t: t, lambda t, p: p)
+    assert results == {0: 10, 1: 11} and skipped == []
+
+    bs = sharding.BatchSharder(0, 1)
+    n = []
+
+    def slow_execute(t, payload):
+        n.append(t)
+        if len(n) == 2:
+            bs.cancel()
+        return t
+
+    bs.run(list(range(1000)), prepare, slow_execute)
+    time.sleep(0.3)
+    assert threading.active_count() == before

@@ -1,0 +1,85 @@
+"""Error budget of the HIP path against the oracle at the SURVEY 8(d) contract:
+|hip - oracle| <= 1e-5 * max(|oracle|, 1e-3); uint8 <= 1 LSB on <= 1e-4 of the samples.
+
+Prints, per shape / scale: the chained error of every stage boundary, the isolated error of every stage (fed with
+the oracle's own stage input), the fraction of samples over the bar and the uint8 mismatch rate.  Development aid;
+run on the GPU box:  python tools/parity_budget.py [--big]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import oracle_inputs, stocks, synthetic_frame  # noqa: E402
+from oracle import stages as st  # noqa: E402
+from raw2film_amd.context import HipContext  # noqa: E402
+from test_gpu_parity import dev, from_planes, setup_ctx, to_planes  # noqa: E402
+
+FLOOR, TOL = 1e-3, 1e-5
+
+
+def stats(a, b, floor=FLOOR):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    e = np.abs(a - b) / np.maximum(np.abs(b), floor)
+    ulp = np.abs(a - b) / np.spacing(np.abs(b).astype(np.float32)).astype(np.float64)
+    return f"rel max {e.max():.2e} p99.99 {np.quantile(e, 0.9999):.2e} over-bar {float((e > TOL).mean()):.1e} | ulp max {ulp.max():.1f} rms {np.sqrt((ulp ** 2).mean()):.2f}"
+
+
+def run(ctx, H, W, scale, seed=21, **kw):
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, scale, **kw)
+    img = synthetic_frame(H, W, seed=seed)
+    ref = st.render(img, p, keep_stages=True)
+    S = p.stages
+    params = setup_ctx(ctx, p)
+    print(f"=== {H}x{W} scale {scale} {kw}  stages {list(S)}")
+    t = dev(img)
+    E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_front(t, params, 0, dst=E)
+    print("front -> exposure            ", stats(from_planes(E), S["exposure"], 1e-4))
+    D = torch.empty_like(E)
+    cur = E
+    if p.halation_kernel is not None:
+        ctx.stage_halation(to_planes(S["exposure"]), D, params, y0=0, y1=H, H_global=H)
+        print("halation+log+curve isolated  ", stats(from_planes(D), S["density"]))
+        ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H)
+    else:
+        ctx.stage_front(t, params, 1, dst=D)
+    print("density chained              ", stats(from_planes(D), S["density"]))
+    cur = D
+    if p.mtf_kernel is not None:
+        D2 = torch.empty_like(E)
+        ctx.stage_mtf(to_planes(S["density"]), D2, params, y0=0, y1=H, H_global=H)
+        print("mtf isolated                 ", stats(from_planes(D2), S["mtf"]))
+        ctx.stage_mtf(D, D2, params, y0=0, y1=H, H_global=H)
+        print("mtf chained                  ", stats(from_planes(D2), S["mtf"]))
+        cur = D2
+    last = "mtf" if p.mtf_kernel is not None else "density"
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    ctx.stage_tail(to_planes(S[last]), params, out_f32=out, y0=0, y1=H, H_global=H)
+    print("tail isolated                ", stats(out.cpu().numpy(), ref))
+    if "grain" in S:
+        pass
+    ctx.stage_tail(cur, params, out_f32=out, y0=0, y1=H, H_global=H)
+    print("output chained (stage calls) ", stats(out.cpu().numpy(), ref))
+    o, u8 = ctx.render(t, params, want_f32=True, want_u8=True)
+    print("output r2f_render            ", stats(o.cpu().numpy(), ref))
+    d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
+    print(f"uint8: max diff {d.max()}  mismatch rate {float((d > 0).mean()):.2e}  ({int((d > 0).sum())} of {d.size})")
+    print(f"oracle output range [{ref.min():.4g}, {ref.max():.4g}]")
+
+
+if __name__ == "__main__":
+    ctx = HipContext(0)
+    run(ctx, 160, 240, 166.67, halation=False, mtf=False, grain=0)
+    run(ctx, 160, 240, 166.67)
+    run(ctx, 131, 203, 341.33)
+    run(ctx, 256, 384, 229.33)
+    if "--big" in sys.argv:
+        run(ctx, 1024, 1536, 341.33, seed=5)
+        run(ctx, 1024, 1536, 166.67, seed=6, halation=False, mtf=False, grain=0)
