@@ -80,6 +80,10 @@ struct r2f_ctx {
     hipEvent_t fft_ev_in = nullptr, fft_ev_out[4] = {nullptr, nullptr, nullptr, nullptr};
     int opt_fft_streams = 2;
     int opt_fft_batch = 192;     // window pairs per launch triple: 192 MB of scratch stay inside the 256 MB Infinity Cache
+    // bit `which`: that stencil's FFT scratch images hold complex64 instead of complex128 elements (r2f_fft.hip, sld / sst).
+    // Default: the MTF only -- it acts on density, whose values are bounded, so two fp32 roundings of the spectrum cost ~1e-7
+    // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
+    int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     int lanczos_key[4] = {0, 0, 0, 0};
     int opt_xcd_band = 0;  // tile columns per band of the xcd_remap = 2 order; 0 = auto
@@ -587,7 +591,7 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
 // the GLOBAL frame, so every row shard of a frame (and every call on it) uses the same shape and the kernel spectra are
 // built once.  stencil_fft_window / stencil_fft_window_rows force an axis (ignored for a box over 200 taps on that axis,
 // which needs the 512-point window).
-void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, int* ny, int* nx) {
+void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int* ny, int* nx) {
     double best = -1.0;
     for (int y = 256; y <= 512; y *= 2) {
         if (bh > 200 ? y != 512 : (ctx->opt_fft_window_rows && y != ctx->opt_fft_window_rows)) continue;
@@ -598,7 +602,8 @@ void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, int* ny, int* 
             // per window: pass 1 (floats in, image out), pass 2 (image in, valid rows out), pass 3 (valid rows in, floats out);
             // two windows share one complex image.  The 512-row pass 2 moves its bytes ~1.3 x slower (r2f_fft.hip).
             const double p2 = y == 512 ? 1.3 : 1.0;
-            const double bytes = 4.0 * n + 8.0 * n + p2 * (8.0 * n + 8.0 * part) + 8.0 * part + 4.0 * vy * vx;
+            const double e = s32 ? 4.0 : 8.0;  // scratch bytes per window element (half a complex64 / complex128)
+            const double bytes = 4.0 * n + e * n + p2 * (e * n + e * part) + e * part + 4.0 * vy * vx;
             const double cost = (double)((W + vx - 1) / vx) * ((H + vy - 1) / vy) * bytes;
             if (best < 0.0 || cost < best) best = cost, *ny = y, *nx = x;
         }
@@ -614,7 +619,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     tap_box(set, chans[0], b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
     int ny = 256, nx = 256;
-    fft_window(ctx, bh, bw, W, H, &ny, &nx);
+    fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, &ny, &nx);
     const size_t img = (size_t)ny * nx;
     if (!ctx->fft_tw.p) {
         // W_256^k, k < 256, then W_512^k, k < 256
@@ -653,6 +658,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         FftConvArgs k = a;
         k.src.data = static_cast<float*>(ctx->fft_kimg.p);
         k.raw = 1;
+        k.s32 = 0;  // spectra are always built and kept in complex128
         k.nch = 1, k.chan[0] = 0, k.ppc = 1;
         k.ntiles = 1, k.gx = 1, k.npairs = 1, k.pair0 = 0;
         k.s1 = static_cast<double2*>(ctx->fft_s1.p);
@@ -677,13 +683,15 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.curve = ctx->curve;
     a.log_eps = log_eps;
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
+    a.s32 = (ctx->opt_fft_s32 >> which) & 1;
+    const size_t img_bytes = img * (a.s32 ? sizeof(float2) : sizeof(double2));
     const int pairs = a.ppc * nch;
     // batches alternate between two internal streams when there is enough work for that to matter
-    // opt_fft_batch counts 256 x 256 pairs (1 MB of scratch each); larger windows take proportionally fewer per launch
-    const int fft_batch = std::max(1, (int)((size_t)ctx->opt_fft_batch * kFftN * kFftN / img));
+    // opt_fft_batch counts MiB of scratch in flight (a 256 x 256 complex128 pair is 1 MiB)
+    const int fft_batch = std::max(1, (int)((size_t)ctx->opt_fft_batch * kFftN * kFftN * sizeof(double2) / img_bytes));
     const int nstreams = pairs > fft_batch ? ctx->opt_fft_streams : 1;
     const int batch = std::min(pairs, std::max(1, fft_batch / nstreams));
-    rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img * sizeof(double2));
+    rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img_bytes);
     if (rc) return rc;
     hipStream_t lanes[4] = {s, s, s, s};
     if (nstreams > 1) {
@@ -717,10 +725,10 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         hipStream_t st = lanes[li];
         a.pair0 = p0;
         a.npairs = std::min(batch, pairs - p0);
-        a.s1 = static_cast<double2*>(ctx->fft_s1.p) + (size_t)li * batch * img;
+        a.s1 = reinterpret_cast<double2*>(static_cast<char*>(ctx->fft_s1.p) + (size_t)li * batch * img_bytes);
         // algorithmic bytes of the passes: window floats in (2 per pair) + scratch image out; scratch in + valid rows out;
         // valid rows in + valid outputs out.  The kernel spectrum (1 MB) stays in L2.
-        const double np = a.npairs, full = (double)img * sizeof(double2), part = full * a.vy / ny;
+        const double np = a.npairs, full = (double)img_bytes, part = full * a.vy / ny;
         rc = timed(0, np * (2.0 * img * sizeof(float) + full), st, [&] { return launch_fft_rows_fwd(a, st); });
         if (rc) return rc;
         rc = timed(1, np * (full + part), st, [&] { return launch_fft_cols(a, 0, st); });
@@ -954,6 +962,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_scratch32")) {
+        if (value < 0 || value > 7) return fail(ctx, R2F_EINVAL, "stencil_fft_scratch32 is a mask over the three stencils (0..7)");
+        ctx->opt_fft_s32 = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_batch")) {

@@ -257,6 +257,32 @@ __device__ __forceinline__ const cplx& at(const cplx* base, unsigned idx) {
     return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + (idx << 4));
 }
 
+// Scratch images come in two element types.  S32 = false: complex128, what the halation needs (linear exposure: a shadow
+// pixel shares its window with speculars 10^4 times brighter, and a rounding to fp32 is relative to the WINDOW's energy).
+// S32 = true: complex64 -- only the two roundings between the passes are fp32, every butterfly stays fp64 -- for stencils on
+// DENSITY (the MTF): values in [0, 4], so those roundings cost ~1e-7 absolute (under one fp32 ulp of a density >= 1; measured
+// in tests/test_gpu_fft.py) and the three passes move half the bytes.
+template <bool S32>
+__device__ __forceinline__ cplx sld(const void* base, unsigned idx) {
+    if (S32) {
+        const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + (idx << 3));
+        return make_double2((double)v.x, (double)v.y);
+    }
+    return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + (idx << 4));
+}
+template <bool S32>
+__device__ __forceinline__ void sst(void* base, unsigned idx, const cplx v) {
+    if (S32)
+        *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + (idx << 3)) = make_float2((float)v.x, (float)v.y);
+    else
+        *reinterpret_cast<cplx*>(reinterpret_cast<char*>(base) + (idx << 4)) = v;
+}
+// scratch image of pair `pair` (n elements each)
+template <bool S32>
+__device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) {
+    return reinterpret_cast<char*>(s1) + pair * n * (S32 ? 8 : 16);
+}
+
 // ---------------------------------------------------------------------------------------------------- pass 1
 // grid (ny / rows per workgroup, pairs).  X512 = false: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
 // X512 = true: 32 lanes per (512-point) row, 8 rows per workgroup, 2 per wave.
@@ -273,7 +299,7 @@ struct RowGeom {
     }
 };
 
-template <bool X512>
+template <bool X512, bool S32>
 __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* fsm) {
     typedef RowGeom<X512> G;
     constexpr int NX = G::NX, LPL = G::LPL;
@@ -337,36 +363,33 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
         else
             fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
     }
-    cplx* s1 = a.s1 + (long long)pair * a.ny * NX;
+    char* s1 = simg<S32>(a.s1, pair, (long long)a.ny * NX);
     if (R2F_FFT_EXP & 2) {
-        if (v[3].x == 1.2345e300) s1[0] = v[5];  // keep the transform alive without storing
+        if (v[3].x == 1.2345e300) sst<S32>(s1, 0, v[5]);  // keep the transform alive without storing
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) at(s1, sidx(r, G::out_col(l, q), G::NBX)) = v[q];
+    for (int q = 0; q < 16; ++q) sst<S32>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
 }
 
+template <bool X512, bool S32>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_fwd_body<false>(a, fsm);
-}
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_x512_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_fwd_body<true>(a, fsm);
+    fft_rows_fwd_body<X512, S32>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
 // grid (nx / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.  NBX = nx / 16.
 // mode 0: forward along r, multiply by the kernel spectrum, inverse, store back
 // mode 1: forward only; the conjugate IS the kernel spectrum (input = the padded kernel image)
-template <int NBX>
+template <int NBX, bool S32>
 __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
-    cplx* s1 = a.s1 + (long long)pair * kN * (NBX * 16);
+    char* s1 = simg<S32>(a.s1, pair, (long long)kN * (NBX * 16));
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = at(s1, sidx(l + 16 * m, k, NBX));
+    for (int m = 0; m < 16; ++m) v[m] = sld<S32>(s1, sidx(l + 16 * m, k, NBX));
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
@@ -381,7 +404,7 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
     fft256<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 16 * q < a.vy) at(s1, sidx(l + 16 * q, k, NBX)) = v[q];  // pass 3 never reads the rows past the valid outputs
+        if (l + 16 * q < a.vy) sst<S32>(s1, sidx(l + 16 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
 }
 
 // 512-row windows: 32 lanes per column, 8 columns per workgroup, 2 per wave; forward by fft512, back by fft512_rev.
@@ -389,14 +412,14 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
 // of the four interleaved columns of the scratch layout, i.e. 32-byte pieces: measured ~25 % slower per byte than the
 // 256-row pass (the host's window choice prices that in; tall kernels have no alternative).  (Pairs as the fast grid index,
 // to share spectrum blocks between the workgroups in flight, was slower for every shape: 7.04 -> 7.46 ms at 256 x 256.)
-template <int NBX>
+template <int NBX, bool S32>
 __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 31;
     const int pair = blockIdx.y, k = blockIdx.x * 8 + (threadIdx.x >> 5);
-    cplx* s1 = a.s1 + (long long)pair * 512 * (NBX * 16);
+    char* s1 = simg<S32>(a.s1, pair, (long long)512 * (NBX * 16));
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = at(s1, sidx(l + 32 * m, k, NBX));
+    for (int m = 0; m < 16; ++m) v[m] = sld<S32>(s1, sidx(l + 32 * m, k, NBX));
     const cplx w1 = a.tw512[l];
     double* tbuf = wave_tbuf(fsm);
     fft512<false>(v, w1, tbuf, lane);
@@ -412,28 +435,19 @@ __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const i
     fft512_rev<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 32 * q < a.vy) at(s1, sidx(l + 32 * q, k, NBX)) = v[q];  // pass 3 never reads the rows past the valid outputs
+        if (l + 32 * q < a.vy) sst<S32>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
 }
 
 #ifndef R2F_FFT_WPE2
 #define R2F_FFT_WPE2 2
 #endif
+template <int NBX, bool Y512, bool S32>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_kernel(const FftConvArgs a, const int mode) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_body<16>(a, mode, fsm);
-}
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_x512_kernel(const FftConvArgs a, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_body<32>(a, mode, fsm);
-}
-
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_y512_kernel(const FftConvArgs a, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_y512_body<16>(a, mode, fsm);
-}
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_y512_x512_kernel(const FftConvArgs a, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_y512_body<32>(a, mode, fsm);
+    if (Y512)
+        fft_cols_y512_body<NBX, S32>(a, mode, fsm);
+    else
+        fft_cols_body<NBX, S32>(a, mode, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -444,21 +458,21 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 #ifndef R2F_FFT_CURVE_BATCH
 #define R2F_FFT_CURVE_BATCH 16
 #endif
-template <bool X512, bool EPI>
+template <bool X512, bool EPI, bool S32>
 __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
     typedef RowGeom<X512> G;
     constexpr int NX = G::NX, LPL = G::LPL;
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
     const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
     const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const cplx* s1 = a.s1 + (long long)pair * a.ny * NX;
+    const char* s1 = simg<S32>(a.s1, pair, (long long)a.ny * NX);
     cplx v[16];
     if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
     } else {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = at(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
+        for (int m = 0; m < 16; ++m) v[m] = sld<S32>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
     }
     if (!(R2F_FFT_EXP3 & 4)) {
         if (X512)
@@ -523,10 +537,10 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #ifndef R2F_FFT_WPE3
 #define R2F_FFT_WPE3 2
 #endif
-template <bool X512, bool EPI>
+template <bool X512, bool EPI, bool S32>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (X512 ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_inv_body<X512, EPI>(a, fsm);
+    fft_rows_inv_body<X512, EPI, S32>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
@@ -535,27 +549,43 @@ static size_t fft_lds_bytes() { return (size_t)(kFftThreads / 64) * 4 * kTLine *
 hipError_t fft_init_attributes() { return hipSuccess; }
 
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
-    if (a.nx == 512)
-        hipLaunchKernelGGL(fft_rows_fwd_x512_kernel, dim3(a.ny / RowGeom<true>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
-    else
-        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(a.ny / RowGeom<false>::ROWS, a.npairs), dim3(kFftThreads), fft_lds_bytes(), s, a);
+    const dim3 block(kFftThreads);
+    if (a.nx == 512) {
+        const dim3 grid(a.ny / RowGeom<true>::ROWS, a.npairs);
+        if (a.s32)
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, true>), grid, block, fft_lds_bytes(), s, a);
+        else
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, false>), grid, block, fft_lds_bytes(), s, a);
+    } else {
+        const dim3 grid(a.ny / RowGeom<false>::ROWS, a.npairs);
+        if (a.s32)
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, true>), grid, block, fft_lds_bytes(), s, a);
+        else
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, false>), grid, block, fft_lds_bytes(), s, a);
+    }
     return hipGetLastError();
 }
 
+template <int NBX, bool Y512>
+static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
+    const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
+    if (a.s32)
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, true>), grid, block, fft_lds_bytes(), s, a, mode);
+    else
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, false>), grid, block, fft_lds_bytes(), s, a, mode);
+}
+
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    const dim3 block(kFftThreads);
     if (a.ny == 512) {
-        const dim3 grid(a.nx / 8, a.npairs);
         if (a.nx == 512)
-            hipLaunchKernelGGL(fft_cols_y512_x512_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+            launch_cols<32, true>(a, mode, s);
         else
-            hipLaunchKernelGGL(fft_cols_y512_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+            launch_cols<16, true>(a, mode, s);
     } else {
-        const dim3 grid(a.nx / 16, a.npairs);
         if (a.nx == 512)
-            hipLaunchKernelGGL(fft_cols_x512_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+            launch_cols<32, false>(a, mode, s);
         else
-            hipLaunchKernelGGL(fft_cols_kernel, grid, block, fft_lds_bytes(), s, a, mode);
+            launch_cols<16, false>(a, mode, s);
     }
     return hipGetLastError();
 }
@@ -564,10 +594,17 @@ template <bool X512>
 static void launch_rows_inv(const FftConvArgs& a, hipStream_t s) {
     const int rows = RowGeom<X512>::ROWS;
     const dim3 grid((a.vy + rows - 1) / rows, a.npairs);  // rows beyond the valid outputs are never stored
-    if (a.epilogue == 1)
-        hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-    else
-        hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+    if (a.epilogue == 1) {
+        if (a.s32)
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, true>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        else
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, false>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+    } else {
+        if (a.s32)
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, true>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        else
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, false>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+    }
 }
 
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s) {

@@ -193,3 +193,29 @@ def test_kernel_change_rebuilds_the_spectrum(ctx):
     assert_close(a, st.convolve_2d(img, k1), 2e-6, 1e-3, "first kernel")
     assert_close(b, st.convolve_2d(img, k2), 2e-6, 1e-3, "second kernel")
     np.testing.assert_array_equal(run(ctx, 0, img, k1, 1), a)
+
+
+@pytest.mark.parametrize("window", WINDOWS)
+def test_complex64_scratch_of_the_mtf_passes(ctx, window):
+    """The MTF's FFT passes keep their scratch images in complex64 by default (stencil_fft_scratch32 bit 1; butterflies stay
+    fp64): on density-like input (values in [0, 4]) the two fp32 roundings of the spectrum are worth <= 3 ulp of the result,
+    which stays inside the contract (1e-5 relative at the 1e-3 floor) with a wide margin; the halation never takes that form
+    (bit 0 is off: linear exposure with speculars needs complex128)."""
+    force_window(ctx, window)
+    rng = np.random.default_rng(5)
+    H, W = 300, 700
+    img = rng.uniform(0.2, 3.5, (H, W, 3)).astype(np.float32)  # densities
+    k = ok.mtf_kernel(stocks()[0].mtf, 341.33)  # 35 x 35 x 3
+    ref = st.convolve_2d(img, k)
+    exact = run(ctx, 1, img, k, 1, stencil_fft_scratch32=0)
+    assert uses_fft(ctx, 1) == [1, 1, 1]
+    c64 = run(ctx, 1, img, k, 1, stencil_fft_scratch32=2)
+    assert_close(exact, ref, 2e-7, 1e-3, "complex128 scratch")  # one rounding to fp32
+    assert_close(c64, ref, 1e-6, 1e-3, "complex64 scratch")
+    ulps = np.abs(c64.astype(np.float64) - ref) / np.spacing(np.abs(ref))
+    assert ulps.max() <= 3 and not np.array_equal(c64, exact)
+    # the halation (which = 0) ignores bit 1 and stays exact with a specular in the window
+    img[100, 300] = 30000.0
+    kh = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)
+    hal = run(ctx, 0, img, kh, 1, stencil_fft_scratch32=2)
+    assert_close(hal, st.convolve_2d(img, kh), 2e-6, 1e-3, "halation keeps complex128")

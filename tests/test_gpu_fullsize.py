@@ -90,19 +90,28 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
 @pytest.mark.parametrize("rows, cols", [(256, 256), (512, 256), (512, 512)])
 def test_the_100mp_render_does_not_depend_on_the_fft_window_shape(full, rows, cols):
     """The fixture rendered with the window shape the cost model picks (256 x 512 here); any other shape tiles the frame
-    differently but computes the same correlation: the results agree to an fp32 ulp on a handful of pixels."""
+    differently but computes the same correlation.  With complex128 scratch everywhere the results agree to an fp32 ulp on a
+    handful of pixels; with the default complex64 scratch of the MTF passes (two fp32 roundings of the spectrum, whose values
+    depend on the window) they agree to the 2 ulp of density those roundings are worth."""
     ctx, params, p, frame, out = full
     assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(256, 512)] * 2
-    ctx.set_option("stencil_fft_window_rows", rows)
-    ctx.set_option("stencil_fft_window", cols)
     try:
-        other, _ = ctx.render(frame, params)
-        assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(rows, cols)] * 2
-        assert [c["window"] for c in ctx.stencil_stats(1)] == [(rows, cols)] * 3
-        diff = (other - out).abs()
-        assert float((diff / out.abs().clamp_min(1e-3)).max()) <= 5e-7
-        assert float((diff > 0).float().mean()) <= 1e-3
+        for s32, tol, frac in ((0, 5e-7, 1e-3), (2, 4e-6, 1.0)):
+            ctx.set_option("stencil_fft_scratch32", s32)
+            ctx.set_option("stencil_fft_window_rows", 0)
+            ctx.set_option("stencil_fft_window", 0)
+            base, _ = ctx.render(frame, params)
+            ctx.set_option("stencil_fft_window_rows", rows)
+            ctx.set_option("stencil_fft_window", cols)
+            other, _ = ctx.render(frame, params)
+            assert [c["window"] for c in ctx.stencil_stats(0)][:2] == [(rows, cols)] * 2
+            assert [c["window"] for c in ctx.stencil_stats(1)] == [(rows, cols)] * 3
+            diff = (other - base).abs()
+            assert float((diff / base.abs().clamp_min(1e-3)).max()) <= tol, s32
+            assert float((diff > 0).float().mean()) <= frac, s32
+            del base, other, diff
     finally:
+        ctx.set_option("stencil_fft_scratch32", 2)
         ctx.set_option("stencil_fft_window_rows", 0)
         ctx.set_option("stencil_fft_window", 0)
         ctx.render(frame, params)  # spectra back to the default shape for the tests that follow

@@ -438,6 +438,61 @@ def test_errors_are_reported(ctx):
     c.close()
 
 
+def test_stencil_stages_refuse_overlapping_planes(ctx):
+    """The stencil stages are out of place (include/r2f.h): a destination that shares bytes with the source is an error, not a
+    race; the pointwise grain stage may run exactly in place."""
+    neg, prt, _ = stocks()
+    H, W = 64, 96
+    p = oracle_inputs(neg, prt, 200.0)
+    params = setup_ctx(ctx, p)
+    buf = torch.rand((4, H, W), dtype=torch.float32, device="cuda") + 0.1
+    D = buf[:3]
+    for call in (lambda: ctx.stage_mtf(D, D, params, y0=0, y1=H, H_global=H),
+                 lambda: ctx.stage_halation(D, D, params, y0=0, y1=H, H_global=H),
+                 lambda: ctx.stage_stencil(1, D, buf[1:4], y0=0, y1=H, H_global=H)):  # shifted by one plane: still overlaps
+        with pytest.raises(ValueError, match="overlap"):
+            call()
+    before = D.clone()
+    separate = torch.empty_like(before)
+    ctx.stage_grain(before, separate, params, y0=0, y1=H, H_global=H)
+    ctx.stage_grain(D, D, params, y0=0, y1=H, H_global=H)  # exactly in place: allowed, same result
+    assert torch.equal(D, separate)
+
+
+def test_two_contexts_in_one_process_leave_the_current_device_alone():
+    """Every C-ABI entry binds its context's device for the call and restores the caller's: contexts can be
+    interleaved from one thread.  On a one-GPU box both sit on device 0; with more GPUs the second one gets device 1 and the
+    current device is switched between the calls."""
+    from raw2film_amd.context import HipContext
+
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 200.0)
+    img = synthetic_frame(72, 100, seed=77)
+    ref = st.render(img, p)
+    n = torch.cuda.device_count()
+    devs = (0, 1 if n > 1 else 0)
+    ctxs = [HipContext(d) for d in devs]
+    try:
+        assert torch.cuda.current_device() == 0  # r2f_create did not move it
+        prm = [setup_ctx(c, p) for c in ctxs]
+        outs = []
+        for k, (c, q, d) in enumerate(zip(ctxs, prm, devs)):
+            torch.cuda.set_device(devs[1 - k])  # the OTHER context's device is current while this one renders
+            with torch.cuda.device(d):
+                t = torch.from_numpy(img).to(f"cuda:{d}")
+            o, _ = c.render(t, q)
+            assert torch.cuda.current_device() == devs[1 - k]
+            outs.append(o.cpu().numpy())
+        torch.cuda.set_device(0)
+        for o in outs:
+            assert_close(o, ref, 1e-5, 1e-3, "two contexts")
+        np.testing.assert_array_equal(outs[0], outs[1])
+    finally:
+        torch.cuda.set_device(0)
+        for c in ctxs:
+            c.close()
+
+
 # ------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 7), (9, 129), (130, 5)])
 def test_tiny_and_ragged_frames_full_pipeline(ctx, shape):
