@@ -353,7 +353,8 @@ class HipContext:
         for c in range(3):
             d = dict(zip(keys, out[8 * c:8 * c + 7]))
             word = out[8 * c + 7]
-            d["unrolled"] = d["sym"] >> 1  # R of the fully unrolled (2 R + 1)^2 direct form, 0: the entry list
+            d["unrolled"] = (d["sym"] >> 1) & 0x7F  # R of the fully unrolled (2 R + 1)^2 direct form, 0: the entry list
+            d["separable"] = (d["sym"] >> 8) & 1  # grain stencil only: two 1-D passes of 2 R + 1 taps
             d["sym"] &= 1
             d["fft"] = word & 1
             d["window"] = ((word >> 1) // 1024, (word >> 1) % 1024) if word >> 1 else None

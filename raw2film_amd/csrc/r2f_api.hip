@@ -96,6 +96,10 @@ struct r2f_ctx {
     bool grain_fixed_valid = false;
     int grain_fixed_r = 0, grain_fixed_same = 0;
     int opt_grain_fixed = 1;  // 0: always the generic entry list (A/B)
+    // the grain stencil as two 1-D passes when every channel is u v^T to fp32 rounding (ensure_grain_fixed)
+    bool grain_sep = false;
+    float grain_sep_u[3][19] = {}, grain_sep_v[3][10] = {};
+    int opt_grain_sep = 1;    // 0: never take the separable form (A/B)
     DeviceBuf stencil_fixed_w[3];  // the same for the direct stencil kernel (stencil_fixed<R, 4>), per stencil
     bool stencil_fixed_valid[3] = {false, false, false};
     int opt_stencil_fixed = 1;
@@ -945,6 +949,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         ctx->opt_grain_fixed = value ? 1 : 0;
         return R2F_OK;
     }
+    if (!strcmp(name, "grain_separable")) {
+        ctx->opt_grain_sep = value ? 1 : 0;
+        return R2F_OK;
+    }
     if (!strcmp(name, "front_blocks_per_cu")) {
         if (value < 1 || value > 64) return fail(ctx, R2F_EINVAL, "front_blocks_per_cu must be in [1, 64]");
         ctx->opt_front_blocks = value;
@@ -1167,7 +1175,9 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
         const int all[3] = {0, 1, 2};
         const int fr = which == R2F_KERNEL_GRAIN ? (ctx->opt_grain_fixed ? fixed_stencil_radius(set, all, 3, 9) : 0)
                                                  : (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 ? fixed_stencil_radius(set, &c, 1, kFixedMaxR) : 0);
-        o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym | (fr << 1);
+        // bit 8: the grain stencil runs as two 1-D passes (known once a tail launch has looked at the taps)
+        const int sep = which == R2F_KERNEL_GRAIN && fr && ctx->grain_fixed_valid && ctx->grain_sep && ctx->opt_grain_sep;
+        o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym | (fr << 1) | (sep << 8);
         o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q;
         o[7] = fft_eligible(ctx, set, c) ? 1 | ((ctx->fft_kf_valid[which][c] ? ctx->fft_kf_dims[which][c] : 0) << 1) : 0;
     }
@@ -1191,10 +1201,44 @@ static int ensure_grain_fixed(r2f_ctx* ctx) {
     ctx->grain_fixed_valid = true;
     const int chans[3] = {0, 1, 2};
     ctx->grain_fixed_r = fixed_stencil_radius(set, chans, 3, 9);
+    ctx->grain_sep = false;
     if (!ctx->grain_fixed_r) return R2F_OK;
     bool same = false;
     const std::vector<float> w = fixed_stencil_weights(set, ctx->grain_fixed_r, kTailQ, &same);
     ctx->grain_fixed_same = same ? 1 : 0;
+    // Separable?  K[i][j] = u[i] v[j] with u = the centre column and v = the centre row / K[R][R]: accepted when the rank-1
+    // form reproduces every tap to 6e-7 of the largest one (u_i v_j rebuilt from fp32 taps carries ~5 roundings of 6e-8), so
+    // the field differs from the full stencil's by < 1e-6 -- far inside the 4e-6 the hardware transcendentals of the noise
+    // are worth -- and 2 (2 R + 1) taps per pixel replace (2 R + 1)^2.
+    {
+        const int R = ctx->grain_fixed_r, n = 2 * R + 1;
+        bool sep = true;
+        for (int c = 0; c < 3 && sep; ++c) {
+            int b[4];
+            tap_box(set, c, b);
+            const int kc = set.kc == 1 ? 0 : c;
+            auto K = [&](int i, int j) { return (double)set.host[((size_t)(b[0] + i) * set.kw + b[2] + j) * set.kc + kc]; };
+            const double centre = K(R, R);
+            double kmax = 0.0;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) kmax = std::max(kmax, std::fabs(K(i, j)));
+            if (!(centre > 0.0) || centre < 0.25 * kmax) {  // a rank-1 form anchored on a small centre tap is ill-conditioned
+                sep = false;
+                break;
+            }
+            for (int i = 0; i < n; ++i) ctx->grain_sep_u[c][i] = (float)K(i, R);
+            for (int j = 0; j <= R; ++j) ctx->grain_sep_v[c][j] = (float)(K(R, j) / centre);
+            for (int i = 0; i < n && sep; ++i)
+                for (int j = 0; j < n; ++j) {
+                    const double v = (double)ctx->grain_sep_v[c][j <= R ? j : 2 * R - j];
+                    if (std::fabs((double)ctx->grain_sep_u[c][i] * v - K(i, j)) > 6e-7 * kmax) {
+                        sep = false;
+                        break;
+                    }
+                }
+        }
+        ctx->grain_sep = sep;
+    }
     return upload(ctx, ctx->grain_fixed_w, w.data(), w.size() * sizeof(float));
 }
 
@@ -1287,6 +1331,10 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         a.fixed_r = ctx->opt_grain_fixed ? ctx->grain_fixed_r : 0;
         a.fixed_same = ctx->grain_fixed_same;
         a.fixed_w = static_cast<const float*>(ctx->grain_fixed_w.p);
+        // (monochrome noise with per-channel taps: the one noise plane cannot be filtered in place three ways -> 2-D form)
+        a.sep = (a.fixed_r && ctx->opt_grain_sep && ctx->grain_sep && (!a.mono || ctx->grain_fixed_same)) ? 1 : 0;
+        memcpy(a.sep_u, ctx->grain_sep_u, sizeof a.sep_u);
+        memcpy(a.sep_v, ctx->grain_sep_v, sizeof a.sep_v);
         if (tail_lds_bytes(a.gk, a.mono) > kMaxLds)
             return fail(ctx, R2F_ETOOLARGE, "grain stencil %dx%d does not fit the LDS noise tile", a.gk[0].kh, a.gk[0].kw);
         a.grain_lut = ctx->grain_lut;

@@ -16,6 +16,10 @@
 
 #include "../../include/r2f.h"
 
+#ifndef R2F_CURVE_BATCH3
+#define R2F_CURVE_BATCH3 1  // A/B switch: a pixel's three curve evaluations as one batch (see front_kernel)
+#endif
+
 namespace r2f {
 
 const StencilVariant kStencilVariants[kNumStencilVariants] = {
@@ -188,7 +192,16 @@ __global__ __launch_bounds__(64 * kFrontBY) void front_kernel(const FrontArgs a)
             if (a.use_matrix) apply_matrix(a.mat, r[q], g[q], b[q]);
             apply_lut2d(a.lut2d, r[q], g[q], b[q]);
             if (a.upto >= R2F_UPTO_DENSITY) {
-                if (LDSC) {
+                if (R2F_CURVE_BATCH3) {
+                    // the pixel's three evaluations together: three gathers in flight, and the corrective gathers only if some
+                    // lane of the wave sits on a breakpoint (curve_eval_batch)
+                    float v3[3] = {log10_fast(r[q], a.log_eps), log10_fast(g[q], a.log_eps), log10_fast(b[q], a.log_eps)};
+                    if (LDSC)
+                        curve_eval_batch<3, 3>((const float4*)cells_lds, a.curve, 0, v3);
+                    else
+                        curve_eval_batch<3, 3>(a.curve.cells, a.curve, 0, v3);
+                    r[q] = v3[0], g[q] = v3[1], b[q] = v3[2];
+                } else if (LDSC) {
                     r[q] = curve_eval_at(cells_lds, a.curve, 0, log10_fast(r[q], a.log_eps));
                     g[q] = curve_eval_at(cells_lds, a.curve, 1, log10_fast(g[q], a.log_eps));
                     b[q] = curve_eval_at(cells_lds, a.curve, 2, log10_fast(b[q], a.log_eps));
@@ -436,7 +449,10 @@ __global__ __launch_bounds__(256) void single_tap_kernel(const TapArgs a) {
 // FR > 0: the fully unrolled (2 FR + 1)^2 grain stencil (stencil_fixed: square mirror-symmetric kernels up to 19 x 19);
 // FR = 0: the generic entry list, every tap column of every entry (run-time masks, i.e. branches, cost more than the
 // padding columns they skip in a stencil of two entries per row step).
-template <int FR>
+// SEP (with FR = R > 0): every channel's grain stencil is separable, K = u v^T to fp32 rounding (checked on the host; any
+// Gaussian-like kernel is): the noise planes are filtered along x IN PLACE (every thread first reads the inputs of its row
+// segments, barrier, then stores), then along y out of LDS -- 2 (2 R + 1) taps per pixel instead of (2 R + 1)^2.
+template <int FR, bool SEP = false>
 __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = kTailBX * kTailBY, TW = 4 * kTailBX, TH = kTailQ * kTailBY, Q = kTailQ;
@@ -453,20 +469,33 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
     // S6a: hash noise for the tile + halo, straight into LDS.  Coordinates are clamped to the
     // frame like the shader's texture reads (grain.wgsl:63-75); the hash sees GLOBAL coordinates.
     // (row, column) of element idx advance with it: one division per thread, not one per element
-    const int step_r = NT / RS, step_c = NT - step_r * RS;
-    int r = (int)threadIdx.x / RS, c = (int)threadIdx.x - r * RS;
-    for (int idx = threadIdx.x; idx < ((R2F_TAIL_EXP & 1) ? 0 : rows * RS); idx += NT, r += step_r, c += step_c) {
-        if (c >= RS) c -= RS, ++r;
-        float nr = 0.f, ng = 0.f, nb = 0.f;
-        if (c < cols_valid) {
-            const int sx = clampi(tile_x0 - g0.ax + c, 0, a.W - 1);
-            const int sy = clampi(tile_y0 - g0.ay + r, 0, a.H_global - 1);
-            gaussian_noise((uint32_t)sx, (uint32_t)sy, a.seed, mono, nr, ng, nb);
-        }
-        smem[idx] = nr;
+    // Only the cols_valid columns that taps can reach are hashed (the padding columns up to RS are zeroed below): every lane
+    // of a wave then does a hash, instead of the lanes that fall on padding idling through it.
+    const int step_r = NT / cols_valid, step_c = NT - step_r * cols_valid;
+    int r = (int)threadIdx.x / cols_valid, c = (int)threadIdx.x - r * cols_valid;
+    for (int idx = threadIdx.x; idx < ((R2F_TAIL_EXP & 1) ? 0 : rows * cols_valid); idx += NT, r += step_r, c += step_c) {
+        if (c >= cols_valid) c -= cols_valid, ++r;
+        float nr, ng, nb;
+        const int sx = clampi(tile_x0 - g0.ax + c, 0, a.W - 1);
+        const int sy = clampi(tile_y0 - g0.ay + r, 0, a.H_global - 1);
+        gaussian_noise((uint32_t)sx, (uint32_t)sy, a.seed, mono, nr, ng, nb);
+        const int at = r * RS + c;
+        smem[at] = nr;
         if (!mono) {
-            smem[plane_sz + idx] = ng;
-            smem[2 * plane_sz + idx] = nb;
+            smem[plane_sz + at] = ng;
+            smem[2 * plane_sz + at] = nb;
+        }
+    }
+    {
+        const int padc = RS - cols_valid;  // < 16
+        for (int idx = threadIdx.x; idx < rows * padc; idx += NT) {
+            const int rr = idx / padc, at = rr * RS + cols_valid + (idx - rr * padc);
+            smem[at] = 0.f;
+            if (!mono) smem[plane_sz + at] = 0.f, smem[2 * plane_sz + at] = 0.f;
+        }
+        if (threadIdx.x < 16) {  // the slack past the last row (prefetch target of the generic entry list)
+            smem[rows * RS + threadIdx.x] = 0.f;
+            if (!mono) smem[plane_sz + rows * RS + threadIdx.x] = 0.f, smem[2 * plane_sz + rows * RS + threadIdx.x] = 0.f;
         }
     }
     // the grain LUT's cells next to the noise planes: 24 gathers per lane hit LDS instead of the vector L1
@@ -478,8 +507,81 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
 
     const int tx = threadIdx.x % kTailBX, ty = threadIdx.x / kTailBX;
     float2v G[3][Q / 2][4];
+    if (SEP && FR > 0) {
+        // ---- pass along x, in place.  LDS column of image column tile_x0 + x is x + AX; segment s = 4 output columns
+        // 4 s .. 4 s + 3 of one row of one plane; its result goes to columns 4 s .. of that row (16-byte aligned).
+        constexpr int R = FR > 0 ? FR : 1, AX = fixed_stencil_ax(R), O = AX - R, NB = (O + 2 * R + 4 + 3) / 4;
+        constexpr int SEGS = TW / 4, PER = (TH + 2 * R) * SEGS, MAXI = (PER + NT - 1) / NT;
+        float4v held[3][MAXI];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+        for (int pl = 0; pl < 3; ++pl) {
+            if (pl > 0 && mono) break;
+            const float* wv = a.sep_v[pl];  // compile-time plane index: the taps stay in SGPRs
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int rem = (int)threadIdx.x + NT * i;
+                held[pl][i] = (float4v){0.f, 0.f, 0.f, 0.f};
+                if (rem < PER) {
+                    const int rr = rem / SEGS, sg = rem - rr * SEGS;
+                    const float* src = smem + pl * plane_sz + rr * RS + 4 * sg;
+                    float x[4 * NB];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float4v v = *reinterpret_cast<const float4v*>(src + 4 * b);
+                        x[4 * b] = v.x, x[4 * b + 1] = v.y, x[4 * b + 2] = v.z, x[4 * b + 3] = v.w;
+                    }
+                    float o[4];
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {  // mirrored taps summed first (v is symmetric), outer taps to the centre
+                        float acc = wv[0] * (x[O + pp] + x[O + pp + 2 * R]);
+#pragma unroll
+                        for (int j = 1; j < R; ++j) acc = fmaf(wv[j], x[O + pp + j] + x[O + pp + 2 * R - j], acc);
+                        o[pp] = fmaf(wv[R], x[O + pp + R], acc);
+                    }
+                    held[pl][i] = (float4v){o[0], o[1], o[2], o[3]};
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            if (pl > 0 && mono) break;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int rem = (int)threadIdx.x + NT * i;
+                if (rem < PER) {
+                    const int rr = rem / SEGS, sg = rem - rr * SEGS;
+                    *reinterpret_cast<float4v*>(smem + pl * plane_sz + rr * RS + 4 * sg) = held[pl][i];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- pass along y: output row y of the tile reads rows y .. y + 2 R of the filtered plane
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0 && mono && a.fixed_same) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) G[c][0][p] = G[0][0][p];
+                continue;
+            }
+            const float* plane = smem + (mono ? 0 : c * plane_sz) + ty * Q * RS + 4 * tx;
+            const float* wu = a.sep_u[c];
+            static_assert(Q == 2, "the separable grain pass packs the lane's two output rows");
+#pragma unroll
+            for (int p = 0; p < 4; ++p) G[c][0][p] = (float2v){0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2 * R + Q; ++i) {
+                const float4v h = *reinterpret_cast<const float4v*>(plane + i * RS);
+                const float2v w = {i <= 2 * R ? wu[i] : 0.f, i >= 1 ? wu[i - 1] : 0.f};  // (row 0's tap, row 1's tap)
+                G[c][0][0] = __builtin_elementwise_fma(w, (float2v){h.x, h.x}, G[c][0][0]);
+                G[c][0][1] = __builtin_elementwise_fma(w, (float2v){h.y, h.y}, G[c][0][1]);
+                G[c][0][2] = __builtin_elementwise_fma(w, (float2v){h.z, h.z}, G[c][0][2]);
+                G[c][0][3] = __builtin_elementwise_fma(w, (float2v){h.w, h.w}, G[c][0][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < ((SEP && FR > 0) ? 0 : 3); ++c) {
 #pragma unroll
         for (int j = 0; j < Q / 2; ++j)
 #pragma unroll
@@ -524,7 +626,14 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
         for (int p = 0; p < 4; ++p) {
             // S6c grain.wgsl:78-89 + clip cpu_processor.py:397
             float ar, ag, ab;
-            if (a.cells_in_lds) {
+            if (R2F_CURVE_BATCH3) {
+                float v3[3] = {r[p], g[p], b[p]};
+                if (a.cells_in_lds)
+                    curve_eval_batch<3, 3>((const float4*)cells_lds, a.grain_lut, 0, v3);
+                else
+                    curve_eval_batch<3, 3>(gcells, a.grain_lut, 0, v3);
+                ar = v3[0], ag = v3[1], ab = v3[2];
+            } else if (a.cells_in_lds) {
                 ar = curve_eval_at((const float4*)cells_lds, a.grain_lut, 0, r[p]);
                 ag = curve_eval_at((const float4*)cells_lds, a.grain_lut, 1, g[p]);
                 ab = curve_eval_at((const float4*)cells_lds, a.grain_lut, 2, b[p]);
@@ -977,6 +1086,15 @@ hipError_t init_kernel_attributes() {
     R2F_SET_LDS((tail_kernel<7>))
     R2F_SET_LDS((tail_kernel<8>))
     R2F_SET_LDS((tail_kernel<9>))
+    R2F_SET_LDS((tail_kernel<1, true>))
+    R2F_SET_LDS((tail_kernel<2, true>))
+    R2F_SET_LDS((tail_kernel<3, true>))
+    R2F_SET_LDS((tail_kernel<4, true>))
+    R2F_SET_LDS((tail_kernel<5, true>))
+    R2F_SET_LDS((tail_kernel<6, true>))
+    R2F_SET_LDS((tail_kernel<7, true>))
+    R2F_SET_LDS((tail_kernel<8, true>))
+    R2F_SET_LDS((tail_kernel<9, true>))
     R2F_SET_LDS(front_kernel<true>)
 #undef R2F_SET_LDS
     return hipSuccess;
@@ -1075,10 +1193,13 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
     b.cells_off = (int)tail_plane_floats(a.gk, a.mono);
     b.cells_in_lds = tail_lds_bytes(a.gk, a.mono, 1, a.grain_lut.m) <= 80 * 1024 ? 1 : 0;  // keep two workgroups per CU
     const size_t lds = tail_lds_bytes(a.gk, a.mono, b.cells_in_lds, a.grain_lut.m);
-    switch (a.fixed_r) {  // small square mirror-symmetric stencils take the unrolled form
-#define R2F_TAIL_FIXED(R)                                              \
-    case R:                                                           \
-        hipLaunchKernelGGL((tail_kernel<R>), grid, block, lds, s, b); \
+    switch (a.fixed_r) {  // small square mirror-symmetric stencils take the unrolled form, separable ones two 1-D passes
+#define R2F_TAIL_FIXED(R)                                                        \
+    case R:                                                                     \
+        if (a.sep)                                                              \
+            hipLaunchKernelGGL((tail_kernel<R, true>), grid, block, lds, s, b); \
+        else                                                                    \
+            hipLaunchKernelGGL((tail_kernel<R>), grid, block, lds, s, b);       \
         break;
         R2F_TAIL_FIXED(1)
         R2F_TAIL_FIXED(2)

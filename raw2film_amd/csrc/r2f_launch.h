@@ -98,6 +98,10 @@ struct TailArgs {
     // fixed_w: 3 channels x (2 R + 2) x (R + 1) weight pairs; fixed_same: the three channels share their taps
     int fixed_r, fixed_same;
     const float* fixed_w;
+    // sep = 1 (with fixed_r = R): every channel's stencil is u v^T to fp32 rounding, v mirror symmetric: two 1-D passes.
+    // sep_u[c][i], i <= 2 R: taps along y; sep_v[c][j], j <= R: the left half of the taps along x
+    int sep;
+    float sep_u[3][19], sep_v[3][10];
 };
 
 constexpr int kChromaMaxTaps = 63;

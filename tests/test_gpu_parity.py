@@ -721,3 +721,60 @@ def test_small_square_grain_stencils_unrolled_form_against_the_oracle_and_the_en
         np.testing.assert_array_equal(from_planes(whole), fields[fixed])  # bit for bit whatever the row range
     ctx.set_option("grain_fixed", 1)
     assert np.abs(fields[1] - fields[0]).max() <= 1e-6 * np.abs(ref).max()  # two summation orders of the same 2-D sum
+
+
+@pytest.mark.parametrize("n", [3, 5, 9, 13, 19])
+@pytest.mark.parametrize("mono, per_channel", [(False, True), (False, False), (True, False), (True, True)])
+def test_separable_grain_stencils_run_as_two_1d_passes(ctx, n, mono, per_channel):
+    """A grain stencil that is u v^T to fp32 rounding (any Gaussian-like kernel: the stand-in of filmstock.grain_kernel, per
+    channel or shared) runs as two 1-D passes; the field agrees with the 2-D sum of the same fp32 taps to rounding, is bit for
+    bit independent of the row range, and a stencil that is NOT rank one (one tap off by 1e-5) keeps the 2-D form."""
+    H, W = 150, 203
+    r = n // 2
+    ax = np.arange(-r, r + 1)
+    sig = np.array([0.35 * r + 0.3, 0.3 * r + 0.4, 0.4 * r + 0.35])
+    k = np.exp(-(ax[:, None, None] ** 2 + ax[None, :, None] ** 2) / (2.0 * sig[None, None, :] ** 2))
+    k = (k / np.sqrt((k ** 2).sum(axis=(0, 1), keepdims=True))).astype(np.float32)
+    if not per_channel:
+        k = np.repeat(k[..., :1], 3, axis=2)
+    # monochrome noise with per-channel taps keeps the 2-D form (one noise plane cannot be filtered in place three ways)
+    two_pass = not (mono and per_channel)
+    ctx.set_grain_lut(stocks()[0].get_grain_curve(341.33, adx=False, bw_grain=False))
+    params = ctx.make_params(seed=99, grain=True, grain_mono=mono)
+    noise = st.gaussian_noise(np.arange(W)[None, :], np.arange(H)[:, None], 99, mono)
+    padded = np.pad(noise, ((r, r), (r, r), (0, 0)), mode="edge").astype(np.float64)
+
+    def field(kk, y_ranges=((0, H),)):
+        ctx.set_kernel(2, kk)
+        F = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        for y0, y1 in y_ranges:
+            ctx.stage_grain_field(F, params, dst_gy0=0, y0=y0, y1=y1, H_global=H)
+        return from_planes(F)
+
+    ref = np.zeros((H, W, 3))
+    for c in range(3):
+        for i in range(n):
+            for j in range(n):
+                ref[..., c] += float(k[i, j, c]) * padded[i:i + H, j:j + W, c]
+    sep = field(k)
+    assert [c["separable"] for c in ctx.stencil_stats(2)] == [1, 1, 1]
+    assert np.abs(sep - ref).max() <= 5e-6 * np.abs(ref).max()
+    np.testing.assert_array_equal(field(k, ((0, 37), (37, 38), (38, H))), sep)
+    ctx.set_option("grain_separable", 0)
+    try:
+        full2d = field(k)
+        assert [c["separable"] for c in ctx.stencil_stats(2)] == [0, 0, 0]
+    finally:
+        ctx.set_option("grain_separable", 1)
+    assert np.abs(sep - full2d).max() <= 2e-6 * np.abs(ref).max() and np.array_equal(sep, full2d) != two_pass
+    if n >= 5:
+        bad = k.copy()
+        bad[0, 1, :] *= np.float32(1.0 + 1e-3)
+        bad[0, n - 2, :] = bad[0, 1, :]  # still mirror symmetric, no longer rank one
+        got = field(bad)
+        assert [c["separable"] for c in ctx.stencil_stats(2)] == [0, 0, 0]
+        ref_bad = ref.copy()
+        for c in range(3):
+            for j in (1, n - 2):
+                ref_bad[..., c] += (float(bad[0, j, c]) - float(k[0, j, c])) * padded[0:H, j:j + W, c]
+        assert np.abs(got - ref_bad).max() <= 5e-6 * np.abs(ref).max()
