@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s of the full film pipeline (neg + print + grain + halation + MTF).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4_100mp|cfg3_45mp|cfg2_24mp]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4_100mp|cfg3_45mp|cfg2_24mp|cfg5_batch]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (S0..S8, float32 output) over one synthetic decoded frame
-that is already resident in HBM.  N = 1: the whole frame on one MI355X.  N > 1: the SAME frame,
-row-sharded over N GPUs with the two RCCL neighbour exchanges of raw2film_amd.sharding (strong
-scaling: total work fixed).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path (S0..S8, float32 output) over one synthetic decoded frame that is already
+resident in HBM.  N = 1: the whole frame on one MI355X.  N > 1: the SAME frame, row-sharded over N GPUs with the RCCL
+neighbour exchange of raw2film_amd.sharding (strong scaling: total work fixed).  Rank 0 prints ONE JSON line.
 
-Extra objects on that line (see DESIGN.md "Measurement"):
-  roofline      the dominant kernel (halation stencil), timed live with events on the launch
-                stream inside the timed steps; fp32 VALU bound.
-  roofline_hbm  whole-pipeline algorithmic bytes (12 B/px read + 12 B/px written) vs HBM peak.
-  cpu_baseline  the NumPy oracle ("port") timed on this box's host cores on a bounded sample
-                (rank 0, N = 1 only).
+Objects on that line besides the contract's keys:
+  roofline      SURVEY.md 8(d)'s definition: 24 algorithmic bytes per pixel (12 read + 12 written) x the frame, over the
+                step time, against the 8 TB/s HBM peak (`frac`); the 12 B/px read-only variant; `traffic` = the L2<->fabric
+                bytes of one step from the committed PMC capture of the SAME sources and configuration (null when the
+                capture does not match what is running; provenance beside it); `dominant_kernel` = the FFT pass with the
+                largest share of the step, timed live with HIP events on its launch streams; `fp64_valu` = the FFT
+                passes' fp64 work against the 78.6 TFLOP/s vector peak.
+  stage_ms      per-stage device time (events on the launch stream, inside the timed steps).
+  cpu_baseline  the NumPy oracle ("port") timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,9 +32,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak == fp32 (f32-input) MFMA dense peak
-HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (FMA = 2 flop): 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 GRAIN_SEED = 20260630
+BASELINE_METRIC = "megapixels/sec full film pipeline (neg+print+grain+halation+MTF), 100MP frame"
+METRICS = {
+    "cfg4_100mp": BASELINE_METRIC,
+    "cfg3_45mp": "megapixels/sec full film pipeline (neg+print+grain+halation+MTF), 45MP frame (BASELINE config 3)",
+    "cfg2_24mp": "megapixels/sec negative+print LUT pipeline, effects off, 24MP frame (BASELINE config 2)",
+    "cfg5_batch": "megapixels/sec full film pipeline, batch of 24MP frames, device-resident compute only "
+                  "(BASELINE config 5 without the host phase and the PCIe copies; see pcie_inclusive)",
+}
+
+
+def source_hash() -> str:
+    """sha256 over the HIP sources and the C header: ties a committed PMC capture to the code that was profiled."""
+    h = hashlib.sha256()
+    for rel in ("raw2film_amd/csrc/r2f_device.h", "raw2film_amd/csrc/r2f_launch.h", "raw2film_amd/csrc/r2f_kernels.hip",
+                "raw2film_amd/csrc/r2f_fft.hip", "raw2film_amd/csrc/r2f_api.hip", "include/r2f.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def fft_fp64_ops(ny: int, nx: int, vy: int):
+    """(flops, fp64 VALU lane-instructions) of the three FFT passes for ONE window pair, counted from r2f_fft.hip:
+    dft16 = 128 add + 9 complex multiplies (2 mul + 2 fma each); twiddle_powers = 29 complex multiplies; a 256-point line =
+    16 lanes x (2 dft16 + twiddles); a 512-point line = 32 lanes x (the same + the radix-2 step: 32 add, 15 multiplies on the
+    odd lanes); pass 2 adds one complex multiply per element (the kernel spectrum)."""
+    cm_f, cm_i = 6, 4                       # complex multiply: flops, instructions
+    d16_f, d16_i = 128 + 9 * cm_f, 128 + 9 * cm_i
+    tw_f, tw_i = 29 * cm_f, 29 * cm_i
+    lane256 = (2 * d16_f + tw_f, 2 * d16_i + tw_i)
+    lane512 = (lane256[0] + 32 + 7.5 * cm_f, lane256[1] + 32 + 7.5 * cm_i)
+
+    def line(n):
+        return (16 * lane256[0], 16 * lane256[1]) if n == 256 else (32 * lane512[0], 32 * lane512[1])
+
+    rx, cy = line(nx), line(ny)
+    mult = (ny * nx * cm_f, ny * nx * cm_i)
+    flops = ny * rx[0] + nx * 2 * cy[0] + mult[0] + vy * rx[0]
+    insts = ny * rx[1] + nx * 2 * cy[1] + mult[1] + vy * rx[1]
+    return flops, insts
 
 
 def main():
@@ -45,10 +87,12 @@ def main():
                     help="synthetic frame statistics: independent pixels (headline; worst case for the LUT gathers) or photograph-like")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone", action="store_true",
-                    help="skip the two extra steps that time the FFT column pass with one internal stream (tools/profile_round.sh: "
+                    help="skip the two extra steps that time the dominant FFT pass with one internal stream (tools/profile_round.sh: "
                          "keeps the profiled launches all of one size)")
+    ap.add_argument("--no-pcie", action="store_true", help="cfg5_batch: skip the PCIe-inclusive BatchSharder leg")
     ap.add_argument("--side-grain", action="store_true", help="A/B: make the grain field on a side stream while the stencils run")
     ap.add_argument("--direct-stencils", action="store_true", help="A/B: run the stencils in their direct fp32 form instead of fp64 FFTs")
+    ap.add_argument("--opt", action="append", default=[], help="A/B: r2f_set_option name=value (repeatable)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the measured configuration); gloo + --same-device validates the N > 1 code path on one GPU")
     ap.add_argument("--same-device", action="store_true", help="validation only: every rank uses cuda:0")
@@ -62,7 +106,7 @@ def main():
 
     from raw2film_amd import HipProcessor, filmstock, stencils
     from raw2film_amd.hip_processor import REC709_TO_XYZ
-    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+    from raw2film_amd.sharding import BatchSharder, HipStageBackend, RowShardedRenderer
     from raw2film_amd.synthetic import CONFIGS, synthetic_frame_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,6 +138,9 @@ def main():
     proc = HipProcessor(device=local_rank)
     if args.direct_stencils:
         proc.ctx.set_option("stencil_fft", 0)
+    for o in args.opt:
+        k, v = o.split("=")
+        proc.ctx.set_option(k, int(v))
     params = proc.prepare(neg, 6, 0.4, (W, H), seed=GRAIN_SEED, matrix=REC709_TO_XYZ, **settings)
     scale = max(H, W) / 36.0
     hal_k = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3) if effects else None
@@ -113,7 +160,7 @@ def main():
     frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}", kind=args.frame)
     out = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device=frame.device)
 
-    # time every stage with events on the launch stream, inside the timed steps (the dominant one feeds `roofline`)
+    # time every stage with events on the launch stream, inside the timed steps
     from raw2film_amd.tracing import TimedBackend
 
     timed = TimedBackend(backend)
@@ -129,13 +176,16 @@ def main():
         for _ in range(frames_here):
             renderer.render(frame, out_f32=out)
 
+    def drain_timing():
+        return [proc.ctx.kernel_timing(cls) for cls in range(6)]  # (total ms, launches, algorithmic bytes) per class
+
     for _ in range(args.warmup):
         step()
     barrier()
     timed.reset()
-    proc.ctx.set_option("kernel_timing", 2)  # events around every launch of the FFT column pass, on the launch stream
-    for cls in range(3):
-        proc.ctx.kernel_timing(cls)  # reset
+    # events around every launch of the FFT column passes (the kernels with the largest share), on their launch streams
+    proc.ctx.set_option("kernel_timing", 2)
+    drain_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -147,10 +197,12 @@ def main():
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
-    mp_per_s = H * W / 1e6 * (args.frames if batch else 1) * args.steps / dt
+    n_frames = args.frames if batch else 1
+    mp_per_s = H * W / 1e6 * n_frames * args.steps / dt
+    full = "3x3 + 2-D LUT + halation + log/curve + MTF + grain + tetrahedral 3-D LUT"
 
     result = {
-        "metric": "megapixels/sec full film pipeline (neg+print+grain+halation+MTF), 100MP frame",
+        "metric": METRICS[args.config],
         "value": mp_per_s,
         "unit": "MP/s",
         "n_gpus": world,
@@ -160,134 +212,167 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 (pointwise stages, grain) + f64 (FFT stencils)" if not args.direct_stencils else "f32",
+        "dtype": ("f32" if args.direct_stencils or not effects else
+                  "f32 (pointwise stages, grain) + f64 (FFT stencils; the MTF's scratch images are complex64)"),
         "data": "synthetic" if args.frame == "noise" else "synthetic (smooth, photograph-like frame: not the headline input)",
         "config": {
-            "workload": f"{args.config}: " + (f"{args.frames} x " if batch else "") + f"{W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 frame, 36x24 mm, "
-                        + ("full pipeline S0-S8: 3x3 + 2-D LUT + halation 87x87 + log/curve + MTF 35x35 + grain 9x9 + tetrahedral 3-D LUT"
-                           if args.config == "cfg4_100mp" else
-                           ("full pipeline S0-S8" if effects else "LUTs only (S0+S1+S3+S4+S8), effects off"))
+            "workload": f"{args.config}: " + (f"{args.frames} x " if batch else "") + f"{W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 "
+                        "frame, 36x24 mm, " + (f"full pipeline S0-S8: {full}" if effects else "LUTs only (S0+S1+S3+S4+S8), effects off")
+                        + (f", stencils {hal_k.shape[0]}x{hal_k.shape[1]} / {mtf_k.shape[0]}x{mtf_k.shape[1]}" if effects else "")
                         + ", fp32 HWC in -> fp32 HWC out",
             "stocks": "synthetic stand-ins portra400_like + k2383_like (spectral_film_lut data unavailable offline)",
             "sharding": (f"batch of {args.frames} frames, frame i -> rank i mod {world}, no collectives" if batch else
                          "single GPU" if world == 1 else
-                         f"row-sharded over {world} GPUs, RCCL halo exchange (E: halation rows, D: MTF rows)"),
+                         f"row-sharded over {world} GPUs, one RCCL halo exchange per frame (exposure rows for both stencils)"),
+            "options": args.opt,
         },
     }
 
     stage_ms = timed.summary()
     result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
-    fft_ms = [proc.ctx.kernel_timing(cls) for cls in range(3)]  # (total ms, launches, algorithmic bytes); only pass 2 was on
+    cols = drain_timing()  # only the column passes (classes 1 and 4) were on
     # the other two passes, for the breakdown only: two extra steps outside the timed region
     proc.ctx.set_option("kernel_timing", 5)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    extra = [proc.ctx.kernel_timing(cls) for cls in range(3)]
-    # ... and the column pass with the GPU to itself (one internal stream): what a launch does when no other kernel shares
-    # the CUs and the memory system with it
-    solo = (0.0, 0, 0.0)
-    if not args.no_alone:
+    extra = drain_timing()
+    # ... and the dominant column pass with the GPU to itself (one internal stream): what a launch does when no other kernel
+    # shares the CUs and the memory system with it
+    solo = [(0.0, 0, 0.0)] * 6
+    if not args.no_alone and effects:
         proc.ctx.set_option("kernel_timing", 2)
         proc.ctx.set_option("stencil_fft_streams", 1)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        solo = proc.ctx.kernel_timing(1)
+        solo = drain_timing()
         proc.ctx.set_option("stencil_fft_streams", 2)
     proc.ctx.set_option("kernel_timing", 0)
-    if effects and "halation" in stage_ms:
-        hal_ms = float(stage_ms["halation"])
-        px = (r1 - r0) * W
-        nnz = [int(np.count_nonzero(hal_k[..., c])) for c in range(3)]
-        flops_nnz = 2.0 * sum(nnz) * px  # one FMA per non-zero tap per pixel
-        st = proc.ctx.stencil_stats(0)
-        traffic = None
-        # HBM bytes per launch from the PMC passes of tools/profile_round.sh (not measurable inside a live run)
-        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")) \
-            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-        if any(c["fft"] for c in st) and fft_ms[1][1] > 0:
-            # The stencils run as fp64 overlap-save FFTs; their column pass is the kernel with the largest share of the step.
-            tot_ms, launches, bytes_alg = fft_ms[1]
-            win = next(c["window"] for c in st if c["fft"])  # (rows, columns) of the halation windows; the MTF's may differ
-            cols_kernel = {(256, 256): "fft_cols_kernel", (256, 512): "fft_cols_x512_kernel", (512, 256): "fft_cols_y512_kernel",
-                           (512, 512): "fft_cols_y512_x512_kernel"}[tuple(win)]
-            if tfiles and world == 1 and args.config == "cfg4_100mp":
-                for name, rec in json.load(open(os.path.join(ROOT, "profiles", tfiles[-1]))).items():
-                    if cols_kernel + "(" in name:
-                        traffic = rec["hbm_bytes_per_launch"]
-            gbps = bytes_alg / (tot_ms * 1e-3) / 1e9
-            result["roofline"] = {
-                "kernel": f"r2f::{cols_kernel} (pass 2 of the fp64 overlap-save FFT stencils, windows of {win[0]} rows x {win[1]} "
-                          "columns: column FFT, x kernel spectrum, inverse column FFT, in place; halation and MTF launches together)",
-                "bound": "hbm",
-                "achieved": gbps,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": gbps / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "kernel_ms": tot_ms / launches,
-                "launches_per_step": launches / args.steps,
-                "bytes_per_launch": bytes_alg / launches,
-                "bytes_counted": f"per window pair: the {win[0]} x {win[1]} complex128 scratch image read ({win[0] * win[1] >> 16} MiB) + "
-                                 f"its rows that hold valid outputs written back (({win[0]} - k + 1) / {win[0]} of it); the kernel "
-                                 "spectrum (same size) is L2-resident",
-                "passes_ms_per_step": {"rows_fwd": extra[0][0] / 2, "cols": fft_ms[1][0] / args.steps, "rows_inv": extra[2][0] / 2,
-                                       "note": "cols: events in the timed steps; the other two passes: two extra steps after them"},
-                "concurrency": "launches alternate between two internal streams, so two FFT-pass kernels usually share the GPU: "
-                               "kernel_ms and achieved are per launch under that sharing; the line below is the aggregate. The "
-                               "event pair around a ~50 us launch also spans its dispatch gap (~5 us), so kernel_ms reads ~10 % "
-                               "above rocprofv3's kernel-only average (profiles/r01_kernel_stats.csv): the quoted frac is the "
-                               "conservative one",
-                "alone": (lambda ms, n, b: {"kernel_ms": ms / n, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                            "note": "the same launches (twice the pairs each) with one internal stream, two extra "
-                                                    "steps after the timed ones: no other kernel on the GPU"})(*solo) if solo[1] else None,
-                "stencil_stages": (lambda b, ms: {"algorithmic_bytes_per_step": b, "ms_per_step": ms, "GB/s": b / (ms * 1e-3) / 1e9,
-                                                  "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                  "note": "all three passes of halation + MTF (window floats in, scratch "
-                                                          "written, read, written back, read, outputs out) over the two "
-                                                          "stages' wall time, single-tap plane included"})(
-                    extra[0][2] / 2 + bytes_alg / args.steps + extra[2][2] / 2,
-                    float(stage_ms["halation"]) + float(stage_ms.get("mtf", 0.0))),
-                "stencil_flops": {
-                    "halation_direct_equivalent_tflops": flops_nnz / (hal_ms * 1e-3) / 1e12,
-                    "note": "what a direct evaluation of the reference's halation stencil (2 flop per non-zero tap) would need, "
-                            "divided by the halation stage's time: the FFT form does the same arithmetic job in ~25x fewer "
-                            "(fp64) flops, so this can exceed the fp32 vector peak of 157.3",
-                },
-            }
-        else:
-            flops_s8d = 2.0 * 2 * hal_k.shape[0] * hal_k.shape[1] * px  # 2 channels x K^2 taps, zeros included
-            achieved = flops_nnz / (hal_ms * 1e-3) / 1e12
-            if tfiles and world == 1 and args.config == "cfg4_100mp":
-                for name, rec in json.load(open(os.path.join(ROOT, "profiles", tfiles[-1]))).items():
-                    if "stencil_kernel" in name and ", 1>" in name:  # the EPI = 1 (halation) instantiation
-                        traffic = rec["hbm_bytes_per_launch"]
-            lane_groups = px / 16.0
-            executed = sum(2.0 * 64 * c["entries"] + (16.0 * c["entries"] if c["sym"] else 0.0) for c in st) * lane_groups
-            result["roofline"] = {
-                "kernel": "r2f::stencil_kernel<32,16,4,1> (S2 halation + S3 log + S4 curve, direct form)",
-                "bound": "mfma",
-                "engine": "fp32 VALU (v_pk_fma_f32 + v_add_f32); no MFMA is issued -- the fp32 dense MFMA peak equals the fp32 VALU peak on gfx950",
-                "achieved": achieved,
-                "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP32_PEAK_TFLOPS,
-                "traffic": traffic,
-                "kernel_ms": hal_ms,
-                "flops_per_launch": flops_nnz,
-                "flops_counted": f"2 x non-zero taps ({nnz[0]} + {nnz[1]} + {nnz[2]} per pixel) x {px} pixels",
-                "achieved_survey_8d": flops_s8d / (hal_ms * 1e-3) / 1e12,
-                "executed": {"tflops": executed / (hal_ms * 1e-3) / 1e12,
-                             "frac": executed / (hal_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                             "entries_per_channel": [c["entries"] for c in st]},
-            }
-    bytes_alg = 24.0 * H * W * (args.frames if batch else 1)
-    gbps = bytes_alg / (ms_per_step * 1e-3) / 1e9
-    result["roofline_hbm"] = {
-        "scope": "whole step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": gbps / HBM_PEAK_GBPS, "bytes_per_px": 24,
+
+    # ---- roofline, SURVEY.md 8(d): 24 algorithmic bytes per pixel over the whole step
+    alg_bytes = 24.0 * H * W * n_frames
+    gbps = alg_bytes / (ms_per_step * 1e-3) / 1e9
+    peak = HBM_PEAK_GBPS * world
+    roof = {
+        "bound": "hbm", "achieved": gbps, "peak": peak, "unit": "GB/s", "frac": gbps / peak,
+        "definition": "SURVEY.md 8(d): 12 B/px read + 12 B/px written (fp32 HWC in and out) x the frame, over ms_per_step"
+                      + (f"; peak = {world} x 8 TB/s" if world > 1 else ""),
+        "bytes_per_px": 24,
+        "read_only": {"bytes_per_px": 12, "achieved": gbps / 2, "frac": gbps / 2 / peak,
+                      "note": "the north_star's 'HBM-read roofline' variant: input bytes only"},
+        "traffic": None,
     }
+    result["roofline"] = roof
+
+    # L2 <-> fabric bytes of one step from the committed PMC capture, only when it was taken from these very sources on this
+    # configuration (tools/profile_round.sh writes the file; it cannot be measured inside an un-profiled run)
+    tfile = os.path.join(ROOT, "profiles", f"r02_{args.config}_hbm_traffic.json")
+    if os.path.exists(tfile) and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain:
+        rec = json.load(open(tfile))
+        meta = rec.get("_meta", {})
+        match = meta.get("source_hash") == source_hash() and meta.get("config") == args.config and meta.get("frame") == args.frame
+        roof["traffic_provenance"] = {"file": os.path.relpath(tfile, ROOT), "collected": meta.get("date"), "command": meta.get("command"),
+                                      "source_hash_then": meta.get("source_hash"), "source_hash_now": source_hash(), "match": match}
+        if match:
+            roof["traffic"] = meta["bytes_per_step"]
+            roof["traffic_over_algorithmic"] = meta["bytes_per_step"] / alg_bytes
+            roof["traffic_note"] = ("FETCH_SIZE x 2 + WRITE_SIZE per step, separate --pmc passes (gfx950 tallies 128-B reads at 64 B): "
+                                    "L2 <-> fabric bytes; Infinity Cache hits are counted, so this is an upper bound on HBM bytes")
+
+    if effects and "halation" in stage_ms:
+        st_h, st_m = proc.ctx.stencil_stats(0), proc.ctx.stencil_stats(1)
+        names = ["rows_fwd (complex128)", "cols (complex128)", "rows_inv (complex128)", "rows_fwd (complex64)", "cols (complex64)",
+                 "rows_inv (complex64)"]
+        per_step = [extra[0][0] / 2, cols[1][0] / args.steps, extra[2][0] / 2, extra[3][0] / 2, cols[4][0] / args.steps, extra[5][0] / 2]
+        roof["fft_pass_ms_per_step"] = {n: round(v, 4) for n, v in zip(names, per_step) if v > 0}
+        roof["fft_pass_note"] = ("event-bracketed launch times summed per step; launches alternate between two internal streams, so "
+                                 "the sums exceed the stage wall time. cols: inside the timed steps; rows_*: two extra steps after them")
+        dom = 1 if cols[1][0] >= cols[4][0] else 4
+        if cols[dom][1] > 0:
+            tot_ms, launches, bytes_alg = cols[dom]
+            stats = st_h if dom == 1 else st_m
+            win = next((c["window"] for c in stats if c["fft"]), None)
+            g = bytes_alg / (tot_ms * 1e-3) / 1e9
+            dk = {
+                "kernel": f"r2f::fft_cols_kernel<{win[1] // 16}, {'true' if win[0] == 512 else 'false'}, {'true' if dom == 4 else 'false'}> "
+                          f"(pass 2 of the fp64 overlap-save FFT of the {'MTF' if dom == 4 else 'halation'} stencil, windows of {win[0]} rows x "
+                          f"{win[1]} columns, {'complex64' if dom == 4 else 'complex128'} scratch: column FFT, x kernel spectrum, inverse "
+                          "column FFT, in place)",
+                "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
+                "kernel_ms": tot_ms / launches, "launches_per_step": launches / args.steps, "bytes_per_launch": bytes_alg / launches,
+                "bytes_counted": "per window pair: the scratch image read + its rows that hold valid outputs written back; the kernel "
+                                 "spectrum (L2-resident) is not counted",
+                "share_of_step": tot_ms / args.steps / ms_per_step,
+                "concurrency": "two FFT-pass kernels usually share the GPU (two internal streams): kernel_ms and achieved are per launch "
+                               "under that sharing; the event pair also spans the dispatch gap (~5 us)",
+            }
+            if solo[dom][1]:
+                ms, n, b = solo[dom]
+                dk["alone"] = {"kernel_ms": ms / n, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "note": "the same launches (twice the pairs each) with one internal stream, two extra steps"}
+            roof["dominant_kernel"] = dk
+        # all FFT passes of both stencils over the two stages' wall time
+        sb = (sum(extra[c][2] / 2 for c in (0, 2, 3, 5)) + sum(cols[c][2] / args.steps for c in (1, 4))) / frames_here  # per frame
+        sms = float(stage_ms["halation"]) + float(stage_ms.get("mtf", 0.0))
+        roof["stencil_stages"] = {"scratch_and_window_bytes_per_frame": sb, "ms_per_frame": sms, "GB/s": sb / (sms * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "bytes_per_px": sb / ((r1 - r0) * W),
+                                  "note": "what the three passes of halation + MTF have to move (window floats in, scratch written, read, "
+                                          "written back, read, outputs out), single-tap plane included in the time"}
+        # fp64 work of the FFT passes against the vector peak
+        flops = insts = 0.0
+        rows_here = r1 - r0
+        for stats, kern in ((st_h, hal_k), (st_m, mtf_k)):
+            for ch, c in enumerate(stats):
+                if not c["fft"] or not c["window"]:
+                    continue
+                nz = np.nonzero(kern[..., ch if kern.shape[2] > 1 else 0])
+                bh, bw = int(nz[0].max() - nz[0].min() + 1), int(nz[1].max() - nz[1].min() + 1)  # box of the non-zero taps
+                ny, nx = c["window"]
+                vy, vx = ny - bh + 1, (nx - bw + 1) & ~3
+                pairs = (((W + vx - 1) // vx) * ((rows_here + vy - 1) // vy) + 1) // 2
+                f, i = fft_fp64_ops(ny, nx, vy)
+                flops += pairs * f
+                insts += pairs * i
+        if flops:
+            roof["fp64_valu"] = {
+                "flops_per_frame": flops, "tflops": flops / (sms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                "frac": flops / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "issue_slot_frac": insts / (sms * 1e-3) / (FP64_PEAK_TFLOPS / 2 * 1e12),
+                "note": "fp64 adds, multiplies and FMAs of the FFT passes counted from r2f_fft.hip (FMA = 2 flop) over the two stencil "
+                        "stages' wall time; issue_slot_frac counts every fp64 instruction as one slot of the 39.3 T lane-instr/s the "
+                        "vector units issue at 2.4 GHz (adds fill a slot with 1 flop)"}
+        if args.direct_stencils:
+            px = (r1 - r0) * W
+            nnz = [int(np.count_nonzero(hal_k[..., c])) for c in range(3)]
+            hal_ms = float(stage_ms["halation"])
+            roof["direct_halation"] = {"tflops_nonzero_taps": 2.0 * sum(nnz) * px / (hal_ms * 1e-3) / 1e12, "fp32_peak": 157.3,
+                                       "kernel_ms": hal_ms}
+
+    if batch and world == 1 and not args.no_pcie:
+        # BASELINE config 5 end to end on this GPU: BatchSharder with the two-phase API, host frames in (pinned), uint8 back to
+        # the host -- PCIe-inclusive, never `value`
+        n_e2e = min(args.frames, 8)
+        host = frame.cpu().pin_memory()
+        payloads = [{"image_array": host, "output_resolution": (W, H), "canvas_resolution": None, "pipeline_resolution": (W, H)}]
+
+        def prepare(task):
+            return payloads[0]
+
+        def execute(task, payload):
+            dev = payload["image_array"].to(frame.device, non_blocking=True)
+            o, u8 = proc.ctx.render(dev, params, want_f32=False, want_u8=True)
+            return u8.cpu()
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res, skipped = BatchSharder(0, 1).run(list(range(n_e2e)), prepare, execute)
+        torch.cuda.synchronize()
+        dt_e2e = time.perf_counter() - t0
+        result["pcie_inclusive"] = {"value": H * W / 1e6 * len(res) / dt_e2e, "unit": "MP/s", "frames": len(res),
+                                    "note": "BatchSharder.run: pinned fp32 HWC frame -> device, render, uint8 result -> host, frame after "
+                                            "frame on one stream (no overlap of copies and renders); not part of `value`"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

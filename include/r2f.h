@@ -217,7 +217,8 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
 /* Per-launch device timing of the FFT stencil passes, for the roofline line of bench.py.  After r2f_set_option(ctx,
  * "kernel_timing", mask) every launch of a pass cls whose bit (1 << cls) is set (0 rows forward, 1 columns, 2 rows inverse) is bracketed by events on its own
  * stream; this call waits for them, returns their summed duration, the launch count and the summed algorithmic bytes
- * (scratch images and windows the pass has to move; the 1 MB kernel spectrum stays in L2), and resets the counters. */
+ * (scratch images and windows the pass has to move; the 1 MB kernel spectrum stays in L2), and resets the counters.
+ * cls = pass (0..2) for launches on complex128 scratch (the halation), pass + 3 for launches on complex64 scratch (the MTF). */
 int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes);
 
 /* Tuning knob for A/B runs: stencil tile variant (0 = auto). */

@@ -69,8 +69,8 @@ struct r2f_ctx {
     // optional per-launch timing of the FFT passes with events on the launch stream (bench.py's roofline): class 0 / 1 / 2 =
     // pass 1 / 2 / 3; algorithmic bytes are summed alongside
     int opt_timing = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev[3];
-    double timing_bytes[3] = {0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_ev[6];  // [pass + 3 * (complex64 scratch ? 1 : 0)]
+    double timing_bytes[6] = {0, 0, 0, 0, 0, 0};
     int opt_fft = 1;             // 1: stencil channels with a large enough kernel take the FFT form
     int opt_fft_min_taps = 400;   // ... "large enough": cropped box of at least this many taps (and at most 200 x 200);
                                  // measured crossover with the direct form: 17 x 17 ties, 23 x 23 is 1.5x faster by FFT
@@ -719,8 +719,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         R2F_HIP(ctx, hipEventRecord(e0, st));
         R2F_HIP(ctx, launch());
         R2F_HIP(ctx, hipEventRecord(e1, st));
-        ctx->timing_ev[cls].push_back({e0, e1});
-        ctx->timing_bytes[cls] += bytes;
+        ctx->timing_ev[cls + 3 * a.s32].push_back({e0, e1});
+        ctx->timing_bytes[cls + 3 * a.s32] += bytes;
         return R2F_OK;
     };
     int turn = 0;
@@ -1137,7 +1137,7 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
 }
 
 int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes) {
-    if (!ctx || cls < 0 || cls > 2 || !total_ms || !launches || !bytes) return R2F_EINVAL;
+    if (!ctx || cls < 0 || cls > 5 || !total_ms || !launches || !bytes) return R2F_EINVAL;
     R2F_GUARD(ctx);
     double sum = 0.0;
     for (auto& ev : ctx->timing_ev[cls]) {

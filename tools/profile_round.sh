@@ -1,28 +1,37 @@
 #!/bin/bash
-# usage: tools/profile_round.sh r01
-# (1) rocprofv3 --kernel-trace --stats of the default bench.py command, (2) HBM traffic counters of the
-# dominant kernel in separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), with the
-# FETCH_SIZE x2 correction for gfx950 (MI355X_MICROARCH.md, HBM; re-checked by tools/cal_pmc.sh).
-# Summaries land in gpurun_out/profile_<tag>/summary/ ; copy them to profiles/.
+# usage: tools/profile_round.sh <tag> [config]      e.g.  tools/profile_round.sh r02 cfg4_100mp
+# (1) rocprofv3 --kernel-trace --stats of the bench.py command for that configuration, (2) L2 <-> fabric traffic of every r2f
+# kernel in separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; kernel-trace only beside them), with the
+# FETCH_SIZE x 2 correction for gfx950 (MI355X_MICROARCH.md, HBM; re-checked by tools/cal_pmc.sh).
+# Summaries land in gpurun_out/profile_<tag>_<config>/summary/ ; copy them to profiles/.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r01}
-OUT=gpurun_out/profile_$TAG
+TAG=${1:-r02}
+CFG=${2:-cfg4_100mp}
+OUT=gpurun_out/profile_${TAG}_$CFG
+STEPS=5; WARM=2; PSTEPS=2; PWARM=1
 rm -rf $OUT; mkdir -p $OUT/summary
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alone > $OUT/bench_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alone > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alone > $OUT/pmc_write.log 2>&1
+ARGS="--config $CFG --no-cpu-baseline --no-alone --no-pcie"
+[ "$CFG" = cfg5_batch ] && ARGS="$ARGS --frames 8"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps $STEPS --warmup $WARM $ARGS > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps $PSTEPS --warmup $PWARM $ARGS > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps $PSTEPS --warmup $PWARM $ARGS > $OUT/pmc_write.log 2>&1
 python3 - <<PY
-import csv, glob, json, collections
-out, tag = "$OUT", "$TAG"
+import csv, glob, json, collections, datetime, sys
+sys.path.insert(0, ".")
+from bench import source_hash
+out, tag, cfg = "$OUT", "$TAG", "$CFG"
+steps, warm, psteps, pwarm = $STEPS, $WARM, $PSTEPS, $PWARM
+frames = 8 if cfg == "cfg5_batch" else 1
 rows = []
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
-with open(f"{out}/summary/{tag}_kernel_stats.csv", "w") as fh:
-    fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alone (9 renders of the 100 MP frame: 2 warm-up + 5 timed + 2 for the\n# per-pass breakdown)\n")
-    fh.write("# torch's frame-generation kernels are folded into one line\n")
+renders = (steps + warm + 2) * frames
+with open(f"{out}/summary/{tag}_{cfg}_kernel_stats.csv", "w") as fh:
+    fh.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps} --warmup {warm} $ARGS\n")
+    fh.write(f"# ({renders} renders: {warm} warm-up + {steps} timed + 2 for the per-pass breakdown" + (f", x {frames} frames each" if frames > 1 else "") + "); torch's frame-generation kernels are folded into one line\n")
     fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     other = [0, 0.0]
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
@@ -32,20 +41,32 @@ with open(f"{out}/summary/{tag}_kernel_stats.csv", "w") as fh:
         else:
             other[0] += int(r["Calls"]); other[1] += float(r["TotalDurationNs"])
     fh.write('"(torch: synthetic frame generation, copies)",%d,%.0f,,%.2f,,\n' % (other[0], other[1], 100 * other[1] / total))
-print(open(f"{out}/summary/{tag}_kernel_stats.csv").read())
+print(open(f"{out}/summary/{tag}_{cfg}_kernel_stats.csv").read())
 tot = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "r2f::" in row["Kernel_Name"]:
             tot[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
+prenders = (psteps + pwarm + 2) * frames
+per_step = 0.0
 for k, d in tot.items():
     fetch = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
     write = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
-    summary[k] = {"FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write, "launches": len(d["FETCH_SIZE"]),
-                  "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
-                  "note": "FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B (checked with tools/cal_pmc.sh: 1 GiB copy reads report 512 MiB for 4-B and 16-B per-lane loads; WRITE_SIZE exact)"}
-json.dump(summary, open(f"{out}/summary/{tag}_hbm_traffic.json", "w"), indent=1)
-print(json.dumps(summary, indent=1))
+    n = len(d["FETCH_SIZE"])
+    b = (2 * fetch + write) * 1024
+    summary[k] = {"FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write, "launches": n, "launches_per_render": n / prenders,
+                  "hbm_bytes_per_launch": b, "bytes_per_render": b * n / prenders}
+    per_step += b * n / prenders * frames
+H, W = {"cfg4_100mp": (8192, 12288), "cfg3_45mp": (5504, 8256), "cfg2_24mp": (4000, 6000), "cfg5_batch": (4000, 6000)}[cfg]
+summary["_meta"] = {
+    "config": cfg, "frame": "noise", "source_hash": source_hash(), "date": datetime.datetime.now().isoformat(timespec="seconds"),
+    "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps {psteps} --warmup {pwarm} $ARGS (two passes)",
+    "bytes_per_step": per_step, "algorithmic_bytes_per_step": 24.0 * H * W * frames, "ratio": per_step / (24.0 * H * W * frames),
+    "note": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, averaged over the launches of each kernel: FETCH_SIZE doubled "
+            "because gfx950 tallies 128-B read requests at 64 B (tools/cal_pmc.sh: a 1 GiB copy reads 512 MiB); WRITE_SIZE exact. "
+            "L2 <-> fabric requests, Infinity Cache hits included."}
+json.dump(summary, open(f"{out}/summary/{tag}_{cfg}_hbm_traffic.json", "w"), indent=1)
+print(json.dumps(summary["_meta"], indent=1))
 PY
-tail -1 $OUT/bench_under_rocprof.log | cut -c1-400
+tail -1 $OUT/bench_under_rocprof.log | cut -c1-600
