@@ -103,6 +103,7 @@ struct r2f_ctx {
     DeviceBuf stencil_fixed_w[3];  // the same for the direct stencil kernel (stencil_fixed<R, 4>), per stencil
     bool stencil_fixed_valid[3] = {false, false, false};
     int opt_stencil_fixed = 1;
+    int opt_front_fast = 1;    // the fused LUT-only pass may take the specialised kernel (r2f_front.hip); 0 = always the generic one (A/B)
     int opt_front_blocks = 6;  // front kernel with the curve in LDS: workgroups per CU in its grid (3 are resident at 48 KB each)
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
 };
@@ -870,7 +871,8 @@ int r2f_create(int device, r2f_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return R2F_EHIP;
     DeviceGuard guard(device);  // the caller's current device is restored on return
     if (guard.status != hipSuccess) return R2F_EHIP;
-    if (init_kernel_attributes() != hipSuccess || fft_init_attributes() != hipSuccess) return R2F_EHIP;
+    if (init_kernel_attributes() != hipSuccess || fft_init_attributes() != hipSuccess || front_fast_init_attributes() != hipSuccess)
+        return R2F_EHIP;
     r2f_ctx* ctx = new r2f_ctx();
     ctx->device = device;
     *out = ctx;
@@ -947,6 +949,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "grain_fixed")) {
         ctx->opt_grain_fixed = value ? 1 : 0;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "front_fast")) {
+        ctx->opt_front_fast = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "grain_separable")) {
@@ -1109,6 +1115,7 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
     }
     a.vec = vec ? 1 : 0;
     a.blocks_per_cu = ctx->opt_front_blocks;
+    a.fast = ctx->opt_front_fast;
     R2F_HIP(ctx, launch_front(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }

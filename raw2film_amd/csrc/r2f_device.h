@@ -161,9 +161,10 @@ struct Mat3 {
     float m[9];
 };
 __device__ __forceinline__ void apply_matrix(const Mat3& M, float& r, float& g, float& b) {
-    float x = (M.m[0] * r + M.m[1] * g) + M.m[2] * b;
-    float y = (M.m[3] * r + M.m[4] * g) + M.m[5] * b;
-    float z = (M.m[6] * r + M.m[7] * g) + M.m[8] * b;
+    // explicit contraction (the same in every kernel that applies S0): m0 r rounded, then two fused multiply-adds
+    float x = fmaf(M.m[2], b, fmaf(M.m[1], g, M.m[0] * r));
+    float y = fmaf(M.m[5], b, fmaf(M.m[4], g, M.m[3] * r));
+    float z = fmaf(M.m[8], b, fmaf(M.m[7], g, M.m[6] * r));
     r = x;
     g = y;
     b = z;
@@ -192,9 +193,10 @@ __device__ __forceinline__ void apply_lut2d(const DevLut2D& L, float& X, float& 
     const float wr = lower ? rf : 1.0f - gf;
     const float wg = lower ? gf : 1.0f - rf;
     const float ws = lower ? 1.0f - fsum : fsum - 1.0f;
-    X = ((rv.x * wr + gv.x * wg) + sv.x * ws) * S;
-    Y = ((rv.y * wr + gv.y * wg) + sv.y * ws) * S;
-    Z = ((rv.z * wr + gv.z * wg) + sv.z * ws) * S;
+    // explicit contraction, the same in every kernel that samples the LUT
+    X = fmaf(sv.x, ws, fmaf(gv.x, wg, rv.x * wr)) * S;
+    Y = fmaf(sv.y, ws, fmaf(gv.y, wg, rv.y * wr)) * S;
+    Z = fmaf(sv.z, ws, fmaf(gv.z, wg, rv.z * wr)) * S;
 }
 
 // S3 + S4: log10(max(x, eps)) then the density curve.

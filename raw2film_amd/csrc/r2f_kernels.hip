@@ -1102,6 +1102,7 @@ hipError_t init_kernel_attributes() {
 
 hipError_t launch_front(const FrontArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
+    if (a.fast && front_fast_eligible(a)) return launch_front_fast(a, s);
     const int quads = (a.W + 3) / 4;
     const int gx = (quads + 63) / 64;
     const int row_groups = (a.y1 - a.y0 + kFrontBY - 1) / kFrontBY;

@@ -26,7 +26,11 @@ struct FrontArgs {
     int lut3d_mode;
     int vec;  // 1: W % 4 == 0 and all bases 16-byte aligned -> float4 paths
     int blocks_per_cu;  // curve-in-LDS variant: workgroups in the grid per CU (each copies the curve cells once, then walks rows)
+    int fast;           // 1: the fused S0..S8 pass may take the specialised kernel of r2f_front.hip when it is eligible
 };
+bool front_fast_eligible(const FrontArgs& a);
+hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s);
+hipError_t front_fast_init_attributes();
 
 struct StencilArgs {
     DevStencil st[3];

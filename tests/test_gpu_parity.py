@@ -778,3 +778,48 @@ def test_separable_grain_stencils_run_as_two_1d_passes(ctx, n, mono, per_channel
             for j in (1, n - 2):
                 ref_bad[..., c] += (float(bad[0, j, c]) - float(k[0, j, c])) * padded[0:H, j:j + W, c]
         assert np.abs(got - ref_bad).max() <= 5e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("layout", ["hwc3", "hwc4", "chw"])
+@pytest.mark.parametrize("matrix", [True, False])
+def test_fused_pointwise_fast_path_matches_generic(ctx, layout, matrix):
+    """BASELINE config 2's single fused kernel has a specialised form (r2f_front.hip: 32-bit table offsets, packed channel
+    pairs, non-negative cell arithmetic for the 3-D LUT); it must give the generic kernel's bits -- float and uint8 -- for every
+    input layout, with and without S0, including pixels in the S < 1e-12 branch, densities past the LUT's last cell, exact
+    ties between the tetrahedron's fractions, and a density curve that dips below zero (the wave then takes the general cell
+    arithmetic, negative indices wrapping like Python's)."""
+    neg, prt, _ = stocks()
+    H, W = 96, 256
+    p = oracle_inputs(neg, prt, 166.67, halation=False, mtf=False, grain=0, matrix=matrix)
+    img = synthetic_frame(H, W, seed=31)
+    img[0, :8] = 0.0
+    img[1, :8] = [1e-9, 0, 0]
+    img[2, :16] = 0.18  # grey: equal fractions on the three axes after a neutral curve
+    img[3, :4] = 60000.0
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    t = {"hwc3": lambda: dev(img), "hwc4": lambda: dev(np.concatenate([img, np.ones((H, W, 1), np.float32)], axis=-1)),
+         "chw": lambda: to_planes(img)}[layout]()
+
+    def both(curve=None):
+        if curve is not None:
+            ctx.set_curve1d(curve)
+        outs = []
+        for fast in (1, 0):
+            ctx.set_option("front_fast", fast)
+            outs.append(ctx.render(t, params, want_f32=True, want_u8=True, layout=layout))
+        ctx.set_option("front_fast", 1)
+        return outs
+
+    (f_fast, u_fast), (f_gen, u_gen) = both()
+    assert torch.equal(f_fast, f_gen) and torch.equal(u_fast, u_gen)
+    # (without S0 the Rec.709 numbers are read as XYZ: saturated "colours" whose red exposure is a difference of LUT terms a
+    # thousand times larger -- fp32 rounding noise of either implementation is then 1e-5 of the result; the comparison with the
+    # oracle is made on the realistic input, the bit-equality of the two kernels on both)
+    assert_close(f_fast.cpu().numpy(), ref, 1e-5 if matrix else 5e-5, 1e-3, "fast fused pass")
+    # a curve shifted below zero: negative densities reach the 3-D LUT
+    low = p.lut_1d.copy()
+    low[1:] -= 0.6
+    (f_fast, u_fast), (f_gen, u_gen) = both(low)
+    assert torch.equal(f_fast, f_gen) and torch.equal(u_fast, u_gen)
+    ctx.set_curve1d(p.lut_1d)

@@ -1,0 +1,94 @@
+// gather_rate.hip -- how fast can a CU gather 16-byte LUT texels?  (MI355X; build: hipcc -O3 --offload-arch=gfx950)
+// Each lane of every wave does ITERS dependent-address-free gathers from a table of `texels` float4 entries:
+//   mode 0: every lane a random texel (all 64 lanes of an instruction in different cache lines)
+//   mode 1: lane quads read 4 neighbouring texels (one 64-byte run per quad: 16 runs per instruction)
+//   mode 2: every lane the same texel (broadcast)
+//   mode 3: random texels of a table held in LDS (ds_read_b128)
+//   mode 4: random 8-byte gathers (global)
+//   mode 5: mode 0 with nontemporal loads (global_load_dwordx4 ... nt)
+// Prints wave-instructions per microsecond per CU and lanes per clock per CU (at the reported clock).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__device__ __forceinline__ unsigned rnd(unsigned& s) {
+    s = s * 1664525u + 1013904223u;
+    return s >> 8;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gather_kernel(const float4* __restrict__ table, unsigned texels, int iters, float* out) {
+    extern __shared__ float4 lds[];
+    const int tid = threadIdx.x;
+    if (MODE == 3) {
+        for (unsigned i = tid; i < texels; i += blockDim.x) lds[i] = table[i];
+        __syncthreads();
+    }
+    unsigned s = (blockIdx.x * blockDim.x + tid) * 2654435761u + 12345u;
+    float acc = 0.f;
+    for (int it = 0; it < iters; it += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned idx = rnd(s) % texels;
+            if (MODE == 1) idx = ((idx & ~3u) + (tid & 3)) % texels;
+            if (MODE == 2) idx = __builtin_amdgcn_readfirstlane(idx);
+            if (MODE == 3)
+                v[k] = lds[idx];
+            else if (MODE == 4) {
+                const float2 t = reinterpret_cast<const float2*>(table)[idx * 2];
+                v[k] = make_float4(t.x, t.y, 0.f, 0.f);
+            } else if (MODE == 5) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(table) + idx);
+                v[k] = make_float4(t.x, t.y, t.z, t.w);
+            } else
+                v[k] = table[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    if (acc == 1.2345e30f) out[0] = acc;
+}
+
+template <int MODE>
+void run(const char* name, const float4* table, unsigned texels, float* out) {
+    const int iters = 512, blocks = 256 * 4, threads = 512;
+    const size_t lds = MODE == 3 ? texels * sizeof(float4) : 0;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gather_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(gather_kernel<MODE>, dim3(blocks), dim3(threads), lds, 0, table, texels, iters, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double lanes = (double)blocks * threads * iters;
+    printf("%-46s table %7.0f KB: %7.3f ms  %8.2f G lane-gathers/s  = %5.2f lanes/clk/CU at 2.1 GHz\n", name, texels * 16.0 / 1024, ms,
+           lanes / ms * 1e-6, lanes / (ms * 1e-3) / 256 / 2.1e9);
+}
+
+int main() {
+    const unsigned sizes[] = {4096, 35937, 1u << 20};  // 64 KB (2-D LUT), 575 KB (33^3 3-D LUT), 16 MB
+    float* out;
+    hipMalloc(&out, 64);
+    for (unsigned texels : sizes) {
+        std::vector<float4> h(texels, make_float4(1, 2, 3, 4));
+        float4* d;
+        hipMalloc(&d, texels * sizeof(float4));
+        hipMemcpy(d, h.data(), texels * sizeof(float4), hipMemcpyHostToDevice);
+        run<0>("global 16 B, random texel per lane", d, texels, out);
+        run<1>("global 16 B, quads read 4 neighbouring texels", d, texels, out);
+        run<2>("global 16 B, one texel per wave (broadcast)", d, texels, out);
+        run<4>("global 8 B, random per lane", d, texels, out);
+        run<5>("global 16 B, random, nontemporal (nt)", d, texels, out);
+        if (texels * 16 <= 128 * 1024) run<3>("LDS 16 B (ds_read_b128), random texel per lane", d, texels, out);
+        hipFree(d);
+    }
+    return 0;
+}
