@@ -90,6 +90,12 @@ def main():
                     help="skip the two extra steps that time the dominant FFT pass with one internal stream (tools/profile_round.sh: "
                          "keeps the profiled launches all of one size)")
     ap.add_argument("--no-pcie", action="store_true", help="cfg5_batch: skip the PCIe-inclusive BatchSharder leg")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="A/B: launch every kernel from the host instead of replaying the frame's HIP graph (the default: everything "
+                         "downstream of the halo exchange is captured once and replayed, raw2film_amd/sharding.py)")
+    ap.add_argument("--checksum", action="store_true",
+                    help="validation: every rank takes its rows of ONE full frame (seed 1234) and the JSON line carries a checksum of "
+                         "the whole output, comparable across --gpus values")
     ap.add_argument("--side-grain", action="store_true", help="A/B: make the grain field on a side stream while the stencils run")
     ap.add_argument("--direct-stencils", action="store_true", help="A/B: run the stencils in their direct fp32 form instead of fp64 FFTs")
     ap.add_argument("--opt", action="append", default=[], help="A/B: r2f_set_option name=value (repeatable)")
@@ -148,23 +154,31 @@ def main():
     backend = HipStageBackend(proc.ctx, params,
                               halation_taps=stencils.vertical_reach(hal_k) if effects else (0, 0),
                               mtf_taps=stencils.vertical_reach(mtf_k) if effects else (0, 0))
+    use_graph = not args.no_graph and effects and not args.side_grain
     if batch:  # whole frames per rank: a renderer of world size 1, and this rank's share of the frames per step
-        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, rank=0, world=1)
+        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, rank=0, world=1, graph=use_graph)
         frames_here = len([i for i in range(args.frames) if i % world == rank])
     else:
-        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, side_grain=args.side_grain)
+        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, side_grain=args.side_grain,
+                                      graph=use_graph)
         frames_here = 1
     r0, r1 = renderer.plan.r0, renderer.plan.r1
 
     # this rank's rows of the synthetic frame, resident in HBM before the clock starts
-    frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}", kind=args.frame)
+    if args.checksum:
+        whole_frame = synthetic_frame_device(H, W, seed=1234, device=f"cuda:{local_rank}", kind=args.frame)
+        frame = whole_frame[r0:r1].contiguous()
+        del whole_frame
+    else:
+        frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}", kind=args.frame)
     out = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device=frame.device)
 
-    # time every stage with events on the launch stream, inside the timed steps
+    # per-stage device times come from eager steps bracketed with events (a replayed graph has no stage boundaries to time)
     from raw2film_amd.tracing import TimedBackend
 
     timed = TimedBackend(backend)
-    renderer.backend = timed
+    if not renderer.graph:
+        renderer.backend = timed
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,12 +193,14 @@ def main():
     def drain_timing():
         return [proc.ctx.kernel_timing(cls) for cls in range(6)]  # (total ms, launches, algorithmic bytes) per class
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 if renderer.graph else 0)):  # (the graph is captured on the second frame)
         step()
     barrier()
     timed.reset()
     # events around every launch of the FFT column passes (the kernels with the largest share), on their launch streams
-    proc.ctx.set_option("kernel_timing", 2)
+    # (eager launches only: a replayed graph carries no events -- its breakdown comes from two eager steps afterwards)
+    if not renderer.graph:
+        proc.ctx.set_option("kernel_timing", 2)
     drain_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -228,8 +244,38 @@ def main():
         },
     }
 
+    result["config"]["launch"] = ("HIP graph replay of the frame's launches" + (" downstream of the halo exchange" if world > 1 else "")
+                                  if renderer.graph else "one host launch per kernel")
+    if args.checksum:
+        # order-independent 64-bit checksum of the fp32 output's bit patterns, summed over the ranks
+        cs = out.view(torch.int32).to(torch.int64).sum().reshape(1)
+        if use_dist:
+            cs = cs.cpu() if args.backend == "gloo" else cs
+            dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+        result["checksum"] = int(cs.item())
+    eager = None
+    if renderer.graph:  # the breakdowns below need per-launch events: the same frame through the eager path
+        eager = RowShardedRenderer(timed, H, W, halation=effects, mtf=effects, grain=effects,
+                                   **({"rank": 0, "world": 1} if batch else {}))
+        eager.E, eager.D, eager.D2 = renderer.E, renderer.D, renderer.D2  # share the planes (no second 2.4 GB set)
+
+        def step():  # noqa: F811 -- from here on the eager renderer
+            for _ in range(frames_here):
+                eager.render(frame, out_f32=out)
+
+        proc.ctx.set_option("kernel_timing", 2)
+        drain_timing()
+        timed.reset()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        steps_for_cols = 2
+    else:
+        steps_for_cols = args.steps
     stage_ms = timed.summary()
     result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+    if renderer.graph:
+        result["stage_ms_note"] = "two eager steps after the timed (graph-replay) steps"
     cols = drain_timing()  # only the column passes (classes 1 and 4) were on
     # the other two passes, for the breakdown only: two extra steps outside the timed region
     proc.ctx.set_option("kernel_timing", 5)
@@ -284,7 +330,7 @@ def main():
         st_h, st_m = proc.ctx.stencil_stats(0), proc.ctx.stencil_stats(1)
         names = ["rows_fwd (complex128)", "cols (complex128)", "rows_inv (complex128)", "rows_fwd (complex64)", "cols (complex64)",
                  "rows_inv (complex64)"]
-        per_step = [extra[0][0] / 2, cols[1][0] / args.steps, extra[2][0] / 2, extra[3][0] / 2, cols[4][0] / args.steps, extra[5][0] / 2]
+        per_step = [extra[0][0] / 2, cols[1][0] / steps_for_cols, extra[2][0] / 2, extra[3][0] / 2, cols[4][0] / steps_for_cols, extra[5][0] / 2]
         roof["fft_pass_ms_per_step"] = {n: round(v, 4) for n, v in zip(names, per_step) if v > 0}
         roof["fft_pass_note"] = ("event-bracketed launch times summed per step; launches alternate between two internal streams, so "
                                  "the sums exceed the stage wall time. cols: inside the timed steps; rows_*: two extra steps after them")
@@ -300,10 +346,10 @@ def main():
                           f"{win[1]} columns, {'complex64' if dom == 4 else 'complex128'} scratch: column FFT, x kernel spectrum, inverse "
                           "column FFT, in place)",
                 "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
-                "kernel_ms": tot_ms / launches, "launches_per_step": launches / args.steps, "bytes_per_launch": bytes_alg / launches,
+                "kernel_ms": tot_ms / launches, "launches_per_step": launches / steps_for_cols, "bytes_per_launch": bytes_alg / launches,
                 "bytes_counted": "per window pair: the scratch image read + its rows that hold valid outputs written back; the kernel "
                                  "spectrum (L2-resident) is not counted",
-                "share_of_step": tot_ms / args.steps / ms_per_step,
+                "share_of_step": tot_ms / steps_for_cols / ms_per_step,
                 "concurrency": "two FFT-pass kernels usually share the GPU (two internal streams): kernel_ms and achieved are per launch "
                                "under that sharing; the event pair also spans the dispatch gap (~5 us)",
             }
@@ -313,7 +359,7 @@ def main():
                                "note": "the same launches (twice the pairs each) with one internal stream, two extra steps"}
             roof["dominant_kernel"] = dk
         # all FFT passes of both stencils over the two stages' wall time
-        sb = (sum(extra[c][2] / 2 for c in (0, 2, 3, 5)) + sum(cols[c][2] / args.steps for c in (1, 4))) / frames_here  # per frame
+        sb = (sum(extra[c][2] / 2 for c in (0, 2, 3, 5)) + sum(cols[c][2] / steps_for_cols for c in (1, 4))) / frames_here  # per frame
         sms = float(stage_ms["halation"]) + float(stage_ms.get("mtf", 0.0))
         roof["stencil_stages"] = {"scratch_and_window_bytes_per_frame": sb, "ms_per_frame": sms, "GB/s": sb / (sms * 1e-3) / 1e9,
                                   "frac_of_hbm_peak": sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -126,7 +126,7 @@ class RowShardedRenderer:
     """
 
     def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,
-                 group=None, rank=None, world=None, side_grain: bool = False):
+                 group=None, rank=None, world=None, side_grain: bool = False, graph: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -168,6 +168,15 @@ class RowShardedRenderer:
                                and getattr(backend, "device", None) is not None and torch.cuda.is_available())
         self.F = backend.empty(p.rows, W) if self.side_grain else None
         self.side_stream = torch.cuda.Stream(device=backend.device) if self.side_grain else None
+        # graph = True (device backends): everything after the halo exchange -- the ~130 launches of the FFT stencils and the
+        # tail, on this renderer's own persistent planes -- is captured into a HIP graph the second time a frame arrives with
+        # the same output buffers, and replayed from then on: one graph launch (10-16 us of host time) instead of one launch
+        # per kernel, which is what a 1/8 row shard (~1 ms of device work) needs to stay device-bound.  With world == 1 there
+        # is no exchange and the front kernel is part of the graph.  Results are the eager path's, bit for bit.
+        self.graph = bool(graph and not burn and not self.side_grain and getattr(backend, "device", None) is not None
+                          and torch.cuda.is_available() and (halation or mtf or grain)
+                          and (world == 1 or self.single_exchange or not mtf))  # no exchange downstream of the front
+        self._graphs = {}   # key -> [calls seen, CUDAGraph or None]
 
     # ------------------------------------------------------------------ neighbour exchange
     def _exchange(self, buf, buf_gy0: int, above: int, below: int, wait: bool = True):
@@ -237,6 +246,32 @@ class RowShardedRenderer:
     def render(self, image_rows, out_f32=None, out_u8=None):
         """image_rows: this rank's own rows of the decoded frame ((rows, W, 3|4) or (3, rows, W)).
         out_*: this rank's own rows of the result, (rows, W, 3)."""
+        if not self.graph:
+            return self._render_eager(image_rows, out_f32, out_u8)
+        torch, p = self.torch, self.plan
+        whole = p.world == 1  # no exchange: the front kernel is captured too (then the input buffer is part of the key)
+        key = (image_rows.data_ptr() if whole else 0, tuple(image_rows.shape),
+               out_f32.data_ptr() if out_f32 is not None else 0, out_u8.data_ptr() if out_u8 is not None else 0)
+        slot = self._graphs.setdefault(key, [0, None])
+        slot[0] += 1
+        if slot[0] == 1:  # first frame with these buffers: eager (tables, scratch and spectra get built here)
+            return self._render_eager(image_rows, out_f32, out_u8)
+        if not whole:
+            self._front_and_exchange(image_rows)
+        if slot[1] is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if whole:
+                    self._front_and_exchange(image_rows)
+                self._after_exchange(out_f32, out_u8, None)
+            slot[1] = g
+            if len(self._graphs) > 8:  # callers that hand in fresh buffers every frame: do not hoard graphs
+                for k in list(self._graphs)[:-8]:
+                    del self._graphs[k]
+        slot[1].replay()
+        return out_f32, out_u8
+
+    def _render_eager(self, image_rows, out_f32=None, out_u8=None):
         p, be = self.plan, self.backend
         H = p.H
         field_ready = None
@@ -250,32 +285,48 @@ class RowShardedRenderer:
         if not (self.halation or self.mtf or self.grain or self.burn):  # LUTs only: one fused pointwise pass
             be.front_to_output(image_rows, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
             return out_f32, out_u8
+        self._front_and_exchange(image_rows)
+        return self._after_exchange(out_f32, out_u8, field_ready)
+
+    def _front_and_exchange(self, image_rows):
+        """S0 + S1 (+ S3 + S4 without halation) on this rank's rows and the exposure halo exchange."""
+        p, be = self.plan, self.backend
+        H = p.H
+        if not (self.halation or self.mtf or self.grain or self.burn):
+            return
         if not (self.halation or self.mtf):
             be.front(image_rows, p.r0, 1, self.Dplain, p.r0, p.r0, p.r1, H)
+        elif self.halation:
+            above, below = p.halo_e
+            if p.world > 1 and (above or below) and p.rows >= above + below:
+                # the rows the neighbours wait for first, then the interior while the halos travel
+                lo_band = p.r0 + (below if p.rank > 0 else 0)
+                hi_band = p.r1 - (above if p.rank < p.world - 1 else 0)
+                if lo_band > p.r0:
+                    be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, lo_band, H)
+                if hi_band < p.r1:
+                    be.front(image_rows, p.r0, 0, self.E, self.e_lo, hi_band, p.r1, H)
+                pending = self._exchange(self.E, self.e_lo, above, below, wait=False)
+                be.front(image_rows, p.r0, 0, self.E, self.e_lo, lo_band, hi_band, H)
+                self._exchange_finish(pending)
+            else:
+                be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
+                self._exchange(self.E, self.e_lo, above, below)
+        else:
+            be.front(image_rows, p.r0, 1, self.D, self.d_lo, p.r0, p.r1, H)
+
+    def _after_exchange(self, out_f32, out_u8, field_ready):
+        """Everything downstream of the exposure planes: S2 .. S8 on this renderer's own buffers."""
+        p, be = self.plan, self.backend
+        H = p.H
+        if not (self.halation or self.mtf):
             cur, cur_lo = self.Dplain, p.r0
         else:
             if self.halation:
-                above, below = p.halo_e
-                if p.world > 1 and (above or below) and p.rows >= above + below:
-                    # the rows the neighbours wait for first, then the interior while the halos travel
-                    lo_band = p.r0 + (below if p.rank > 0 else 0)
-                    hi_band = p.r1 - (above if p.rank < p.world - 1 else 0)
-                    if lo_band > p.r0:
-                        be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, lo_band, H)
-                    if hi_band < p.r1:
-                        be.front(image_rows, p.r0, 0, self.E, self.e_lo, hi_band, p.r1, H)
-                    pending = self._exchange(self.E, self.e_lo, above, below, wait=False)
-                    be.front(image_rows, p.r0, 0, self.E, self.e_lo, lo_band, hi_band, H)
-                    self._exchange_finish(pending)
-                else:
-                    be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
-                    self._exchange(self.E, self.e_lo, above, below)
                 if self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
                     be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H)
                 else:
                     be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
-            else:
-                be.front(image_rows, p.r0, 1, self.D, self.d_lo, p.r0, p.r1, H)
             cur, cur_lo = self.D, self.d_lo
             if self.mtf:
                 if not self.single_exchange:

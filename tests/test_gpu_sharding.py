@@ -142,3 +142,72 @@ def test_batch_export_through_the_two_phase_api():
         assert sorted(mine0 + mine1) == list(range(6)) and not set(mine0) & set(mine1)
     finally:
         proc.close()
+
+
+def test_graph_replay_of_a_frame_is_bit_identical_to_eager_launches():
+    """RowShardedRenderer(graph=True) captures everything downstream of the (absent, world = 1) exchange on its second frame and
+    replays it afterwards: same bits as the eager path, for new input CONTENT in the same buffers, and again after the
+    output buffer changes (a new capture)."""
+    from raw2film_amd import HipProcessor, stencils
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+
+    neg, prt, _ = stocks()
+    H, W, fw = 300, 640, 2.0  # 320 px/mm: 81-tap halation and 33-tap MTF by FFT, 9 x 9 grain
+    proc = HipProcessor(device=0)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
+                          frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
+    scale = max(H, W) / fw
+    hal, mtf = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3), stencils.mtf_stencil(neg, scale, 0.0, 1.0)
+    be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
+    eager = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=0, world=1)
+    graphed = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=0, world=1, graph=True)
+    assert graphed.graph and not eager.graph
+    img = torch.from_numpy(synthetic_frame(H, W, seed=5)).cuda()
+    out_e = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    out_g = torch.zeros_like(out_e)
+    u8_g = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    eager.render(img, out_f32=out_e)
+    for k in range(4):  # eager, capture + replay, replay, replay
+        out_g.zero_()
+        graphed.render(img, out_f32=out_g, out_u8=u8_g)
+        assert torch.equal(out_g, out_e), k
+    assert [v[1] is not None for v in graphed._graphs.values()] == [True]
+    img.copy_(torch.from_numpy(synthetic_frame(H, W, seed=6)).cuda())  # new content, same buffers: the graph reads it
+    eager.render(img, out_f32=out_e)
+    graphed.render(img, out_f32=out_g, out_u8=u8_g)
+    assert torch.equal(out_g, out_e)
+    other = torch.zeros_like(out_e)  # another output buffer: eager once, then its own graph
+    for _ in range(3):
+        graphed.render(img, out_f32=other)
+        assert torch.equal(other, out_e)
+    assert len(graphed._graphs) == 2
+    proc.close()
+
+
+def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tmp_path):
+    """bench.py's N > 1 path end to end on a one-GPU box: torch.distributed.run with two ranks over gloo that share cuda:0 (RCCL
+    refuses two ranks on one device; only the transport differs from the real run).  The line must say n_gpus 2 and strong
+    scaling, and with the direct stencils (tile-independent tap order) the sharded frame's checksum equals the whole frame's."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "cfg3_45mp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alone", "--checksum",
+              "--direct-stencils"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--backend", "gloo", "--same-device"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900,
+                         env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "strong" and l1["n_gpus"] == 1
+    assert l2["metric"] == l1["metric"] and l2["unit"] == "MP/s" and l2["value"] > 0
+    assert "row-sharded over 2 GPUs" in l2["config"]["sharding"]
+    assert l2["checksum"] == l1["checksum"]
+    assert l2["roofline"]["peak"] == 2 * l1["roofline"]["peak"]
