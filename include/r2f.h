@@ -197,6 +197,31 @@ int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef);
  * (log1p, 3-bin smoothing, bar image) is host work: raw2film_amd/histogram.py. */
 int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint32_t* counts, void* stream);
 
+/* The CPU processor's last step (cpu_processor.py:411-412 -> utils.resolution_scaling, utils.py:226-236): cv.resize(uint8 frame,
+ * INTER_AREA) when the rendered (and canvas-framed) frame is larger than the requested resolution.  src / dst: uint8
+ * (H, W, 3) / (out_h, out_w, 3) on the device, out_h <= H, out_w <= W. */
+int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
+
+/* The GPU processor's preview blit, shaders/copy_to_int.wgsl as bound by gpu_processor.py:1416-1539: the display-referred float
+ * frame (H, W, 3) sampled bilinearly (clamp to edge) into an RGBA8 destination (dst_h, dst_w, 4): inside the scaled image the
+ * sample (alpha 255), elsewhere inside the canvas bounds the canvas colour, transparent outside.  The transform is the shader's
+ * uniform block (raw2film_amd.geometry.blit_transform computes it like _bind_copy_to_dst). */
+typedef struct r2f_blit {
+    float scale_x, scale_y;    /* 1 / rendered size of the image inside the destination, in destination pixels */
+    float offset_x, offset_y;  /* its top-left corner */
+    float canvas_min_x, canvas_min_y, canvas_max_x, canvas_max_y;
+    float canvas_color[3];     /* 0..1 */
+} r2f_blit;
+int r2f_blit_rgba8(r2f_ctx* ctx, const float* src_f32_hwc, int H, int W, uint8_t* dst_rgba, int dst_h, int dst_w, const r2f_blit* t,
+                   void* stream);
+
+/* shaders/histogram.wgsl pass2_process + pass3_render and shaders/scale_texture.wgsl (gpu_processor.py:1245-1285, 1883-1889) on
+ * the counts of r2f_histogram_u8: log1p of the normalised counts, 3-bin smoothing, bar heights, the (height, 256, 4) RGBA bar
+ * image coloured by mix_table_rgba (HOST, 8 x 4 bytes, index is_r * 4 + is_g * 2 + is_b) and, when target_rgba is given, its
+ * nearest-neighbour copy into a (target_h, target_w, 4) widget texture.  counts / image / target are device pointers. */
+int r2f_histogram_render(r2f_ctx* ctx, const uint32_t* counts, const uint8_t* mix_table_rgba, int height, uint8_t* image_rgba,
+                         uint8_t* target_rgba, int target_h, int target_w, void* stream);
+
 /* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
  * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
 int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,

@@ -42,6 +42,14 @@ class Planes(C.Structure):
     ]
 
 
+class Blit(C.Structure):  # r2f_blit: the uniform block of shaders/copy_to_int.wgsl
+    _fields_ = [
+        ("scale_x", C.c_float), ("scale_y", C.c_float), ("offset_x", C.c_float), ("offset_y", C.c_float),
+        ("canvas_min_x", C.c_float), ("canvas_min_y", C.c_float), ("canvas_max_x", C.c_float), ("canvas_max_y", C.c_float),
+        ("canvas_color", C.c_float * 3),
+    ]
+
+
 _P = C.POINTER
 _fp = C.c_void_p  # float* (host numpy or device) passed as an address
 _SIGNATURES = {
@@ -125,6 +133,12 @@ _SIGNATURES = {
     ),
     "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "r2f_resize_area_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "r2f_blit_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _P(Blit), C.c_void_p]),
+    "r2f_histogram_render": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    ),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

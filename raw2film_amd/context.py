@@ -343,6 +343,52 @@ class HipContext:
                                                      out.data_ptr(), int(out_h), int(out_w), self._stream()))
         return out
 
+    def resize_area_u8(self, image_u8, out_h: int, out_w: int):
+        """cv.resize(uint8 (H, W, 3), (out_w, out_h), interpolation=cv.INTER_AREA), shrinking, on the device (utils.py:226-236 as
+        the CPU processor applies it to the finished frame, cpu_processor.py:411-412)."""
+        torch = self._torch
+        if not (image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.is_contiguous() and image_u8.dim() == 3
+                and image_u8.shape[2] == 3):
+            raise ValueError("resize_area_u8 needs a contiguous uint8 (H, W, 3) CUDA tensor")
+        out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.r2f_resize_area_u8(self._h, image_u8.data_ptr(), int(image_u8.shape[0]), int(image_u8.shape[1]),
+                                                 out.data_ptr(), int(out_h), int(out_w), self._stream()))
+        return out
+
+    def blit_rgba8(self, image_f32, dst_rgba, transform: dict):
+        """shaders/copy_to_int.wgsl: the float (H, W, 3) frame letterboxed into the uint8 (h, w, 4) destination tensor.
+        `transform`: the dict of geometry.blit_transform (the shader's uniform block)."""
+        torch = self._torch
+        if not (image_f32.is_cuda and image_f32.dtype == torch.float32 and image_f32.is_contiguous() and image_f32.dim() == 3
+                and image_f32.shape[2] == 3):
+            raise ValueError("blit_rgba8 needs a contiguous float32 (H, W, 3) CUDA tensor")
+        if not (dst_rgba.is_cuda and dst_rgba.dtype == torch.uint8 and dst_rgba.is_contiguous() and dst_rgba.dim() == 3
+                and dst_rgba.shape[2] == 4):
+            raise ValueError("blit_rgba8 needs a contiguous uint8 (h, w, 4) CUDA destination")
+        t = _lib.Blit(transform["scale_x"], transform["scale_y"], transform["offset_x"], transform["offset_y"],
+                      transform["canvas_min_x"], transform["canvas_min_y"], transform["canvas_max_x"], transform["canvas_max_y"],
+                      (C.c_float * 3)(*transform["canvas_color"]))
+        self._check(self._lib.r2f_blit_rgba8(self._h, image_f32.data_ptr(), int(image_f32.shape[0]), int(image_f32.shape[1]),
+                                             dst_rgba.data_ptr(), int(dst_rgba.shape[0]), int(dst_rgba.shape[1]), C.byref(t),
+                                             self._stream()))
+        return dst_rgba
+
+    def histogram_render(self, counts, mix_table, height: int, target=None):
+        """histogram.wgsl passes 2 + 3 (+ scale_texture.wgsl into `target`, a uint8 (h, w, 4) device tensor) from the (3, 256)
+        device counts of `histogram_counts`; returns the (height, 256, 4) uint8 device bar image."""
+        torch = self._torch
+        mix = np.ascontiguousarray(np.asarray(mix_table, dtype=np.uint8).reshape(8, 4))
+        image = torch.empty((int(height), 256, 4), dtype=torch.uint8, device=self.device)
+        counts = counts.contiguous()
+        if target is not None and not (target.is_cuda and target.dtype == torch.uint8 and target.is_contiguous() and target.dim() == 3
+                                       and target.shape[2] == 4):
+            raise ValueError("histogram_render needs a contiguous uint8 (h, w, 4) CUDA target")
+        self._check(self._lib.r2f_histogram_render(
+            self._h, counts.data_ptr(), mix.ctypes.data, int(height), image.data_ptr(),
+            target.data_ptr() if target is not None else None, int(target.shape[0]) if target is not None else 0,
+            int(target.shape[1]) if target is not None else 0, self._stream()))
+        return image
+
     def stencil_stats(self, which: int):
         """Per channel: dict(entries, rowsteps, phases, sym, unrolled, kh, kw, q, fft, window) of the device form of stencil `which`
         (bench.py); fft = 1: the channel takes the FFT form, window = (rows, columns) of its last launch or None."""

@@ -1546,6 +1546,39 @@ int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, u
     return R2F_OK;
 }
 
+int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (!src_hwc || !dst_hwc || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || out_h > H || out_w > W)
+        return fail(ctx, R2F_EINVAL, "resize_area_u8: the target must be a non-empty frame no larger than the source");
+    R2F_HIP(ctx, launch_resize_area_u8(src_hwc, H, W, dst_hwc, out_h, out_w, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_blit_rgba8(r2f_ctx* ctx, const float* src_f32_hwc, int H, int W, uint8_t* dst_rgba, int dst_h, int dst_w, const r2f_blit* t,
+                   void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (!src_f32_hwc || !dst_rgba || !t || H <= 0 || W <= 0 || dst_h <= 0 || dst_w <= 0)
+        return fail(ctx, R2F_EINVAL, "blit: bad arguments");
+    if (reinterpret_cast<uintptr_t>(dst_rgba) & 3u) return fail(ctx, R2F_EINVAL, "blit: the destination must be 4-byte aligned");
+    R2F_HIP(ctx, launch_blit_rgba8(src_f32_hwc, H, W, dst_rgba, dst_h, dst_w, *t, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_histogram_render(r2f_ctx* ctx, const uint32_t* counts, const uint8_t* mix_table_rgba, int height, uint8_t* image_rgba,
+                         uint8_t* target_rgba, int target_h, int target_w, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (!counts || !mix_table_rgba || !image_rgba || height <= 0 || (target_rgba && (target_h <= 0 || target_w <= 0)))
+        return fail(ctx, R2F_EINVAL, "histogram_render: bad arguments");
+    if ((reinterpret_cast<uintptr_t>(image_rgba) & 3u) || (reinterpret_cast<uintptr_t>(target_rgba) & 3u))
+        return fail(ctx, R2F_EINVAL, "histogram_render: images must be 4-byte aligned");
+    R2F_HIP(ctx, launch_histogram_render(counts, mix_table_rgba, height, image_rgba, target_rgba, target_h, target_w,
+                                         static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
 static int chroma_weights(r2f_ctx* ctx, int size, ChromaArgs& a) {
     // gaussian_kernel_1d(2*size+1, 0.3*((taps-1)/2 - 1) + 0.8), effects.py:421-435,554-556: exp in double, float32 taps
     // normalised by their float32 sum

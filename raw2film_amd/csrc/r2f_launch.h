@@ -4,6 +4,8 @@
 #include <cstdint>
 #include "r2f_device.h"
 
+struct r2f_blit;
+
 namespace r2f {
 
 struct FrontArgs {
@@ -232,6 +234,11 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
 hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s);
 hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s);
+// r2f_post.hip
+hipError_t launch_resize_area_u8(const uint8_t* src, int H, int W, uint8_t* dst, int out_h, int out_w, hipStream_t s);
+hipError_t launch_blit_rgba8(const float* src, int H, int W, uint8_t* dst, int dst_h, int dst_w, const ::r2f_blit& t, hipStream_t s);
+hipError_t launch_histogram_render(const uint32_t* counts, const uint8_t* mix_rgba, int height, uint8_t* image, uint8_t* target, int th,
+                                   int tw, hipStream_t s);
 hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s);
 hipError_t launch_chroma_h(const ChromaArgs& a, hipStream_t s);
 hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s);

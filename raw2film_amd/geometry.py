@@ -125,3 +125,47 @@ def add_canvas(image, canvas_mode: str, canvas_scale: float = 1.0, canvas_ratio:
     canvas[...] = torch.tensor(color, dtype=torch.uint8, device=image.device)
     canvas[oy:oy + h, ox:ox + w] = image
     return canvas
+
+
+def blit_transform(src_size, dst_size, pipeline_resolution=None, output_resolution=None, canvas_resolution=None,
+                   canvas_color=(255, 255, 255)) -> dict:
+    """The uniform block of shaders/copy_to_int.wgsl as GpuProcessor._bind_copy_to_dst computes it
+    (gpu_processor.py:1416-1515): where the rendered frame (src_size = (w, h)) lands inside a destination of dst_size = (w, h)
+    -- letterboxed to the aspect of the canvas (or of the output / pipeline resolution), the image itself scaled by
+    output / canvas inside the canvas area -- plus the canvas bounds and colour.  All sizes are (width, height) like upstream's."""
+    src_w, src_h = src_size
+    dst_w, dst_h = dst_size
+    has_canvas = canvas_resolution is not None and canvas_resolution[0] > 0
+    if has_canvas:
+        content_w, content_h = canvas_resolution
+    elif output_resolution is not None and output_resolution[0] > 0:
+        content_w, content_h = output_resolution
+    else:
+        content_w, content_h = pipeline_resolution if pipeline_resolution is not None else (src_w, src_h)
+    src_aspect = content_w / content_h
+    dst_aspect = dst_w / dst_h
+    if src_aspect > dst_aspect:
+        canvas_render_w, canvas_render_h = dst_w, dst_w / src_aspect
+        canvas_offset_x, canvas_offset_y = 0.0, (dst_h - canvas_render_h) / 2.0
+    else:
+        canvas_render_w, canvas_render_h = dst_h * src_aspect, dst_h
+        canvas_offset_x, canvas_offset_y = (dst_w - canvas_render_w) / 2.0, 0.0
+    if has_canvas:
+        cmin_x, cmin_y = canvas_offset_x, canvas_offset_y
+        cmax_x, cmax_y = canvas_offset_x + canvas_render_w, canvas_offset_y + canvas_render_h
+    else:
+        cmin_x = cmin_y = cmax_x = cmax_y = 0.0
+    raw = canvas_color if canvas_color is not None else (255, 255, 255)
+    color = tuple(c / 255.0 if max(raw) > 1.0 else float(c) for c in raw[:3])
+    if canvas_resolution is not None and output_resolution is not None:
+        target_w, target_h = output_resolution
+        render_w = canvas_render_w * (target_w / content_w)
+        render_h = canvas_render_h * (target_h / content_h)
+        offset_x = canvas_offset_x + (canvas_render_w - render_w) / 2.0
+        offset_y = canvas_offset_y + (canvas_render_h - render_h) / 2.0
+    else:
+        render_w, render_h = canvas_render_w, canvas_render_h
+        offset_x, offset_y = canvas_offset_x, canvas_offset_y
+    return {"scale_x": 1.0 / render_w, "scale_y": 1.0 / render_h, "offset_x": offset_x, "offset_y": offset_y,
+            "canvas_min_x": cmin_x, "canvas_min_y": cmin_y, "canvas_max_x": cmax_x, "canvas_max_y": cmax_y,
+            "canvas_color": color}

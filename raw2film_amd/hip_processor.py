@@ -188,6 +188,9 @@ class HipProcessor:
         if resolution is None and max_scale is not None:
             resolution = (h, w)
         resize_to, upscale_to = None, None
+        # what CpuProcessor.load_image returns as `orig_resolution` (cpu_processor.py:122) and process() hands to the final
+        # resolution_scaling (cpu_processor.py:411-412)
+        final_resolution = (int(resolution[0]), int(resolution[1])) if resolution is not None else None
         if resolution is not None:
             resolution = (int(resolution[0]), int(resolution[1]))
             scale = max(resolution) / max(frame_width, frame_height)
@@ -218,6 +221,7 @@ class HipProcessor:
         image = np.ascontiguousarray(image, dtype=np.float32)
         return {
             "image_array": image,
+            "final_resolution": final_resolution,
             "output_resolution": (out_w, out_h),
             "canvas_resolution": canvas_res,
             "pipeline_resolution": (w, h),
@@ -257,9 +261,11 @@ class HipProcessor:
                 sharpness=True, sharpening_strength=0.0, sharpening_sigma=1.0, chroma_nr=0, grain=2,
                 highlight_burn=0.0, burn_scale=50.0, half_size=True, cache=True, color_masking=None, max_scale=400.0,
                 seed=None, **_):
-        """Load (decoded) frame and render it: np.uint8 (H, W, 3), like cpu_processor.py:414."""
-        if dst_texture is not None or histogram_texture is not None:
-            raise NotImplementedError("wgpu destination textures are not supported; use the bitmap branch (gui.py:2219-2228)")
+        """Load (decoded) frame and render it: np.uint8 (H, W, 3), like cpu_processor.py:414 -- including the CPU processor's
+        last step, resolution_scaling of the finished (canvas-framed) frame to the requested resolution (cpu_processor.py:411-412).
+        With `dst_texture` (a uint8 (h, w, 4) CUDA tensor standing in for the preview widget's wgpu texture) the call behaves
+        like GpuProcessor.process with a destination (gpu_processor.py:1865-1890): the frame is letterboxed into it on the
+        device, `histogram_texture` (same kind of tensor) receives the histogram image, and None is returned."""
         payload = self.extract_image_data_cpu(
             src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
             half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio,
@@ -275,13 +281,31 @@ class HipProcessor:
             sharpening_strength=sharpening_strength, sharpening_sigma=sharpening_sigma, grain=grain,
             highlight_burn=highlight_burn, burn_scale=burn_scale, color_masking=color_masking, seed=seed,
             canvas_mode=canvas_mode, canvas_scale=canvas_scale, canvas_ratio=canvas_ratio,
+            dst_texture=dst_texture, histogram_texture=histogram_texture, final_scaling="cpu",
         )
 
+    def _check_texture(self, t, what):
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 4
+                and t.is_contiguous()):
+            raise NotImplementedError(f"{what}: wgpu textures are not supported; pass a contiguous uint8 (h, w, 4) CUDA tensor "
+                                      "(or use the bitmap branch, gui.py:2219-2228)")
+
     def process_preloaded(self, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture=None,
-                          histogram_texture=None, **settings):
-        """PHASE 2 (gpu_processor.py:1643-1693): upload the payload and run the device pipeline."""
-        if dst_texture is not None or histogram_texture is not None:
-            raise NotImplementedError("wgpu destination textures are not supported")
+                          histogram_texture=None, final_scaling="gpu", **settings):
+        """PHASE 2 (gpu_processor.py:1643-1693): upload the payload and run the device pipeline.
+
+        final_scaling: "gpu" -- like GpuProcessor, the canvas keeps its size and only a `max_scale` render is scaled back up;
+        "cpu" -- like CpuProcessor.process (cpu_processor.py:411-412), the finished frame, canvas included, is scaled to the
+        requested resolution (INTER_AREA down, LANCZOS4 up).  dst_texture / histogram_texture: see process()."""
+        if dst_texture is not None:
+            self._check_texture(dst_texture, "dst_texture")
+        if histogram_texture is not None:
+            self._check_texture(histogram_texture, "histogram_texture")
+            if dst_texture is None:
+                raise ValueError("histogram_texture needs dst_texture (gpu_processor.py:1883: the histogram is only drawn on the "
+                                 "destination-texture branch)")
         torch = self._torch
         image = cpu_payload["image_array"]
         if isinstance(image, np.ndarray):
@@ -298,16 +322,38 @@ class HipProcessor:
             image, layout = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"], layout=layout), "chw"
         if cpu_payload.get("resize_to"):  # preview down-scale (cv.INTER_AREA), after the NR like cpu_processor.py:119-134
             image, layout = self.ctx.resize_area(image.contiguous(), *cpu_payload["resize_to"], layout=layout), "chw"
-        _, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True,
-                                           layout=layout, **settings)
+        out_f32, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=dst_texture is not None,
+                                                 want_u8=True, layout=layout, **settings)
+        if dst_texture is not None:
+            # GpuProcessor's destination branch (gpu_processor.py:1865-1890): letterbox the float frame into the widget's
+            # texture with copy_to_int.wgsl's transform, draw the histogram into its own texture, return nothing
+            H, W = int(out_f32.shape[0]), int(out_f32.shape[1])
+            color = None
+            if settings.get("canvas_mode", "No") != "No":
+                _, color, _ = geometry.canvas_layout((H, W), settings["canvas_mode"], settings.get("canvas_scale", 1.0),
+                                                     settings.get("canvas_ratio", 1.0))
+            t = geometry.blit_transform((W, H), (int(dst_texture.shape[1]), int(dst_texture.shape[0])),
+                                        pipeline_resolution=cpu_payload.get("pipeline_resolution"),
+                                        output_resolution=cpu_payload.get("output_resolution"),
+                                        canvas_resolution=cpu_payload.get("canvas_resolution"), canvas_color=color)
+            self.ctx.blit_rgba8(out_f32, dst_texture, t)
+            self.last_output = out_u8
+            if histogram_texture is not None:
+                from . import histogram
+
+                self.ctx.histogram_render(self.ctx.histogram_counts(out_u8), histogram.MIX_TABLE, 256, target=histogram_texture)
+            return None
         # canvas on the device result (cpu_processor.py:409 / copy_to_int.wgsl): a paste, no arithmetic
         out_u8 = geometry.add_canvas(out_u8, settings.get("canvas_mode", "No"), settings.get("canvas_scale", 1.0),
                                      settings.get("canvas_ratio", 1.0))
-        up = cpu_payload.get("upscale_to")
-        if up:  # cpu_processor.py:411-412 -> utils.resolution_scaling -> cv.resize(INTER_LANCZOS4) on the uint8 frame
-            f = min(up[0] / out_u8.shape[0], up[1] / out_u8.shape[1])
-            if f > 1:
-                out_u8 = self.ctx.resize_lanczos4_u8(out_u8.contiguous(), round(out_u8.shape[0] * f), round(out_u8.shape[1] * f))
+        target = cpu_payload.get("final_resolution") if final_scaling == "cpu" else cpu_payload.get("upscale_to")
+        if target:  # cpu_processor.py:411-412 -> utils.resolution_scaling (utils.py:226-244) on the uint8 frame
+            f = min(target[0] / out_u8.shape[0], target[1] / out_u8.shape[1])
+            size = (round(out_u8.shape[0] * f), round(out_u8.shape[1] * f))
+            if f > 1:  # cv.INTER_LANCZOS4
+                out_u8 = self.ctx.resize_lanczos4_u8(out_u8.contiguous(), *size)
+            elif f < 1 and final_scaling == "cpu":  # cv.INTER_AREA: the CPU processor shrinks the canvas-framed frame
+                out_u8 = self.ctx.resize_area_u8(out_u8.contiguous(), *size)
         self.last_output = out_u8
         return out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
 

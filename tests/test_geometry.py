@@ -80,3 +80,25 @@ def test_oracle_warp_is_the_identity_for_the_identity_matrix_and_zero_outside():
     assert np.allclose(shifted[:, :-1], 0.5 * (img[:, :-1] + img[:, 1:]))
     assert np.allclose(shifted[:, -1], 0.5 * img[:, -1])  # the right neighbour is the constant border 0
     assert not st.warp_affine_linear(img, np.array([[1, 0, 100.0], [0, 1, 0]], float)).any()
+
+
+def test_blit_transform_matches_the_reference_uniform_block(golden_dir):
+    """geometry.blit_transform against the twelve floats GpuProcessor._bind_copy_to_dst hands to copy_to_int.wgsl
+    (tools/make_golden_blit.py executed the reference's own method): 240 source / destination / output / canvas / colour cases."""
+    import os
+
+    import numpy as np
+
+    from raw2film_amd import geometry
+
+    g = np.load(os.path.join(golden_dir, "blit_transform.npz"))
+    for case, want in zip(g["cases"], g["uniforms"]):
+        src, dst = tuple(case[0:2]), tuple(case[2:4])
+        out_res = None if case[4] < 0 else tuple(case[4:6])
+        can_res = None if case[6] < 0 else tuple(case[6:8])
+        color = None if case[8] < 0 else tuple(case[8:11])
+        t = geometry.blit_transform(src, dst, pipeline_resolution=src, output_resolution=out_res, canvas_resolution=can_res,
+                                    canvas_color=color)
+        got = np.array([t["scale_x"], t["scale_y"], t["offset_x"], t["offset_y"], t["canvas_min_x"], t["canvas_min_y"],
+                        t["canvas_max_x"], t["canvas_max_y"], *t["canvas_color"], 0.0], dtype=np.float32)
+        np.testing.assert_array_equal(got, want)

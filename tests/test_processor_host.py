@@ -250,3 +250,29 @@ def test_lens_correction_is_refused_only_when_the_reference_would_correct(proc):
     HipProcessor.extract_image_data_cpu(proc, frame, cam="cam", lens="lens", lens_correction=False)
     with pytest.raises(NotImplementedError, match="lens correction"):
         HipProcessor.extract_image_data_cpu(proc, frame, cam="cam", lens="lens", lens_correction=True)
+
+
+def test_icc_transform_is_applied_to_the_output_lut_in_8_bits(proc):
+    """cpu_processor.py:255-263: with an ICC transform the 3-D LUT itself goes through (lut * 255).astype(uint8) -> PIL
+    ImageCms.applyTransform -> / 255 before it is uploaded; the transform is part of the cache key."""
+    from PIL import Image, ImageCms
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    uploaded = []
+    proc.ctx.set_lut3d = lambda lut: uploaded.append(np.array(lut, copy=True))
+    srgb = ImageCms.createProfile("sRGB")
+    to_lab = ImageCms.buildTransform(srgb, srgb, "RGB", "RGB", renderingIntent=ImageCms.Intent.PERCEPTUAL)
+    proc.load_output_lut(neg, prt, icc_transform=None, color_masking=1.0)
+    proc.load_output_lut(neg, prt, icc_transform=to_lab, color_masking=1.0)
+    proc.load_output_lut(neg, prt, icc_transform=to_lab, color_masking=1.0)  # unchanged -> cached
+    assert len(uploaded) == 2
+    plain, icc = uploaded
+    # the same steps by hand, as the reference spells them
+    lut = (plain * 255).astype(np.uint8)
+    img = Image.fromarray(lut.reshape(lut.shape[0], -1, lut.shape[-1]))
+    ImageCms.applyTransform(img, to_lab, inPlace=True)
+    want = (np.array(img, np.uint8).reshape(lut.shape) / 255.0).astype(np.float32)
+    np.testing.assert_array_equal(icc, want)
+    assert icc.dtype == np.float32 and len(np.unique(np.round(icc * 255))) <= 256
+    assert np.abs(icc - plain).max() <= 1.5 / 255 and not np.array_equal(icc, plain)  # 8-bit quantisation happened
