@@ -191,6 +191,14 @@ int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, c
 int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
 int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef);
 
+/* Pre-path up-scale to a preview LARGER than the frame: utils.resolution_scaling's cv.resize(float32 frame, dsize,
+ * interpolation=cv.INTER_LANCZOS4) (utils.py:237-242, called at cpu_processor.py:134).  `in`: a whole H x W float32 frame (any
+ * in_layout); `dst` receives out_h x out_w planes.  r2f_lanczos4_table_f32: the host-side per-destination tables (source index
+ * of tap 3, eight float weights), exported for the tests. */
+int r2f_resize_lanczos4_f32(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
+                            void* stream);
+int r2f_lanczos4_table_f32(int ssize, int dsize, int* ofs, float* coef);
+
 /* Caller-side RGB histogram of the rendered bitmap: the counting loop of utils.generate_histogram (utils.py:160-165; GPU twin
  * histogram.wgsl pass1_accumulate, dispatched at gpu_processor.py:1149).  image_hwc: uint8 (H, W, 3) on the device, 16-byte
  * aligned; counts: 3 x 256 uint32 on the device (R bins, G bins, B bins), overwritten.  The 768-value post-processing

@@ -131,3 +131,41 @@ def histogram_render(counts: np.ndarray, mix_table: np.ndarray, height: int, tar
         sy = ((np.arange(th, dtype=F32) / F32(th)) * F32(height)).astype(np.int64)
         target = image[np.minimum(sy, height - 1)[:, None], np.minimum(sx, 255)[None, :]]
     return image, target, heights
+
+
+def lanczos4_table_f32(ssize: int, dsize: int):
+    """cv::resize's INTER_LANCZOS4 tables for CV_32F: source index of tap 3 and the eight float32 weights of
+    interpolateLanczos4 (oracle.stages.lanczos4_coeffs), no fixed-point conversion."""
+    from . import stages as st
+
+    scale = 1.0 / (float(dsize) / float(ssize))
+    ofs = np.zeros(dsize, dtype=np.int32)
+    coef = np.zeros((dsize, 8), dtype=F32)
+    for d in range(dsize):
+        fx = F32((d + 0.5) * scale - 0.5)
+        sx = int(math.floor(float(fx)))
+        ofs[d] = sx
+        coef[d] = st.lanczos4_coeffs(F32(fx - F32(sx)))
+    return ofs, coef
+
+
+def resize_lanczos4_f32(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """cv.resize(float32 (H, W, 3), (out_w, out_h), interpolation=cv.INTER_LANCZOS4): utils.resolution_scaling's up-scaling
+    branch applied to the float frame before the path (utils.py:237-242, cpu_processor.py:134).  PARITY UNPINNED (no OpenCV
+    here): the generic C++ path -- HResizeLanczos4 sums the 8 products of a row left to right, VResizeLanczos4 the 8 rows top
+    to bottom, float32 with separate roundings, replicated border."""
+    img = np.asarray(img, dtype=F32)
+    H, W = img.shape[:2]
+    xo, xa = lanczos4_table_f32(W, out_w)
+    yo, ya = lanczos4_table_f32(H, out_h)
+    cols = np.clip(xo[:, None] - 3 + np.arange(8)[None, :], 0, W - 1)  # (out_w, 8)
+    hor = None
+    for j in range(8):
+        term = (img[:, cols[:, j], :] * xa[None, :, j, None]).astype(F32)
+        hor = term if hor is None else (hor + term).astype(F32)
+    rows = np.clip(yo[:, None] - 3 + np.arange(8)[None, :], 0, H - 1)  # (out_h, 8)
+    out = None
+    for k in range(8):
+        term = (hor[rows[:, k]] * ya[:, k, None, None]).astype(F32)
+        out = term if out is None else (out + term).astype(F32)
+    return out

@@ -133,6 +133,11 @@ _SIGNATURES = {
     ),
     "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "r2f_resize_lanczos4_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(Planes), C.c_int, C.c_int, C.c_void_p],
+    ),
+    "r2f_lanczos4_table_f32": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "r2f_resize_area_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "r2f_blit_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _P(Blit), C.c_void_p]),
     "r2f_histogram_render": (

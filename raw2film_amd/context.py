@@ -316,6 +316,17 @@ class HipContext:
                                               self._stream()))
         return out
 
+    def resize_lanczos4_f32(self, image, out_h, out_w, layout=None):
+        """Pre-path cv.resize(float32 frame, INTER_LANCZOS4) up-scale of a whole frame -> (3, out_h, out_w) planes."""
+        torch = self._torch
+        self._check_image(image)
+        layout, H, W = self.layout_of(image, layout)
+        out = torch.empty((3, int(out_h), int(out_w)), dtype=torch.float32, device=self.device)
+        pd = self.planes(out, 0)
+        self._check(self._lib.r2f_resize_lanczos4_f32(self._h, image.data_ptr(), layout, H, W, C.byref(pd), int(out_h), int(out_w),
+                                                      self._stream()))
+        return out
+
     def warp_affine(self, image, m_dst_to_src, window=None, layout=None):
         """cv.warpAffine(image, M, same size, INTER_LINEAR) restricted to `window` = (row0, col0, rows, cols) -> (3, rows, cols)
         planes.  m_dst_to_src: inverse of M, 2 x 3 (geometry.rotation_plan)."""

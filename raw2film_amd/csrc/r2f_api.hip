@@ -85,6 +85,7 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
+    DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
     int lanczos_key[4] = {0, 0, 0, 0};
     int opt_xcd_band = 0;  // tile columns per band of the xcd_remap = 2 order; 0 = auto
     int opt_variant = -1;  // -1 auto
@@ -893,6 +894,7 @@ void r2f_destroy(r2f_ctx* ctx) {
         }
     for (auto& t : ctx->tile_order) t.buf.release();
     ctx->lanczos_buf.release();
+    ctx->lanczos_f32_buf.release();
     ctx->grain_fixed_w.release();
     for (auto& b : ctx->stencil_fixed_w) b.release();
     ctx->fft_tw.release();
@@ -1512,6 +1514,45 @@ int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef) {
             coef[d * 8 + k] = (short)std::min<long>(std::max<long>(v, -32768), 32767);
         }
     }
+    return R2F_OK;
+}
+
+// cv::resize's tables for INTER_LANCZOS4 on CV_32F: the same source index and interpolateLanczos4 weights, kept as floats.
+int r2f_lanczos4_table_f32(int ssize, int dsize, int* ofs, float* coef) {
+    if (ssize <= 0 || dsize <= 0 || !ofs || !coef) return R2F_EINVAL;
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        const int sx = (int)std::floor(fx);
+        fx -= sx;
+        ofs[d] = sx;
+        lanczos4_coeffs(fx, coef + 8 * (size_t)d);
+    }
+    return R2F_OK;
+}
+
+int r2f_resize_lanczos4_f32(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
+                            void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (!in || in_layout < 0 || in_layout > 2 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
+        return fail(ctx, R2F_EINVAL, "resize_lanczos4_f32: bad arguments");
+    int rc = check_rows(ctx, "lanczos dst", dst, 0, out_h);
+    if (rc) return rc;
+    const size_t n_ofs = (size_t)out_w + out_h, n_coef = 8 * n_ofs;
+    const size_t coef_off = (n_ofs * sizeof(int) + 15) / 16 * 16;
+    std::vector<unsigned char> host(coef_off + n_coef * sizeof(float));
+    int* ofs = reinterpret_cast<int*>(host.data());
+    float* coef = reinterpret_cast<float*>(host.data() + coef_off);
+    r2f_lanczos4_table_f32(W, out_w, ofs, coef);
+    r2f_lanczos4_table_f32(H, out_h, ofs + out_w, coef + 8 * (size_t)out_w);
+    rc = upload(ctx, ctx->lanczos_f32_buf, host.data(), host.size());  // (waits for renders in flight, like every table upload)
+    if (rc) return rc;
+    const unsigned char* base = static_cast<const unsigned char*>(ctx->lanczos_f32_buf.p);
+    const int* xofs = reinterpret_cast<const int*>(base);
+    const float* xcoef = reinterpret_cast<const float*>(base + coef_off);
+    R2F_HIP(ctx, launch_lanczos4_f32(in, in_layout, H, W, to_dev(dst), out_h, out_w, xofs, xcoef, xofs + out_w, xcoef + 8 * (size_t)out_w,
+                                     static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
 

@@ -107,6 +107,68 @@ __global__ __launch_bounds__(256) void resize_area_u8_kernel(const AreaU8Args a)
     for (int c = 0; c < 3; ++c) o[c] = sat_u8(sum[c]);
 }
 
+// ---------------------------------------------------------------------------------------------------- LANCZOS4, float32
+// cv.resize(float32 frame, INTER_LANCZOS4): utils.resolution_scaling's other branch (utils.py:237-242), taken BEFORE the path
+// when the preview is larger than the frame (cpu_processor.py:134).  cv::resize's generic path for CV_32F: float weights from
+// interpolateLanczos4 (host tables, r2f_api.hip), HResizeLanczos4 = the 8 products of a row summed left to right, then
+// VResizeLanczos4 = the 8 rows times beta summed top to bottom; indices outside the frame repeat the edge sample.
+struct LanczosF32Args {
+    const void* in;
+    int in_layout, H, W;
+    DevPlanes dst;
+    int out_h, out_w;
+    const int* xofs;    // out_w: source column of tap 3
+    const float* xcoef;  // out_w x 8
+    const int* yofs;
+    const float* ycoef;
+};
+
+__device__ __forceinline__ void load_px(const void* in_, int layout, int H, int W, int y, int x, float (&v)[3]) {
+    const float* in = static_cast<const float*>(in_);
+    if (layout == R2F_LAYOUT_CHW) {
+        const long long plane = (long long)H * W, o = (long long)y * W + x;
+        v[0] = in[o], v[1] = in[plane + o], v[2] = in[2 * plane + o];
+    } else {
+        const float* p = in + ((long long)y * W + x) * (layout == R2F_LAYOUT_HWC4 ? 4 : 3);
+        v[0] = p[0], v[1] = p[1], v[2] = p[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void lanczos4_f32_kernel(const LanczosF32Args a) {
+#pragma clang fp contract(off)
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= a.out_w || dy >= a.out_h) return;
+    const int sx = a.xofs[dx] - 3, sy = a.yofs[dy] - 3;
+    float wx[8], wy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wx[k] = a.xcoef[dx * 8 + k], wy[k] = a.ycoef[dy * 8 + k];
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int yy = clampi(sy + k, 0, a.H - 1);
+        float h[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v[3];
+            load_px(a.in, a.in_layout, a.H, a.W, yy, clampi(sx + j, 0, a.W - 1), v);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float prod = v[c] * wx[j];
+                h[c] = j == 0 ? prod : h[c] + prod;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float prod = h[c] * wy[k];
+            acc[c] = k == 0 ? prod : acc[c] + prod;
+        }
+    }
+    float* p0 = a.dst.data + (long long)(dy - a.dst.gy0) * a.out_w + dx;
+    p0[0] = acc[0];
+    p0[a.dst.plane_stride] = acc[1];
+    p0[2 * a.dst.plane_stride] = acc[2];
+}
+
 // ---------------------------------------------------------------------------------------------------- preview blit
 struct BlitArgs {
     const float* src;  // (H, W, 3) display-referred float
@@ -214,6 +276,13 @@ __global__ __launch_bounds__(256) void histogram_render_kernel(const HistArgs a)
 hipError_t launch_resize_area_u8(const uint8_t* src, int H, int W, uint8_t* dst, int out_h, int out_w, hipStream_t s) {
     AreaU8Args a{src, dst, H, W, out_h, out_w};
     hipLaunchKernelGGL(resize_area_u8_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lanczos4_f32(const void* in, int in_layout, int H, int W, const DevPlanes& dst, int out_h, int out_w, const int* xofs,
+                               const float* xcoef, const int* yofs, const float* ycoef, hipStream_t s) {
+    LanczosF32Args a{in, in_layout, H, W, dst, out_h, out_w, xofs, xcoef, yofs, ycoef};
+    hipLaunchKernelGGL(lanczos4_f32_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 

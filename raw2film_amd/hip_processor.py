@@ -199,11 +199,9 @@ class HipProcessor:
                 resolution = tuple(round(x * (max_scale / scale)) for x in resolution)
             # utils.resolution_scaling (utils.py:226-244), applied on the device in phase 2
             factor = min(resolution[0] / h, resolution[1] / w)
-            if factor > 1:
-                raise NotImplementedError("up-scaling the float frame before the path (cv.INTER_LANCZOS4 on float32, "
-                                          "utils.py:237-242: a preview larger than the frame) is outside the accelerated path")
-            if factor < 1:
-                resize_to = (round(h * factor), round(w * factor))  # cv.resize(dsize=(round(w f), round(h f)), INTER_AREA)
+            if factor != 1:
+                # cv.resize(dsize=(round(w f), round(h f))): INTER_AREA down, INTER_LANCZOS4 up (a preview larger than the frame)
+                resize_to = (round(h * factor), round(w * factor))
                 h, w = resize_to
         out_h, out_w = h, w
         if upscale_to is not None:  # the uint8 result goes back up with LANCZOS4, same rule (fit inside the target)
@@ -320,8 +318,13 @@ class HipProcessor:
             layout = "chw"
         if cpu_payload.get("chroma_nr"):  # pre-path chroma NR (effects.py:547-561): XYZ planes out, CHW into the pipeline
             image, layout = self.ctx.chroma_nr(image.contiguous(), cpu_payload["chroma_nr"], layout=layout), "chw"
-        if cpu_payload.get("resize_to"):  # preview down-scale (cv.INTER_AREA), after the NR like cpu_processor.py:119-134
-            image, layout = self.ctx.resize_area(image.contiguous(), *cpu_payload["resize_to"], layout=layout), "chw"
+        if cpu_payload.get("resize_to"):  # preview scaling, after the NR like cpu_processor.py:119-134
+            _, h_in, w_in = self.ctx.layout_of(image, layout)
+            rt = cpu_payload["resize_to"]
+            if rt[0] <= h_in and rt[1] <= w_in:  # cv.INTER_AREA
+                image, layout = self.ctx.resize_area(image.contiguous(), *rt, layout=layout), "chw"
+            else:  # cv.INTER_LANCZOS4 on the float frame (utils.py:237-242)
+                image, layout = self.ctx.resize_lanczos4_f32(image.contiguous(), *rt, layout=layout), "chw"
         out_f32, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=dst_texture is not None,
                                                  want_u8=True, layout=layout, **settings)
         if dst_texture is not None:

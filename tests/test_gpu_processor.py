@@ -296,3 +296,24 @@ def test_process_with_destination_textures_like_the_gpu_processor(proc):
     assert plain.shape == (H, W, 3)
     with pytest.raises(NotImplementedError):
         proc.process(img, neg, 6, 0.4, dst_texture=object(), **kw)
+
+
+@pytest.mark.parametrize("layout", ["hwc3", "chw"])
+def test_float_lanczos4_upscale_before_the_path(proc, layout):
+    """A preview larger than the frame: cv.resize(float32, INTER_LANCZOS4) on the device, then the pipeline at that size."""
+    from oracle import post
+
+    rng = np.random.default_rng(12)
+    img = rng.uniform(0.0, 2.0, (37, 53, 3)).astype(np.float32)
+    t = torch.from_numpy(img if layout == "hwc3" else np.ascontiguousarray(img.transpose(2, 0, 1))).cuda()
+    got = proc.ctx.resize_lanczos4_f32(t, 90, 129, layout=layout).cpu().numpy().transpose(1, 2, 0)
+    np.testing.assert_array_equal(got, post.resize_lanczos4_f32(img, 90, 129))
+    neg, prt, _ = stocks()
+    kw = dict(print_film=prt, frame_width=36, frame_height=24, exp_kelvin=6000, color_masking=1.0, seed=SEED,
+              halation=False, sharpness=False, grain=0)
+    xyz = st.apply_matrix3x3(rng.uniform(0.2, 0.6, (40, 60, 3)).astype(np.float32), st.REC709_TO_XYZ)  # no negative overshoot
+    out = proc.process(xyz, neg, 6, 0.4, resolution=(100, 150), **kw)
+    assert out.shape == (100, 150, 3)
+    p = oracle_inputs(neg, prt, 150 / 36, halation=False, mtf=False, grain=0, matrix=False)
+    ref = st.to_uint8(st.render(post.resize_lanczos4_f32(xyz, 100, 150), p))
+    assert _u8_close(out, ref)

@@ -40,3 +40,17 @@ def test_flat_frames_stay_flat_and_the_size_rule_is_the_references():
 def test_identity_size_reproduces_the_image():
     img = np.random.default_rng(1).integers(0, 256, (12, 17, 3)).astype(np.uint8)
     assert np.array_equal(st.resize_lanczos4_u8(img, 12, 17), img)
+
+
+@pytest.mark.parametrize("ssize,dsize", [(10, 25), (100, 333), (400, 601), (7, 7), (1, 9)])
+def test_float_tables_of_the_pre_path_upscale_match_the_oracle(ssize, dsize):
+    from oracle import post
+
+    lib = _lib.load()
+    ofs = np.zeros(dsize, np.int32)
+    coef = np.zeros((dsize, 8), np.float32)
+    assert lib.r2f_lanczos4_table_f32(ssize, dsize, ofs.ctypes.data, coef.ctypes.data) == 0
+    o, c = post.lanczos4_table_f32(ssize, dsize)
+    assert np.array_equal(o, ofs) and np.array_equal(c, coef)
+    flat = np.full((5, ssize, 3), 0.375, np.float32)
+    assert np.abs(post.resize_lanczos4_f32(flat, 5, dsize) - 0.375).max() < 1e-6

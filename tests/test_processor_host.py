@@ -123,8 +123,8 @@ def test_out_of_scope_requests_raise(proc):
     img = np.zeros((40, 60, 3), np.float32)
     with pytest.raises(NotImplementedError):
         proc.process("photo.cr3", neg, 6, 0.4)
-    with pytest.raises(NotImplementedError):
-        proc.extract_image_data_cpu(img, resolution=(80, 120))  # a preview larger than the frame: float32 LANCZOS4 before the path
+    up = proc.extract_image_data_cpu(img, resolution=(80, 120))  # a preview larger than the frame: LANCZOS4 on the device
+    assert up["resize_to"] == (80, 120) and up["pipeline_resolution"] == (120, 80)
     with pytest.raises(NotImplementedError):
         proc.process(img, neg, 6, 0.4, dst_texture=object())
 
