@@ -52,7 +52,10 @@ enum {
     R2F_F_MTF = 1u << 2,      /* S5 */
     R2F_F_GRAIN = 1u << 3,    /* S6 (+ the clip of cpu_processor.py:397) */
     R2F_F_GRAIN_MONO = 1u << 4, /* grain == 1: noise_bw.wgsl */
-    R2F_F_BURN = 1u << 5        /* S7 highlight burn (effects.py:396-418), needs burn_* below */
+    R2F_F_BURN = 1u << 5,       /* S7 highlight burn (effects.py:396-418), needs burn_* below */
+    R2F_F_IDENTITY_DONE = 1u << 6 /* r2f_stage_halation only: the channels whose halation stencil is a single tap at the anchor
+                                     (the blue layer of a colour stock, effects.py:248-263) were already finished into the
+                                     density planes by r2f_stage_front_split for rows [y0, y1) -- skip them */
 };
 
 /* `upto` of r2f_stage_front */
@@ -127,6 +130,16 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
 int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
                     int upto, const r2f_planes* dst, float* out_f32_hwc, uint8_t* out_u8_hwc, int out_gy0, int y0,
                     int y1, int W, int H_global, void* stream);
+/* r2f_stage_front(upto = EXPOSURE) for a frame that goes on to r2f_stage_halation, split by what the halation does to each
+ * channel: a channel with a real stencil gets its exposure written to `exposure`; a channel whose halation stencil is ONE tap
+ * at the anchor (f_c = 0: the blue layer of a colour stock) needs no neighbours, so its tap weight, S3 and S4 are applied here
+ * and the result goes straight to `density` -- its exposure plane is not written at all.  Saves that plane's round trip and
+ * the pointwise pass over it.  *finished_mask receives the channels handled that way (bit c); when it is non-zero call
+ * r2f_stage_halation with R2F_F_IDENTITY_DONE.  Whole-frame use only: a row shard's neighbours need the exposure rows of
+ * every channel.  Falls back to plain r2f_stage_front (mask 0) when no channel qualifies or the fast kernel does not apply. */
+int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
+                          const r2f_planes* exposure, const r2f_planes* density, int y0, int y1, int W, int H_global,
+                          int* finished_mask, void* stream);
 /* S2 halation stencil on exposure + S3 log + S4 curve -> density planes. */
 int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,
                        int y0, int y1, int W, int H_global, void* stream);

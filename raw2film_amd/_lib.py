@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
 # enums of include/r2f.h
 LAYOUT_HWC3, LAYOUT_HWC4, LAYOUT_CHW = 0, 1, 2
 KERNEL_HALATION, KERNEL_MTF, KERNEL_GRAIN = 0, 1, 2
-F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO, F_BURN = 1, 2, 4, 8, 16, 32
+F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO, F_BURN, F_IDENTITY_DONE = 1, 2, 4, 8, 16, 32, 64
 UPTO_EXPOSURE, UPTO_DENSITY, UPTO_OUTPUT = 0, 1, 2
 OK, EINVAL, EHIP, ETOOLARGE = 0, -1, -2, -3
 
@@ -133,6 +133,11 @@ _SIGNATURES = {
     ),
     "r2f_stencil_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "r2f_histogram_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "r2f_stage_front_split": (
+        C.c_int,
+        [C.c_void_p, _P(Params), C.c_void_p, C.c_int, C.c_int, C.c_int, _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int,
+         _P(C.c_int), C.c_void_p],
+    ),
     "r2f_resize_lanczos4_f32": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(Planes), C.c_int, C.c_int, C.c_void_p],

@@ -209,6 +209,22 @@ class HipContext:
         )
         self._check(rc)
 
+    def stage_front_split(self, image, params, exposure, density, *, in_gy0=0, exposure_gy0=0, density_gy0=0, y0=None, y1=None,
+                          H_global=None, layout=None) -> int:
+        """S0 + S1 for a frame that goes on to stage_halation: channels with a real halation stencil -> `exposure`; channels
+        whose halation stencil is one tap at the anchor are finished (tap weight, log, curve) straight into `density`.  Returns
+        the mask of channels finished that way: pass it to stage_halation(identity_done=mask)."""
+        self._check_image(image)
+        layout, rows, W = self.layout_of(image, layout)
+        y0 = in_gy0 if y0 is None else y0
+        y1 = in_gy0 + rows if y1 is None else y1
+        H_global = in_gy0 + rows if H_global is None else H_global
+        pe, pd = self.planes(exposure, exposure_gy0), self.planes(density, density_gy0)
+        mask = C.c_int(0)
+        self._check(self._lib.r2f_stage_front_split(self._h, C.byref(params), image.data_ptr(), layout, in_gy0, rows, C.byref(pe),
+                                                    C.byref(pd), y0, y1, W, H_global, C.byref(mask), self._stream()))
+        return mask.value
+
     def _stencil_call(self, fn, first, src, src_gy0, dst, dst_gy0, y0, y1, H_global):
         ps, pd = self.planes(src, src_gy0), self.planes(dst, dst_gy0)
         W = int(src.shape[2])
@@ -216,7 +232,10 @@ class HipContext:
             raise ValueError("source and destination widths differ")
         self._check(fn(self._h, first, C.byref(ps), C.byref(pd), y0, y1, W, H_global, self._stream()))
 
-    def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):
+    def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global, identity_done=0):
+        if identity_done:  # stage_front_split already wrote the identity channels' density for these rows
+            params = _lib.Params.from_buffer_copy(params)
+            params.flags |= _lib.F_IDENTITY_DONE
         self._stencil_call(self._lib.r2f_stage_halation, C.byref(params), exposure, src_gy0, density, dst_gy0, y0, y1, H_global)
 
     def stage_mtf(self, density_in, density_out, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):

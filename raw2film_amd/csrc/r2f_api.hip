@@ -750,8 +750,18 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     return R2F_OK;
 }
 
+// Is channel c's stencil a single tap at the anchor?  (*w = its weight)
+bool single_tap_channel(const StencilSet& set, int c, float* w) {
+    int tb[4];
+    tap_box(set, c, tb);
+    if (!(tb[0] == tb[1] && tb[2] == tb[3] && tb[0] == set.kh / 2 && tb[2] == set.kw / 2)) return false;
+    if (w) *w = set.host[((size_t)tb[0] * set.kw + tb[2]) * set.kc + (set.kc == 1 ? 0 : c)];
+    return true;
+}
+
+// skip_identity: the single-tap channels were finished by the front kernel (r2f_stage_front_split) -- leave them alone.
 int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
-                int epilogue, float log_eps, hipStream_t s) {
+                int epilogue, float log_eps, hipStream_t s, bool skip_identity = false) {
     if (y1 <= y0) return R2F_OK;
     if (W <= 0 || H <= 0 || y0 < 0 || y1 > H) return fail(ctx, R2F_EINVAL, "stencil: bad geometry");
     StencilSet& set = ctx->stencil[which];
@@ -816,6 +826,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
             rc = run_stencil_fft(ctx, which, group, ng, src, dst, y0, y1, W, H, epilogue, log_eps, s);
             if (rc) return rc;
         } else if (tb[0] == tb[1] && tb[2] == tb[3] && tb[0] == set.kh / 2 && tb[2] == set.kw / 2 && ctx->opt_ablate == 0) {
+            if (skip_identity) continue;
             TapArgs t;  // a single tap at the anchor: pointwise
             t.src = to_dev(src), t.dst = to_dev(dst);
             t.ch = c, t.y0 = y0, t.y1 = y1, t.W = W;
@@ -1068,9 +1079,29 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
 }
 
 // ------------------------------------------------------------------------------- stages
+static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
+                            const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
+                            int H_global, void* stream, const r2f_planes* finish_dst, int* finished_mask);
+
 int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
                     const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
                     int H_global, void* stream) {
+    return stage_front_impl(ctx, p, in, in_layout, in_gy0, in_rows, upto, dst, out_f32, out_u8, out_gy0, y0, y1, W, H_global, stream,
+                            nullptr, nullptr);
+}
+
+int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
+                          const r2f_planes* exposure, const r2f_planes* density, int y0, int y1, int W, int H_global,
+                          int* finished_mask, void* stream) {
+    if (!finished_mask) return R2F_EINVAL;
+    *finished_mask = 0;
+    return stage_front_impl(ctx, p, in, in_layout, in_gy0, in_rows, R2F_UPTO_EXPOSURE, exposure, nullptr, nullptr, 0, y0, y1, W, H_global,
+                            stream, density, finished_mask);
+}
+
+static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
+                            const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
+                            int H_global, void* stream, const r2f_planes* finish_dst, int* finished_mask) {
     if (!ctx || !p) return R2F_EINVAL;
     R2F_GUARD(ctx);
     if (y1 <= y0) return R2F_OK;
@@ -1118,6 +1149,21 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
     a.vec = vec ? 1 : 0;
     a.blocks_per_cu = ctx->opt_front_blocks;
     a.fast = ctx->opt_front_fast;
+    if (finish_dst && upto == R2F_UPTO_EXPOSURE && a.fast && ctx->stencil[R2F_KERNEL_HALATION].present && ctx->curve.cells) {
+        // channels the halation leaves to a single tap: finish them here when the fast kernel can take the job
+        int rc = check_rows(ctx, "front density dst", finish_dst, y0, y1);
+        if (rc) return rc;
+        FrontArgs f = a;
+        f.finish_dst = to_dev(finish_dst);
+        for (int c = 0; c < 3; ++c)
+            if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &f.finish_w[c])) f.finish_mask |= 1 << c;
+        f.vec = (vec && planes_vec_ok(finish_dst, W)) ? 1 : 0;
+        if (f.finish_mask && f.finish_mask != 7 && front_fast_eligible(f)) {
+            *finished_mask = f.finish_mask;
+            R2F_HIP(ctx, launch_front_fast(f, static_cast<hipStream_t>(stream)));
+            return R2F_OK;
+        }
+    }
     R2F_HIP(ctx, launch_front(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
@@ -1127,7 +1173,7 @@ int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* expo
     if (!ctx || !p) return R2F_EINVAL;
     R2F_GUARD(ctx);
     return run_stencil(ctx, R2F_KERNEL_HALATION, exposure, density, y0, y1, W, H_global, 1, p->log_eps,
-                       static_cast<hipStream_t>(stream));
+                       static_cast<hipStream_t>(stream), (p->flags & R2F_F_IDENTITY_DONE) != 0);
 }
 
 int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1,
@@ -1761,13 +1807,18 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     float* base = static_cast<float*>(workspace);
     r2f_planes A{base, (int64_t)(set_floats / 3), 0, H};
     r2f_planes B{base + set_floats, (int64_t)(set_floats / 3), 0, H};
-    int rc = r2f_stage_front(ctx, p, in, in_layout, 0, H, hal ? R2F_UPTO_EXPOSURE : R2F_UPTO_DENSITY, &A, nullptr, nullptr,
-                             0, 0, H, W, H, stream);
+    int rc, finished = 0;
+    if (hal)  // the halation's identity channels (blue on a colour stock) are finished by the front kernel, straight into B
+        rc = r2f_stage_front_split(ctx, p, in, in_layout, 0, H, &A, &B, 0, H, W, H, &finished, stream);
+    else
+        rc = r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_DENSITY, &A, nullptr, nullptr, 0, 0, H, W, H, stream);
     if (rc) return rc;
     const r2f_planes* cur = &A;
     const r2f_planes* other = &B;
     if (hal) {
-        rc = r2f_stage_halation(ctx, p, cur, other, 0, H, W, H, stream);
+        r2f_params q = *p;
+        if (finished) q.flags |= R2F_F_IDENTITY_DONE;
+        rc = r2f_stage_halation(ctx, &q, cur, other, 0, H, W, H, stream);
         if (rc) return rc;
         std::swap(cur, other);
     }

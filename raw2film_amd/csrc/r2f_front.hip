@@ -121,16 +121,18 @@ __device__ __forceinline__ V3 lut3d_tetra_nonneg(const float4* tex, const int n,
     return o;
 }
 
-template <int LAYOUT, int UPTO, int BY>
+// FIN (with UPTO = EXPOSURE): the channels of a.finish_mask are finished here -- tap weight, log, density curve -- and written
+// to a.finish_dst instead of the exposure planes (r2f_stage_front_split); the curve's cells then sit in LDS like for DENSITY.
+template <int LAYOUT, int UPTO, int BY, bool FIN = false>
 __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     float4* lut_lds = smem4;                                // n x n texels of the 2-D LUT
-    float4* cells_lds = smem4 + a.lut2d.n * a.lut2d.n;      // 3 x (m - 1) curve cells (UPTO >= DENSITY)
+    float4* cells_lds = smem4 + a.lut2d.n * a.lut2d.n;      // 3 x (m - 1) curve cells (UPTO >= DENSITY, or FIN)
     {
         const int tid = threadIdx.y * 64 + threadIdx.x;
         const int nt = a.lut2d.n * a.lut2d.n;
         for (int i = tid; i < nt; i += 64 * BY) lut_lds[i] = a.lut2d.tex[i];
-        if (UPTO >= R2F_UPTO_DENSITY) {
+        if (UPTO >= R2F_UPTO_DENSITY || FIN) {
             const int nc = 3 * (a.curve.m - 1);
             for (int i = tid; i < nc; i += 64 * BY) cells_lds[i] = a.curve.cells[i];
         }
@@ -173,6 +175,11 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             p = lut2d(lut_lds, a.lut2d.n, p);
             if (UPTO == R2F_UPTO_EXPOSURE) {
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
+                if (FIN) {  // same arithmetic as single_tap_kernel with the halation epilogue: w * x, log10, curve
+                    if (a.finish_mask & 1) r[q] = curve_eval_at((const float4*)cells_lds, a.curve, 0, log10_fast(a.finish_w[0] * r[q], a.log_eps));
+                    if (a.finish_mask & 2) g[q] = curve_eval_at((const float4*)cells_lds, a.curve, 1, log10_fast(a.finish_w[1] * g[q], a.log_eps));
+                    if (a.finish_mask & 4) b[q] = curve_eval_at((const float4*)cells_lds, a.curve, 2, log10_fast(a.finish_w[2] * b[q], a.log_eps));
+                }
                 continue;
             }
             float v3[3] = {log10_fast(p.xy.x, a.log_eps), log10_fast(p.xy.y, a.log_eps), log10_fast(p.z, a.log_eps)};
@@ -191,9 +198,12 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         }
         if (UPTO != R2F_UPTO_OUTPUT) {
             float* d0 = a.dst.data + (long long)(gy - a.dst.gy0) * W + x;
-            *reinterpret_cast<float4*>(d0) = make_float4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<float4*>(d0 + a.dst.plane_stride) = make_float4(g[0], g[1], g[2], g[3]);
-            *reinterpret_cast<float4*>(d0 + 2 * a.dst.plane_stride) = make_float4(b[0], b[1], b[2], b[3]);
+            float* f0 = FIN ? a.finish_dst.data + (long long)(gy - a.finish_dst.gy0) * W + x : d0;
+            const long long fs = FIN ? a.finish_dst.plane_stride : 0;
+            *reinterpret_cast<float4*>((FIN && (a.finish_mask & 1)) ? f0 : d0) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>((FIN && (a.finish_mask & 2)) ? f0 + fs : d0 + a.dst.plane_stride) = make_float4(g[0], g[1], g[2], g[3]);
+            *reinterpret_cast<float4*>((FIN && (a.finish_mask & 4)) ? f0 + 2 * fs : d0 + 2 * a.dst.plane_stride) =
+                make_float4(b[0], b[1], b[2], b[3]);
             continue;
         }
         const long long obase = ((long long)(gy - a.out_gy0) * W + x) * 3;
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
 
 size_t fast_lds_bytes(const FrontArgs& a) {
     const size_t lut = (size_t)a.lut2d.n * a.lut2d.n * sizeof(float4);
-    const size_t cells = a.upto >= R2F_UPTO_DENSITY ? (size_t)3 * (a.curve.m > 1 ? a.curve.m - 1 : 0) * sizeof(float4) : 0;
+    const size_t cells = (a.upto >= R2F_UPTO_DENSITY || a.finish_mask) ? (size_t)3 * (a.curve.m > 1 ? a.curve.m - 1 : 0) * sizeof(float4) : 0;
     return lut + cells;
 }
 
@@ -223,12 +233,12 @@ size_t fast_lds_bytes(const FrontArgs& a) {
 // Is the pointwise pass of `a` in the fast kernels' domain?
 bool front_fast_eligible(const FrontArgs& a) {
     if (!a.vec || a.lut2d.n < 2 || (long long)a.W * 16 >= (1ll << 31) || fast_lds_bytes(a) > 144 * 1024) return false;
-    if (a.upto >= R2F_UPTO_DENSITY && !(a.curve.near && a.curve.m >= 2)) return false;
+    if ((a.upto >= R2F_UPTO_DENSITY || a.finish_mask) && !(a.curve.near && a.curve.m >= 2)) return false;
     if (a.upto == R2F_UPTO_OUTPUT && !(a.lut3d_mode == 0 && a.lut3d.n >= 2 && a.lut3d.n <= 256)) return false;
     return true;
 }
 
-template <int UPTO, int BY>
+template <int UPTO, int BY, bool FIN = false>
 static void launch_fast(const FrontArgs& a, hipStream_t s) {
     const int quads = (a.W + 3) / 4, gx = (quads + 63) / 64;
     const int row_groups = (a.y1 - a.y0 + BY - 1) / BY;
@@ -240,16 +250,18 @@ static void launch_fast(const FrontArgs& a, hipStream_t s) {
     gy = gy > row_groups ? row_groups : (gy < 1 ? 1 : gy);
     const dim3 grid(gx, gy), block(64, BY);
     switch (a.in_layout) {
-        case R2F_LAYOUT_CHW: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_CHW, UPTO, BY>), grid, block, lds, s, a); break;
-        case R2F_LAYOUT_HWC3: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_HWC3, UPTO, BY>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_HWC4, UPTO, BY>), grid, block, lds, s, a); break;
+        case R2F_LAYOUT_CHW: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_CHW, UPTO, BY, FIN>), grid, block, lds, s, a); break;
+        case R2F_LAYOUT_HWC3: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_HWC3, UPTO, BY, FIN>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_HWC4, UPTO, BY, FIN>), grid, block, lds, s, a); break;
     }
 }
 
 hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s) {
     // more than 80 KB of tables: one workgroup per CU, so give it 16 waves; else two (or three) of 8
     const bool big = fast_lds_bytes(a) > 80 * 1024;
-    if (a.upto == R2F_UPTO_EXPOSURE)
+    if (a.upto == R2F_UPTO_EXPOSURE && a.finish_mask)
+        big ? launch_fast<R2F_UPTO_EXPOSURE, 16, true>(a, s) : launch_fast<R2F_UPTO_EXPOSURE, 8, true>(a, s);
+    else if (a.upto == R2F_UPTO_EXPOSURE)
         big ? launch_fast<R2F_UPTO_EXPOSURE, 16>(a, s) : launch_fast<R2F_UPTO_EXPOSURE, 8>(a, s);
     else if (a.upto == R2F_UPTO_DENSITY)
         big ? launch_fast<R2F_UPTO_DENSITY, 16>(a, s) : launch_fast<R2F_UPTO_DENSITY, 8>(a, s);
@@ -264,6 +276,11 @@ hipError_t front_fast_init_attributes() {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(front_fast_kernel<L, U, B>),                     \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);                       \
         if (e != hipSuccess) return e;                                                                                    \
+        if (U == R2F_UPTO_EXPOSURE) {                                                                                     \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(front_fast_kernel<L, U, B, true>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);                              \
+            if (e != hipSuccess) return e;                                                                                \
+        }                                                                                                                 \
     }
 #define R2F_FAST_ATTR3(U, B) R2F_FAST_ATTR(R2F_LAYOUT_HWC3, U, B) R2F_FAST_ATTR(R2F_LAYOUT_HWC4, U, B) R2F_FAST_ATTR(R2F_LAYOUT_CHW, U, B)
     R2F_FAST_ATTR3(R2F_UPTO_EXPOSURE, 8)

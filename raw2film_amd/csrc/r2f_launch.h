@@ -29,6 +29,11 @@ struct FrontArgs {
     int vec;  // 1: W % 4 == 0 and all bases 16-byte aligned -> float4 paths
     int blocks_per_cu;  // curve-in-LDS variant: workgroups in the grid per CU (each copies the curve cells once, then walks rows)
     int fast;           // 1: the fused S0..S8 pass may take the specialised kernel of r2f_front.hip when it is eligible
+    // upto = EXPOSURE, fast kernel only: channels in finish_mask get finish_w[c] * exposure -> log -> curve and are written to
+    // `finish_dst` (density planes) instead of `dst`
+    int finish_mask;
+    float finish_w[3];
+    DevPlanes finish_dst;
 };
 bool front_fast_eligible(const FrontArgs& a);
 hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s);

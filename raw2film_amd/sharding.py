@@ -80,8 +80,14 @@ class HipStageBackend:
     def front(self, image_rows, in_gy0, upto, dst, dst_gy0, y0, y1, H):
         self.ctx.stage_front(image_rows, self.params, upto, in_gy0=in_gy0, dst=dst, dst_gy0=dst_gy0, y0=y0, y1=y1, H_global=H)
 
-    def halation(self, E, e_gy0, D, d_gy0, y0, y1, H):
-        self.ctx.stage_halation(E, D, self.params, src_gy0=e_gy0, dst_gy0=d_gy0, y0=y0, y1=y1, H_global=H)
+    def front_split(self, image_rows, in_gy0, E, e_gy0, D, d_gy0, y0, y1, H):
+        """front(upto = exposure) with the halation's identity channels finished straight into D; returns their mask."""
+        return self.ctx.stage_front_split(image_rows, self.params, E, D, in_gy0=in_gy0, exposure_gy0=e_gy0, density_gy0=d_gy0,
+                                          y0=y0, y1=y1, H_global=H)
+
+    def halation(self, E, e_gy0, D, d_gy0, y0, y1, H, identity_done=0):
+        self.ctx.stage_halation(E, D, self.params, src_gy0=e_gy0, dst_gy0=d_gy0, y0=y0, y1=y1, H_global=H,
+                                identity_done=identity_done)
 
     def mtf(self, D, d_gy0, D2, d2_gy0, y0, y1, H):
         self.ctx.stage_mtf(D, D2, self.params, src_gy0=d_gy0, dst_gy0=d2_gy0, y0=y0, y1=y1, H_global=H)
@@ -177,6 +183,7 @@ class RowShardedRenderer:
                           and torch.cuda.is_available() and (halation or mtf or grain)
                           and (world == 1 or self.single_exchange or not mtf))  # no exchange downstream of the front
         self._graphs = {}   # key -> [calls seen, CUDAGraph or None]
+        self._identity_done = 0  # channel mask front_split finished (world == 1 only)
 
     # ------------------------------------------------------------------ neighbour exchange
     def _exchange(self, buf, buf_gy0: int, above: int, below: int, wait: bool = True):
@@ -309,6 +316,9 @@ class RowShardedRenderer:
                 pending = self._exchange(self.E, self.e_lo, above, below, wait=False)
                 be.front(image_rows, p.r0, 0, self.E, self.e_lo, lo_band, hi_band, H)
                 self._exchange_finish(pending)
+            elif p.world == 1 and hasattr(be, "front_split"):
+                # no neighbours to feed: the halation's identity channels (blue on a colour stock) skip their exposure plane
+                self._identity_done = be.front_split(image_rows, p.r0, self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
             else:
                 be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
                 self._exchange(self.E, self.e_lo, above, below)
@@ -323,10 +333,11 @@ class RowShardedRenderer:
             cur, cur_lo = self.Dplain, p.r0
         else:
             if self.halation:
+                kw = {"identity_done": self._identity_done} if self._identity_done else {}
                 if self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
-                    be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H)
+                    be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H, **kw)
                 else:
-                    be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
+                    be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H, **kw)
             cur, cur_lo = self.D, self.d_lo
             if self.mtf:
                 if not self.single_exchange:

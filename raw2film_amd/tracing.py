@@ -10,7 +10,7 @@ roofline of the dominant kernel and handy for "where did the frame time go" ques
 
 from __future__ import annotations
 
-STAGES = ("front", "halation", "mtf", "grain", "burn_sums", "burn_map", "tail", "tail_field", "front_to_output")
+STAGES = ("front", "front_split", "halation", "mtf", "grain", "burn_sums", "burn_map", "tail", "tail_field", "front_to_output")
 
 
 class TimedBackend:

@@ -823,3 +823,38 @@ def test_fused_pointwise_fast_path_matches_generic(ctx, layout, matrix):
     (f_fast, u_fast), (f_gen, u_gen) = both(low)
     assert torch.equal(f_fast, f_gen) and torch.equal(u_fast, u_gen)
     ctx.set_curve1d(p.lut_1d)
+
+
+@pytest.mark.parametrize("bw", [False, True])
+def test_identity_halation_channels_are_finished_by_the_front_kernel(ctx, bw):
+    """Whole-frame renders hand the halation's single-tap channels (blue on a colour stock: f_b = 0) to the front kernel: tap
+    weight, log and curve there, density written directly, no exposure plane and no pointwise pass for them.  Same bits as the
+    path through the exposure plane; a black-and-white stock (halation on all three layers) has nothing to hand over."""
+    neg, prt, bwstock = stocks()
+    H, W = 200, 320
+    p = oracle_inputs(bwstock if bw else neg, prt, 250.0)
+    img = synthetic_frame(H, W, seed=77)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    t = dev(img)
+    E = torch.full((3, H, W), -1.0, dtype=torch.float32, device="cuda")
+    D = torch.full((3, H, W), -1.0, dtype=torch.float32, device="cuda")
+    mask = ctx.stage_front_split(t, params, E, D)
+    assert mask == (0 if bw else 4)
+    E_plain = torch.empty_like(E)
+    ctx.stage_front(t, params, 0, dst=E_plain)
+    if bw:
+        assert torch.equal(E, E_plain) and float(D.max()) == -1.0
+    else:
+        assert torch.equal(E[:2], E_plain[:2]) and float(E[2].max()) == -1.0  # the blue exposure plane is never written
+        D_ref = torch.empty_like(D)
+        ctx.stage_halation(E_plain, D_ref, params, y0=0, y1=H, H_global=H)
+        ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H, identity_done=mask)
+        assert torch.equal(D, D_ref)
+    outs = []
+    for fast in (1, 0):  # r2f_render takes the split front when the fast kernel applies
+        ctx.set_option("front_fast", fast)
+        outs.append(ctx.render(t, params)[0])
+    ctx.set_option("front_fast", 1)
+    assert torch.equal(outs[0], outs[1])
+    assert_close(outs[0].cpu().numpy(), ref, 1e-5, 1e-3, "render with the split front")
