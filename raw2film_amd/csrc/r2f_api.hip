@@ -575,7 +575,11 @@ std::vector<float> fixed_stencil_weights(const StencilSet& set, int R, int Q, bo
 }
 
 constexpr int kFftMaxTaps = 400;
-constexpr int kFixedMaxR = 11;  // the unrolled direct form beats the FFT form up to 23 x 23 (tools/fft_probe.py), ties at 25 x 25
+constexpr int kFixedMaxR = 11;  // largest unrolled direct form (23 x 23)
+// Up to which radius the unrolled direct form is preferred over the FFT form (tools/fft_probe.py, 24 MP x 3 channels): against
+// complex128 scratch it wins up to 23 x 23 (0.54 vs 0.55 ms; 25 x 25: 0.81 vs 0.57); against the complex64 scratch of the MTF
+// passes (0.42-0.45 ms whatever the taps) only up to 19 x 19 (0.40; 21 x 21: 0.45 vs 0.45, 23 x 23: 0.54 vs 0.43).
+int fixed_preferred_max_r(const r2f_ctx* ctx, int which) { return ((ctx->opt_fft_s32 >> which) & 1) ? 9 : kFixedMaxR; }
 
 // Does channel c of stencil `which` take the overlap-save FFT form?
 bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
@@ -588,7 +592,9 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     if (!(bh <= kFftMaxTaps && bw <= kFftMaxTaps && bh * bw >= ctx->opt_fft_min_taps)) return false;
     // square mirror-symmetric stencils up to 23 x 23 are faster in the unrolled direct form (needs the device form: callers
     // run ensure_stencil first)
-    if (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 && s.built_q && fixed_stencil_radius(s, &c, 1, kFixedMaxR)) return false;
+    const int which = (int)(&s - ctx->stencil);
+    if (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 && s.built_q && fixed_stencil_radius(s, &c, 1, fixed_preferred_max_r(ctx, which)))
+        return false;
     return true;
 }
 
@@ -1229,7 +1235,9 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
         // (the grain stencil: all three channels together, and the geometry of the tail tile, which this call may not have built)
         const int all[3] = {0, 1, 2};
         const int fr = which == R2F_KERNEL_GRAIN ? (ctx->opt_grain_fixed ? fixed_stencil_radius(set, all, 3, 9) : 0)
-                                                 : (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 ? fixed_stencil_radius(set, &c, 1, kFixedMaxR) : 0);
+                                                 : (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 && !fft_eligible(ctx, set, c)
+                                                        ? fixed_stencil_radius(set, &c, 1, kFixedMaxR)
+                                                        : 0);
         // bit 8: the grain stencil runs as two 1-D passes (known once a tail launch has looked at the taps)
         const int sep = which == R2F_KERNEL_GRAIN && fr && ctx->grain_fixed_valid && ctx->grain_sep && ctx->opt_grain_sep;
         o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym | (fr << 1) | (sep << 8);

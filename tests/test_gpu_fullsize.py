@@ -254,7 +254,7 @@ def test_cfg2_24mp_lut_only_windows_match_the_oracle():
 
 
 def test_cfg3_45mp_full_pipeline_windows_match_the_oracle():
-    """BASELINE config 3 at its full size: 8256 x 5504, 59 / 23 / 7-tap stencils (halation by FFT, MTF in the unrolled direct
+    """BASELINE config 3 at its full size: 8256 x 5504, 59 / 23 / 7-tap stencils (halation and, since its scratch is complex64, MTF by FFT rather than in the unrolled direct
     form), grain on."""
     from raw2film_amd.context import HipContext
     from raw2film_amd.synthetic import synthetic_frame_device

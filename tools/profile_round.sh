@@ -28,10 +28,12 @@ rows = []
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
-renders = (steps + warm + 2) * frames
+# renders in the traced run: the kernels launched once per render (front / tail / the fused LUT pass) tell
+once = [int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("tail_kernel", "front_fast_kernel", "front_kernel", "lut3d_kernel"))]
+renders = min(once) if once else (steps + warm + 2) * frames
 with open(f"{out}/summary/{tag}_{cfg}_kernel_stats.csv", "w") as fh:
     fh.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps} --warmup {warm} $ARGS\n")
-    fh.write(f"# ({renders} renders: {warm} warm-up + {steps} timed + 2 for the per-pass breakdown" + (f", x {frames} frames each" if frames > 1 else "") + "); torch's frame-generation kernels are folded into one line\n")
+    fh.write(f"# ({renders} renders of the frame: warm-up, {steps} timed steps (HIP graph replay), eager steps for the stage and per-pass breakdowns); torch's frame-generation kernels are folded into one line\n")
     fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     other = [0, 0.0]
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
@@ -48,7 +50,8 @@ for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
         if "r2f::" in row["Kernel_Name"]:
             tot[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
-prenders = (psteps + pwarm + 2) * frames
+once = [len(d["FETCH_SIZE"]) for k, d in tot.items() if any(n in k for n in ("tail_kernel", "front_fast_kernel", "front_kernel", "lut3d_kernel"))]
+prenders = min(once) if once else (psteps + pwarm + 2) * frames   # renders in the counter runs (once-per-render kernels)
 per_step = 0.0
 for k, d in tot.items():
     fetch = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
@@ -58,6 +61,7 @@ for k, d in tot.items():
     summary[k] = {"FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write, "launches": n, "launches_per_render": n / prenders,
                   "hbm_bytes_per_launch": b, "bytes_per_render": b * n / prenders}
     per_step += b * n / prenders * frames
+summary["_renders_in_counter_run"] = prenders
 H, W = {"cfg4_100mp": (8192, 12288), "cfg3_45mp": (5504, 8256), "cfg2_24mp": (4000, 6000), "cfg5_batch": (4000, 6000)}[cfg]
 summary["_meta"] = {
     "config": cfg, "frame": "noise", "source_hash": source_hash(), "date": datetime.datetime.now().isoformat(timespec="seconds"),
