@@ -32,6 +32,20 @@ REC709_TO_XYZ = np.array(  # data.py:128-135
 )
 
 
+class PendingFrame:
+    """A frame submitted with HipProcessor.submit_preloaded: `.result()` waits for its download and returns the uint8 array."""
+
+    def __init__(self, host, done):
+        self._host, self._done = host, done
+
+    def ready(self) -> bool:
+        return self._done.query()
+
+    def result(self) -> np.ndarray:
+        self._done.synchronize()
+        return self._host.numpy()
+
+
 class HipProcessor:
     """Drop-in for the hot path of CpuProcessor / GpuProcessor (gui.py:1584-1585)."""
 
@@ -297,6 +311,49 @@ class HipProcessor:
         final_scaling: "gpu" -- like GpuProcessor, the canvas keeps its size and only a `max_scale` render is scaled back up;
         "cpu" -- like CpuProcessor.process (cpu_processor.py:411-412), the finished frame, canvas included, is scaled to the
         requested resolution (INTER_AREA down, LANCZOS4 up).  dst_texture / histogram_texture: see process()."""
+        torch = self._torch
+        image = cpu_payload["image_array"]
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
+        out_u8 = self._render_preloaded(image, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture,
+                                        final_scaling, **settings)
+        return None if out_u8 is None else out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def submit_preloaded(self, cpu_payload, negative_film, grain_size, grain_sigma, final_scaling="gpu", **settings):
+        """process_preloaded without waiting: the upload runs on a copy stream, the render on the current stream, the download
+        of the uint8 result into pinned host memory on a second copy stream; returns a `PendingFrame` whose `.result()` is
+        process_preloaded's return value.  Keeping one frame pending while the next one is submitted overlaps both PCIe
+        directions with the render (raw2film_amd.sharding.BatchSharder.run(..., collect=...) does exactly that) -- what the
+        reference's queue.write_texture / read_texture pair serialises."""
+        torch = self._torch
+        if getattr(self, "_up_stream", None) is None:
+            self._up_stream = torch.cuda.Stream(device=self.device)
+            self._down_stream = torch.cuda.Stream(device=self.device)
+        image = cpu_payload["image_array"]
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        if not image.is_cuda and not image.is_pinned():
+            image = image.pin_memory()  # (a pageable source would make the "asynchronous" copy a synchronous one)
+        compute = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._up_stream):
+            dev = image.to(self.device, non_blocking=True)
+            uploaded = self._up_stream.record_event()
+        compute.wait_event(uploaded)
+        dev.record_stream(compute)
+        out_u8 = self._render_preloaded(dev, cpu_payload, negative_film, grain_size, grain_sigma, None, None, final_scaling, **settings)
+        rendered = compute.record_event()
+        with torch.cuda.stream(self._down_stream):
+            self._down_stream.wait_event(rendered)
+            host = torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True)
+            host.copy_(out_u8, non_blocking=True)
+            out_u8.record_stream(self._down_stream)
+            done = self._down_stream.record_event()
+        return PendingFrame(host, done)
+
+    def _render_preloaded(self, image, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture,
+                          final_scaling, **settings):
+        """The device half of process_preloaded on an uploaded frame; returns the uint8 device result (None with a dst_texture)."""
         if dst_texture is not None:
             self._check_texture(dst_texture, "dst_texture")
         if histogram_texture is not None:
@@ -305,10 +362,6 @@ class HipProcessor:
                 raise ValueError("histogram_texture needs dst_texture (gpu_processor.py:1883: the histogram is only drawn on the "
                                  "destination-texture branch)")
         torch = self._torch
-        image = cpu_payload["image_array"]
-        if isinstance(image, np.ndarray):
-            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
-        image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         layout = None  # the payload is (H, W, C) like the reference's; the device pre-path hands on (3, H, W) planes
         warp = cpu_payload.get("warp")
         if warp:  # free rotation (effects.rotate) + the crops behind it + quarter turns (np.rot90 on the planes)
@@ -358,7 +411,7 @@ class HipProcessor:
             elif f < 1 and final_scaling == "cpu":  # cv.INTER_AREA: the CPU processor shrinks the canvas-framed frame
                 out_u8 = self.ctx.resize_area_u8(out_u8.contiguous(), *size)
         self.last_output = out_u8
-        return out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+        return out_u8
 
     def generate_histogram(self, image=None, mix_table=None, height=100):
         """utils.generate_histogram (utils.py:145-223) of `image` (uint8 (H, W, 3), NumPy or device) -- or, with no image,

@@ -383,7 +383,10 @@ class BatchSharder:
     def cancel(self):
         self._cancel.set()
 
-    def run(self, tasks, prepare, execute, progress=None):
+    def run(self, tasks, prepare, execute, progress=None, collect=None):
+        """collect: when given, `execute` only SUBMITS a frame (`HipProcessor.submit_preloaded`) and returns a handle; the
+        handle of frame k is collected (`collect(task, handle)`, e.g. `handle.result()` + export) after frame k + 1 has been
+        submitted, so uploads, renders and downloads of consecutive frames overlap on the GPU's copy and compute streams."""
         mine = self.my_tasks(tasks)
         q: queue.Queue = queue.Queue(maxsize=1)
         results, skipped = {}, []
@@ -417,6 +420,7 @@ class BatchSharder:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
+        in_flight = None  # (index, task, handle) of the frame submitted but not yet collected
         try:
             while not self._cancel.is_set():
                 try:
@@ -430,9 +434,18 @@ class BatchSharder:
                 if payload is None:
                     skipped.append(idx)
                     continue
-                results[idx] = execute(task, payload)
+                if collect is None:
+                    results[idx] = execute(task, payload)
+                else:
+                    handle = execute(task, payload)
+                    if in_flight is not None:
+                        results[in_flight[0]] = collect(in_flight[1], in_flight[2])
+                    in_flight = (idx, task, handle)
                 if progress is not None:
                     progress(idx, len(mine))
+            if in_flight is not None:
+                results[in_flight[0]] = collect(in_flight[1], in_flight[2])
+                in_flight = None
         finally:
             # whatever ended the loop (cancel, the sentinel, an exception out of execute): stop the producer and drop what
             # it still holds, so it neither decodes the rest of the batch nor sits on a ~400 MB payload

@@ -317,3 +317,22 @@ def test_float_lanczos4_upscale_before_the_path(proc, layout):
     p = oracle_inputs(neg, prt, 150 / 36, halation=False, mtf=False, grain=0, matrix=False)
     ref = st.to_uint8(st.render(post.resize_lanczos4_f32(xyz, 100, 150), p))
     assert _u8_close(out, ref)
+
+
+def test_submitted_frames_equal_processed_frames_and_overlap_is_safe(proc):
+    """submit_preloaded + PendingFrame.result() == process_preloaded, also with several frames in flight whose uploads, renders
+    and downloads run on three streams (each frame's buffers must survive until its own download has finished)."""
+    from raw2film_amd.sharding import BatchSharder
+
+    neg, prt, _ = stocks()
+    H, W = 150, 210
+    kw = dict(print_film=prt, frame_width=36, frame_height=24, exp_kelvin=6000, color_masking=1.0, seed=SEED)
+    frames = [_xyz(H, W, seed=60 + i) for i in range(5)]
+    payloads = [proc.extract_image_data_cpu(f, frame_width=36, frame_height=24) for f in frames]
+    want = [proc.process_preloaded(p, neg, 6, 0.4, **kw) for p in payloads]
+    pend = [proc.submit_preloaded(p, neg, 6, 0.4, **kw) for p in payloads]  # all five in flight
+    for w, h in zip(want, pend):
+        np.testing.assert_array_equal(h.result(), w)
+    res, skipped = BatchSharder(0, 1).run(list(range(5)), lambda i: payloads[i],
+                                          lambda i, p: proc.submit_preloaded(p, neg, 6, 0.4, **kw), collect=lambda i, h: h.result())
+    assert skipped == [] and all(np.array_equal(res[i], want[i]) for i in range(5))

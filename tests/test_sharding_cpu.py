@@ -274,3 +274,28 @@ def test_batch_sharder_stops_its_producer_when_execute_raises_or_the_run_is_canc
     bs.run(list(range(1000)), prepare, slow_execute)
     time.sleep(0.3)
     assert threading.active_count() == before
+
+
+def test_batch_sharder_pipelined_collect_keeps_one_frame_in_flight():
+    """With `collect`, execute() only submits: frame k is collected after frame k + 1 went in, the last one at the end, results
+    keyed like the serial form's."""
+    log = []
+    bs = sharding.BatchSharder(0, 1)
+
+    def execute(t, payload):
+        log.append(("submit", t))
+        return ("handle", t)
+
+    def collect(t, handle):
+        assert handle == ("handle", t)
+        log.append(("collect", t))
+        return t * 10
+
+    def prepare(t):
+        if t == 2:
+            raise RuntimeError("decode failed")
+        return t
+
+    results, skipped = bs.run([0, 1, 2, 3], prepare, execute, collect=collect)
+    assert results == {0: 0, 1: 10, 3: 30} and skipped == [2]
+    assert log == [("submit", 0), ("submit", 1), ("collect", 0), ("submit", 3), ("collect", 1), ("collect", 3)]
