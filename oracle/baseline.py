@@ -4,9 +4,11 @@ a bounded sample of the benchmark workload on the box's own host cores.
 TEST/BENCH INFRASTRUCTURE ONLY (see oracle/__init__.py).  It is a reported baseline, never the
 thing shipped: the product path has no CPU implementation.
 
-Method: the sample is a set of independent tiles rendered with exactly the benchmark's LUTs and
-stencils (same px/mm, hence the same 87x87 / 35x35 / 9x9 taps as the full frame); one worker
-process per host core (scipy.fft pinned to one thread per worker), tiles dealt round-robin.
+Method: the sample is a set of independent 1.5 MP tiles rendered with exactly the benchmark's LUTs and
+stencils (same px/mm, hence the same 87x87 / 35x35 / 9x9 taps as the full frame; the mirror padding of a
+1024 x 1536 tile is 1.14x its area, against 1.3x for the 512 x 768 tiles of round 1, so the baseline is no
+longer understated by the tiling); one worker process per host core (scipy.fft pinned to one thread per
+worker), tiles dealt round-robin.
 Stencils use FFT correlation with mirror padding -- what OpenCV's filter2D does for kernels
 larger than 11x11 on the reference's CPU path -- so the baseline is not artificially slow.
 """
@@ -58,7 +60,7 @@ def usable_cores() -> int:
     return n
 
 
-def time_cpu_baseline(p: st.RenderInputs, tile_hw=(512, 768), target_seconds: float = 15.0, cores: int | None = None,
+def time_cpu_baseline(p: st.RenderInputs, tile_hw=(1024, 1536), target_seconds: float = 15.0, cores: int | None = None,
                       seed: int = 1234) -> dict:
     """Render tiles for about `target_seconds` of wall time; returns the cpu_baseline object of bench.py."""
     if cores is None:
