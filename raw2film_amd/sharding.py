@@ -267,10 +267,19 @@ class RowShardedRenderer:
             self._front_and_exchange(image_rows)
         if slot[1] is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                # thread_local: other threads (RCCL's watchdog polls events) may keep calling into HIP during the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    if whole:
+                        self._front_and_exchange(image_rows)
+                    self._after_exchange(out_f32, out_u8, None)
+            except Exception:  # noqa: BLE001 -- a failed capture must not cost the frame: eager launches from here on
+                self.graph = False
+                self._graphs.clear()
+                torch.cuda.synchronize()
                 if whole:
                     self._front_and_exchange(image_rows)
-                self._after_exchange(out_f32, out_u8, None)
+                return self._after_exchange(out_f32, out_u8, None)
             slot[1] = g
             if len(self._graphs) > 8:  # callers that hand in fresh buffers every frame: do not hoard graphs
                 for k in list(self._graphs)[:-8]:
