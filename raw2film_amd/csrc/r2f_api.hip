@@ -84,6 +84,7 @@ struct r2f_ctx {
     // Default: the MTF only -- it acts on density, whose values are bounded, so two fp32 roundings of the spectrum cost ~1e-7
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
+    int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
     int lanczos_key[4] = {0, 0, 0, 0};
@@ -695,8 +696,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.curve = ctx->curve;
     a.log_eps = log_eps;
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
-    a.s32 = (ctx->opt_fft_s32 >> which) & 1;
-    const size_t img_bytes = img * (a.s32 ? sizeof(float2) : sizeof(double2));
+    a.s32 = ((ctx->opt_fft_s96 >> which) & 1) ? 2 : ((ctx->opt_fft_s32 >> which) & 1);
+    const size_t img_bytes = img * (a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));
     const int pairs = a.ppc * nch;
     // batches alternate between two internal streams when there is enough work for that to matter
     // opt_fft_batch counts MiB of scratch in flight (a 256 x 256 complex128 pair is 1 MiB)
@@ -727,8 +728,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         R2F_HIP(ctx, hipEventRecord(e0, st));
         R2F_HIP(ctx, launch());
         R2F_HIP(ctx, hipEventRecord(e1, st));
-        ctx->timing_ev[cls + 3 * a.s32].push_back({e0, e1});
-        ctx->timing_bytes[cls + 3 * a.s32] += bytes;
+        ctx->timing_ev[cls + 3 * (a.s32 == 1)].push_back({e0, e1});
+        ctx->timing_bytes[cls + 3 * (a.s32 == 1)] += bytes;
         return R2F_OK;
     };
     int turn = 0;
@@ -995,6 +996,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_scratch96")) {
+        if (value < 0 || value > 7) return fail(ctx, R2F_EINVAL, "stencil_fft_scratch96 is a mask over the three stencils (0..7)");
+        ctx->opt_fft_s96 = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_scratch32")) {

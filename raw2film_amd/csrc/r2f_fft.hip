@@ -262,25 +262,46 @@ __device__ __forceinline__ const cplx& at(const cplx* base, unsigned idx) {
 // S32 = true: complex64 -- only the two roundings between the passes are fp32, every butterfly stays fp64 -- for stencils on
 // DENSITY (the MTF): values in [0, 4], so those roundings cost ~1e-7 absolute (under one fp32 ulp of a density >= 1; measured
 // in tests/test_gpu_fft.py) and the three passes move half the bytes.
-template <bool S32>
+// ST = 2: a 12-byte element {fp32 head of re, fp32 head of im, the two residuals v - head as bf16}: 2^-33 relative, a quarter
+// fewer bytes than complex128 -- enough for linear exposure (a 65 504 specular in the window costs its shadows 1e-7 absolute).
+struct __attribute__((packed, aligned(4))) C96 {
+    float hr, hi;
+    unsigned lo;
+};
+template <int ST>
 __device__ __forceinline__ cplx sld(const void* base, unsigned idx) {
-    if (S32) {
+    if (ST == 1) {
         const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + (idx << 3));
         return make_double2((double)v.x, (double)v.y);
     }
+    if (ST == 2) {
+        const C96 e = *reinterpret_cast<const C96*>(reinterpret_cast<const char*>(base) + idx * 12u);
+        const float lr = __uint_as_float(e.lo << 16), li = __uint_as_float(e.lo & 0xffff0000u);
+        return make_double2((double)e.hr + (double)lr, (double)e.hi + (double)li);
+    }
     return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + (idx << 4));
 }
-template <bool S32>
+__device__ __forceinline__ unsigned bf16_bits(float x) {  // round to nearest even, like v_cvt_pk_bf16_f32
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <int ST>
 __device__ __forceinline__ void sst(void* base, unsigned idx, const cplx v) {
-    if (S32)
+    if (ST == 1)
         *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + (idx << 3)) = make_float2((float)v.x, (float)v.y);
-    else
+    else if (ST == 2) {
+        C96 e;
+        e.hr = (float)v.x, e.hi = (float)v.y;
+        const float rr = (float)(v.x - (double)e.hr), ri = (float)(v.y - (double)e.hi);
+        e.lo = bf16_bits(rr) | (bf16_bits(ri) << 16);
+        *reinterpret_cast<C96*>(reinterpret_cast<char*>(base) + idx * 12u) = e;
+    } else
         *reinterpret_cast<cplx*>(reinterpret_cast<char*>(base) + (idx << 4)) = v;
 }
 // scratch image of pair `pair` (n elements each)
-template <bool S32>
+template <int ST>
 __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) {
-    return reinterpret_cast<char*>(s1) + pair * n * (S32 ? 8 : 16);
+    return reinterpret_cast<char*>(s1) + pair * n * (ST == 1 ? 8 : (ST == 2 ? 12 : 16));
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 1
@@ -299,7 +320,7 @@ struct RowGeom {
     }
 };
 
-template <bool X512, bool S32>
+template <bool X512, int ST>
 __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* fsm) {
     typedef RowGeom<X512> G;
     constexpr int NX = G::NX, LPL = G::LPL;
@@ -363,33 +384,33 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
         else
             fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
     }
-    char* s1 = simg<S32>(a.s1, pair, (long long)a.ny * NX);
+    char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
     if (R2F_FFT_EXP & 2) {
-        if (v[3].x == 1.2345e300) sst<S32>(s1, 0, v[5]);  // keep the transform alive without storing
+        if (v[3].x == 1.2345e300) sst<ST>(s1, 0, v[5]);  // keep the transform alive without storing
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) sst<S32>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
+    for (int q = 0; q < 16; ++q) sst<ST>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
 }
 
-template <bool X512, bool S32>
+template <bool X512, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_fwd_body<X512, S32>(a, fsm);
+    fft_rows_fwd_body<X512, ST>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
 // grid (nx / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.  NBX = nx / 16.
 // mode 0: forward along r, multiply by the kernel spectrum, inverse, store back
 // mode 1: forward only; the conjugate IS the kernel spectrum (input = the padded kernel image)
-template <int NBX, bool S32>
+template <int NBX, int ST>
 __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
-    char* s1 = simg<S32>(a.s1, pair, (long long)kN * (NBX * 16));
+    char* s1 = simg<ST>(a.s1, pair, (long long)kN * (NBX * 16));
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = sld<S32>(s1, sidx(l + 16 * m, k, NBX));
+    for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(l + 16 * m, k, NBX));
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
@@ -404,7 +425,7 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
     fft256<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 16 * q < a.vy) sst<S32>(s1, sidx(l + 16 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
+        if (l + 16 * q < a.vy) sst<ST>(s1, sidx(l + 16 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
 }
 
 // 512-row windows: 32 lanes per column, 8 columns per workgroup, 2 per wave; forward by fft512, back by fft512_rev.
@@ -412,14 +433,14 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
 // of the four interleaved columns of the scratch layout, i.e. 32-byte pieces: measured ~25 % slower per byte than the
 // 256-row pass (the host's window choice prices that in; tall kernels have no alternative).  (Pairs as the fast grid index,
 // to share spectrum blocks between the workgroups in flight, was slower for every shape: 7.04 -> 7.46 ms at 256 x 256.)
-template <int NBX, bool S32>
+template <int NBX, int ST>
 __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 31;
     const int pair = blockIdx.y, k = blockIdx.x * 8 + (threadIdx.x >> 5);
-    char* s1 = simg<S32>(a.s1, pair, (long long)512 * (NBX * 16));
+    char* s1 = simg<ST>(a.s1, pair, (long long)512 * (NBX * 16));
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = sld<S32>(s1, sidx(l + 32 * m, k, NBX));
+    for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(l + 32 * m, k, NBX));
     const cplx w1 = a.tw512[l];
     double* tbuf = wave_tbuf(fsm);
     fft512<false>(v, w1, tbuf, lane);
@@ -435,19 +456,19 @@ __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const i
     fft512_rev<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 32 * q < a.vy) sst<S32>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
+        if (l + 32 * q < a.vy) sst<ST>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
 }
 
 #ifndef R2F_FFT_WPE2
 #define R2F_FFT_WPE2 2
 #endif
-template <int NBX, bool Y512, bool S32>
+template <int NBX, bool Y512, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_kernel(const FftConvArgs a, const int mode) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     if (Y512)
-        fft_cols_y512_body<NBX, S32>(a, mode, fsm);
+        fft_cols_y512_body<NBX, ST>(a, mode, fsm);
     else
-        fft_cols_body<NBX, S32>(a, mode, fsm);
+        fft_cols_body<NBX, ST>(a, mode, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -458,21 +479,21 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 #ifndef R2F_FFT_CURVE_BATCH
 #define R2F_FFT_CURVE_BATCH 16
 #endif
-template <bool X512, bool EPI, bool S32>
+template <bool X512, bool EPI, int ST>
 __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
     typedef RowGeom<X512> G;
     constexpr int NX = G::NX, LPL = G::LPL;
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
     const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
     const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const char* s1 = simg<S32>(a.s1, pair, (long long)a.ny * NX);
+    const char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
     cplx v[16];
     if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
     } else {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = sld<S32>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
+        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
     }
     if (!(R2F_FFT_EXP3 & 4)) {
         if (X512)
@@ -537,10 +558,10 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #ifndef R2F_FFT_WPE3
 #define R2F_FFT_WPE3 2
 #endif
-template <bool X512, bool EPI, bool S32>
+template <bool X512, bool EPI, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (X512 ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_inv_body<X512, EPI, S32>(a, fsm);
+    fft_rows_inv_body<X512, EPI, ST>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
@@ -552,16 +573,20 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     const dim3 block(kFftThreads);
     if (a.nx == 512) {
         const dim3 grid(a.ny / RowGeom<true>::ROWS, a.npairs);
-        if (a.s32)
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, true>), grid, block, fft_lds_bytes(), s, a);
+        if (a.s32 == 1)
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, 1>), grid, block, fft_lds_bytes(), s, a);
+        else if (a.s32 == 2)
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, 2>), grid, block, fft_lds_bytes(), s, a);
         else
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, false>), grid, block, fft_lds_bytes(), s, a);
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, 0>), grid, block, fft_lds_bytes(), s, a);
     } else {
         const dim3 grid(a.ny / RowGeom<false>::ROWS, a.npairs);
-        if (a.s32)
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, true>), grid, block, fft_lds_bytes(), s, a);
+        if (a.s32 == 1)
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, 1>), grid, block, fft_lds_bytes(), s, a);
+        else if (a.s32 == 2)
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, 2>), grid, block, fft_lds_bytes(), s, a);
         else
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, false>), grid, block, fft_lds_bytes(), s, a);
+            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, 0>), grid, block, fft_lds_bytes(), s, a);
     }
     return hipGetLastError();
 }
@@ -569,10 +594,12 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
 template <int NBX, bool Y512>
 static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
     const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
-    if (a.s32)
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, true>), grid, block, fft_lds_bytes(), s, a, mode);
+    if (a.s32 == 1)
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1>), grid, block, fft_lds_bytes(), s, a, mode);
+    else if (a.s32 == 2)
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 2>), grid, block, fft_lds_bytes(), s, a, mode);
     else
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, false>), grid, block, fft_lds_bytes(), s, a, mode);
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 0>), grid, block, fft_lds_bytes(), s, a, mode);
 }
 
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
@@ -595,15 +622,19 @@ static void launch_rows_inv(const FftConvArgs& a, hipStream_t s) {
     const int rows = RowGeom<X512>::ROWS;
     const dim3 grid((a.vy + rows - 1) / rows, a.npairs);  // rows beyond the valid outputs are never stored
     if (a.epilogue == 1) {
-        if (a.s32)
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, true>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        if (a.s32 == 1)
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, 1>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        else if (a.s32 == 2)
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, 2>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
         else
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, false>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, 0>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
     } else {
-        if (a.s32)
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, true>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        if (a.s32 == 1)
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, 1>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        else if (a.s32 == 2)
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, 2>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
         else
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, false>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, 0>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
     }
 }
 

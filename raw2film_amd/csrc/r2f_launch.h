@@ -185,7 +185,7 @@ struct FftConvArgs {
     const double2* kfs[3];    // per launch channel: conj of the kernel's 2-D spectrum (scratch layout)
     double2* kf_out;          // pass 2, mode 1
     double2* s1;              // npairs x ny x nx scratch images, transformed in place (layout: sidx in r2f_fft.hip)
-    int s32;                  // 1: the scratch images hold complex64 elements (half the bytes; the arithmetic stays fp64)
+    int s32;                  // scratch element: 0 complex128, 1 complex64 (half the bytes; the arithmetic stays fp64), 2 the 12-byte form
     int epilogue;
     DevCurve curve;
     float log_eps;
