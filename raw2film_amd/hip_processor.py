@@ -282,6 +282,10 @@ class HipProcessor:
             src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
             half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio,
         )
+        if dst_texture is not None:
+            self._check_texture(dst_texture, "dst_texture")
+        if histogram_texture is not None:
+            self._check_texture(histogram_texture, "histogram_texture")
         return self.process_preloaded(
             payload, negative_film, grain_size, grain_sigma, print_film=print_film, exp_comp=exp_comp,
             red_light=red_light, green_light=green_light, blue_light=blue_light, projector_kelvin=projector_kelvin,
