@@ -258,6 +258,75 @@ __device__ __forceinline__ void apply_lut3d_tetra(const DevLut3D& L, float s, fl
     b = fmaf(d3, c1.z - cb.z, fmaf(d2, cb.z - ca.z, fmaf(d1, ca.z - c0.z, c0.z)));
 }
 
+// apply_lut3d_tetra for inputs known to be >= 0 (after the S6 clip, cpu_processor.py:397) and n <= 512: no index wrap, the
+// tetrahedron chosen with selects instead of branches, 32-bit byte offsets from the wave-uniform table base.  The same
+// fused multiply-adds on the same texels: bit-identical to the general form.
+__device__ __forceinline__ void lut3d_axis_nonneg(float x, float s, int n, int& lo, float& d) {
+    const float t = x * s;
+    const int i0 = (int)t;
+    lo = min(i0, n - 2);
+    d = i0 >= n - 1 ? 1.0f : t - (float)i0;
+}
+
+__device__ __forceinline__ float4 lut3d_texel(const float4* tex, unsigned off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tex) + off);
+}
+
+__device__ __forceinline__ void apply_lut3d_tetra_nonneg(const DevLut3D& L, float s, float& r, float& g, float& b) {
+    const int n = L.n;
+    int rl, gl, bl;
+    float dr, dg, db;
+    lut3d_axis_nonneg(r, s, n, rl, dr);
+    lut3d_axis_nonneg(g, s, n, gl, dg);
+    lut3d_axis_nonneg(b, s, n, bl, db);
+    const unsigned er = (unsigned)(n * n) << 4, eg = (unsigned)n << 4, eb = 16u;
+    const unsigned o0 = (unsigned)((rl * n + gl) * n + bl) << 4;
+    // utils.py:298-376, ties included: the axis of the largest fraction first
+    const bool c1 = dr >= dg, c2 = dg >= db, c3 = dr >= db, c4 = db >= dg, c5 = db >= dr;
+    const unsigned e1 = c1 ? ((c2 || c3) ? er : eb) : (c4 ? eb : eg);
+    const unsigned e12 = c1 ? (c2 ? er + eg : er + eb) : ((c4 || c5) ? eg + eb : eg + er);
+    const float d1 = fmaxf(fmaxf(dr, dg), db), d3 = fminf(fminf(dr, dg), db), d2 = __builtin_amdgcn_fmed3f(dr, dg, db);
+    const float4 c0 = lut3d_texel(L.tex, o0);
+    const float4 ca = lut3d_texel(L.tex, o0 + e1);
+    const float4 cb = lut3d_texel(L.tex, o0 + e12);
+    const float4 cz = lut3d_texel(L.tex, o0 + (er + eg + eb));
+    r = fmaf(d3, cz.x - cb.x, fmaf(d2, cb.x - ca.x, fmaf(d1, ca.x - c0.x, c0.x)));
+    g = fmaf(d3, cz.y - cb.y, fmaf(d2, cb.y - ca.y, fmaf(d1, ca.y - c0.y, c0.y)));
+    b = fmaf(d3, cz.z - cb.z, fmaf(d2, cb.z - ca.z, fmaf(d1, ca.z - c0.z, c0.z)));
+}
+
+// N pixels at once: all 4 N gathers are issued before the first is consumed.
+template <int N>
+__device__ __forceinline__ void apply_lut3d_tetra_nonneg_batch(const DevLut3D& L, float s, float (&r)[N], float (&g)[N], float (&b)[N]) {
+    const int n = L.n;
+    const unsigned er = (unsigned)(n * n) << 4, eg = (unsigned)n << 4, eb = 16u;
+    float4 c0[N], ca[N], cb[N], cz[N];
+    float d1[N], d2[N], d3[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int rl, gl, bl;
+        float dr, dg, db;
+        lut3d_axis_nonneg(r[k], s, n, rl, dr);
+        lut3d_axis_nonneg(g[k], s, n, gl, dg);
+        lut3d_axis_nonneg(b[k], s, n, bl, db);
+        const unsigned o0 = (unsigned)((rl * n + gl) * n + bl) << 4;
+        const bool c1 = dr >= dg, c2 = dg >= db, c3 = dr >= db, c4 = db >= dg, c5 = db >= dr;
+        const unsigned e1 = c1 ? ((c2 || c3) ? er : eb) : (c4 ? eb : eg);
+        const unsigned e12 = c1 ? (c2 ? er + eg : er + eb) : ((c4 || c5) ? eg + eb : eg + er);
+        d1[k] = fmaxf(fmaxf(dr, dg), db), d3[k] = fminf(fminf(dr, dg), db), d2[k] = __builtin_amdgcn_fmed3f(dr, dg, db);
+        c0[k] = lut3d_texel(L.tex, o0);
+        ca[k] = lut3d_texel(L.tex, o0 + e1);
+        cb[k] = lut3d_texel(L.tex, o0 + e12);
+        cz[k] = lut3d_texel(L.tex, o0 + (er + eg + eb));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        r[k] = fmaf(d3[k], cz[k].x - cb[k].x, fmaf(d2[k], cb[k].x - ca[k].x, fmaf(d1[k], ca[k].x - c0[k].x, c0[k].x)));
+        g[k] = fmaf(d3[k], cz[k].y - cb[k].y, fmaf(d2[k], cb[k].y - ca[k].y, fmaf(d1[k], ca[k].y - c0[k].y, c0[k].y)));
+        b[k] = fmaf(d3[k], cz[k].z - cb[k].z, fmaf(d2[k], cb[k].z - ca[k].z, fmaf(d1[k], ca[k].z - c0[k].z, c0[k].z)));
+    }
+}
+
 // S8 GPU-variant: trilinear between texel centres, lut_3d.wgsl:27-40 (fp32 LUT).
 __device__ __forceinline__ void apply_lut3d_trilinear(const DevLut3D& L, float scale, float& r, float& g, float& b) {
     const int n = L.n;

@@ -26,6 +26,10 @@
 
 #include "../../include/r2f.h"
 
+#ifndef R2F_FRONT_LUT_BATCH
+#define R2F_FRONT_LUT_BATCH 4  // pixels of a lane whose 3-D LUT gathers are in flight together (1, 2 or 4)
+#endif
+
 namespace r2f {
 
 namespace {
@@ -188,12 +192,36 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
                 r[q] = v3[0], g[q] = v3[1], b[q] = v3[2];
                 continue;
             }
+            if (R2F_FRONT_LUT_BATCH > 1) {  // S8 below, for R2F_FRONT_LUT_BATCH pixels at a time
+                r[q] = v3[0], g[q] = v3[1], b[q] = v3[2];
+                continue;
+            }
             if (__builtin_amdgcn_ballot_w64(fminf(fminf(v3[0], v3[1]), v3[2]) < 0.0f) == 0) {
                 p = lut3d_tetra_nonneg(a.lut3d.tex, a.lut3d.n, s3, v3[0], v3[1], v3[2]);
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
             } else {  // a curve that dips below zero: the general cell arithmetic (negative indices wrap like Python's)
                 apply_lut3d_tetra(a.lut3d, s3, v3[0], v3[1], v3[2]);
                 r[q] = v3[0], g[q] = v3[1], b[q] = v3[2];
+            }
+        }
+        if (UPTO == R2F_UPTO_OUTPUT && R2F_FRONT_LUT_BATCH > 1) {
+            constexpr int NB = R2F_FRONT_LUT_BATCH > 1 ? R2F_FRONT_LUT_BATCH : 2;
+#pragma unroll
+            for (int q0 = 0; q0 < 4; q0 += NB) {
+                float rn[NB], gn[NB], bn[NB], lo = 0.f;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    rn[k] = r[q0 + k], gn[k] = g[q0 + k], bn[k] = b[q0 + k];
+                    lo = fminf(lo, fminf(fminf(rn[k], gn[k]), bn[k]));
+                }
+                if (__builtin_amdgcn_ballot_w64(lo < 0.0f) == 0) {  // all gathers of the batch in flight together
+                    apply_lut3d_tetra_nonneg_batch<NB>(a.lut3d, s3, rn, gn, bn);
+                } else {  // a curve that dips below zero: the general cell arithmetic (negative indices wrap like Python's)
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) apply_lut3d_tetra(a.lut3d, s3, rn[k], gn[k], bn[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) r[q0 + k] = rn[k], g[q0 + k] = gn[k], b[q0 + k] = bn[k];
             }
         }
         if (UPTO != R2F_UPTO_OUTPUT) {

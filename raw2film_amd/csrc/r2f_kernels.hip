@@ -476,6 +476,9 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
         for (int p = 0; p < 4; ++p) pre_r[q][p] = pre_g[q][p] = pre_b[q][p] = 0.f;
         if (a.to_planes != 2 && pgx < a.W && gy < a.y1) load_planes4(a.src, gy, pgx, a.W, min(4, a.W - pgx), a.vec != 0, pre_r[q], pre_g[q], pre_b[q]);
     }
+#ifndef R2F_TAIL_LUT_BATCH
+#define R2F_TAIL_LUT_BATCH 2  // pixels of a lane whose 3-D LUT gathers are in flight together (1, 2 or 4)
+#endif
 #ifndef R2F_TAIL_EXP
 #define R2F_TAIL_EXP 0  // development switch (tools/ablate_stencil.py): bit 0 no noise generation, 1 no grain stencil, 2 no LUTs
 #endif
@@ -623,6 +626,8 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
     if (gx >= a.W) return;
     const int nv = min(4, a.W - gx);
     const bool vec = a.vec != 0;
+    const bool tetra_nonneg = a.lut3d_mode == 0 && a.lut3d.n >= 2 && a.lut3d.n <= 512;
+    const float s3 = a.lut3d_scale * (float)(a.lut3d.n - 1);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int gy = tile_y0 + ty * Q + q;
@@ -659,7 +664,21 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
             r[p] = fmaxf(__fadd_rn(r[p], __fmul_rn(G[0][q / 2][p][q & 1], ar)), 0.f);
             g[p] = fmaxf(__fadd_rn(g[p], __fmul_rn(G[1][q / 2][p][q & 1], ag)), 0.f);
             b[p] = fmaxf(__fadd_rn(b[p], __fmul_rn(G[2][q / 2][p][q & 1], ab)), 0.f);
-            if (!a.to_planes && !(R2F_TAIL_EXP & 4)) apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
+            if (!a.to_planes && !(R2F_TAIL_EXP & 4)) {
+                if (!tetra_nonneg)
+                    apply_lut3d(a.lut3d, a.lut3d_scale, a.lut3d_mode, r[p], g[p], b[p]);
+                else if (R2F_TAIL_LUT_BATCH == 1)  // the clip above made every input >= 0
+                    apply_lut3d_tetra_nonneg(a.lut3d, s3, r[p], g[p], b[p]);
+                else if ((p + 1) % R2F_TAIL_LUT_BATCH == 0) {
+                    constexpr int NB = R2F_TAIL_LUT_BATCH;
+                    float rn[NB], gn[NB], bn[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) rn[k] = r[p + 1 - NB + k], gn[k] = g[p + 1 - NB + k], bn[k] = b[p + 1 - NB + k];
+                    apply_lut3d_tetra_nonneg_batch<NB>(a.lut3d, s3, rn, gn, bn);
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) r[p + 1 - NB + k] = rn[k], g[p + 1 - NB + k] = gn[k], b[p + 1 - NB + k] = bn[k];
+                }
+            }
         }
         if (a.to_planes)
             store_planes4(a.dst, gy, gx, a.W, nv, vec, r, g, b);
