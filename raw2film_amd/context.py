@@ -433,7 +433,7 @@ class HipContext:
             d["separable"] = (d["sym"] >> 8) & 1  # grain stencil only: two 1-D passes of 2 R + 1 taps
             d["sym"] &= 1
             d["fft"] = word & 1
-            d["window"] = ((word >> 1) // 1024, (word >> 1) % 1024) if word >> 1 else None
+            d["window"] = ((word >> 1) // 4096, (word >> 1) % 4096) if word >> 1 else None
             stats.append(d)
         return stats
 

@@ -63,8 +63,10 @@ struct r2f_ctx {
     // FFT form of large stencils (r2f_fft.hip): twiddles, per stencil and channel the kernel spectrum, pass scratch
     DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_kimg;
     bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
-    int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 1024 + nx) each spectrum was built for
-    int opt_fft_window = 0;      // window columns: 0 = the cheaper of 256 / 512 per stencil and frame, or one of them forced
+    int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 4096 + nx) each spectrum was built for
+    int opt_fft_window = 0;      // window columns: 0 = the cheapest of 256 / 512 / 1024 per stencil and frame, or one of them forced
+    int opt_fft_window_max = 512;  // widest window the automatic choice may take (1024 columns: 9 % fewer window elements for the
+                                   // 87-tap disc, but the passes run 10-25 % slower per element)
     int opt_fft_window_rows = 0;  // window rows, likewise
     // optional per-launch timing of the FFT passes with events on the launch stream (bench.py's roofline): class 0 / 1 / 2 =
     // pass 1 / 2 / 3; algorithmic bytes are summed alongside
@@ -599,8 +601,8 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     return true;
 }
 
-// Window shape for a bh x bw tap box on a W x H frame: of {256, 512} rows x {256, 512} columns the one whose three passes
-// move the fewest scratch bytes (an 87-tap disc keeps 44 % of a 256 x 256 window and 69 % of a 512 x 512 one).  Chosen from
+// Window shape for a bh x bw tap box on a W x H frame: of {256, 512} rows x {256, 512, 1024} columns the one whose three
+// passes move the fewest scratch bytes (an 87-tap disc keeps 44 % of a 256 x 256 window and 61 % of a 256 x 1024 one).  Chosen from
 // the GLOBAL frame, so every row shard of a frame (and every call on it) uses the same shape and the kernel spectra are
 // built once.  stencil_fft_window / stencil_fft_window_rows force an axis (ignored for a box over 200 taps on that axis,
 // which needs the 512-point window).
@@ -608,8 +610,9 @@ void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int*
     double best = -1.0;
     for (int y = 256; y <= 512; y *= 2) {
         if (bh > 200 ? y != 512 : (ctx->opt_fft_window_rows && y != ctx->opt_fft_window_rows)) continue;
-        for (int x = 256; x <= 512; x *= 2) {
-            if (bw > 200 ? x != 512 : (ctx->opt_fft_window && x != ctx->opt_fft_window)) continue;
+        for (int x = 256; x <= 1024; x *= 2) {
+            if (x > ctx->opt_fft_window_max && x != ctx->opt_fft_window) continue;
+            if (bw > 200 ? (x < 512 || (ctx->opt_fft_window >= 512 && x != ctx->opt_fft_window)) : (ctx->opt_fft_window && x != ctx->opt_fft_window)) continue;
             const int vy = y - bh + 1, vx = (x - bw + 1) & ~3;
             const double n = (double)y * x, part = n * vy / y;
             // per window: pass 1 (floats in, image out), pass 2 (image in, valid rows out), pass 3 (valid rows in, floats out);
@@ -635,13 +638,15 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, &ny, &nx);
     const size_t img = (size_t)ny * nx;
     if (!ctx->fft_tw.p) {
-        // W_256^k, k < 256, then W_512^k, k < 256
-        std::vector<double> tw(4 * kFftN);
+        // W_256^k, k < 256, then W_512^k, k < 256, then W_1024^k, k < 64
+        std::vector<double> tw(4 * kFftN + 2 * 64);
+        const double pi = 3.14159265358979323846264338327950288;
         for (int k = 0; k < kFftN; ++k) {
-            const double pi = 3.14159265358979323846264338327950288;
             tw[2 * k] = std::cos(-2.0 * pi * k / kFftN), tw[2 * k + 1] = std::sin(-2.0 * pi * k / kFftN);
             tw[2 * (kFftN + k)] = std::cos(-pi * k / kFftN), tw[2 * (kFftN + k) + 1] = std::sin(-pi * k / kFftN);
         }
+        for (int k = 0; k < 64; ++k)
+            tw[2 * (2 * kFftN + k)] = std::cos(-2.0 * pi * k / 1024.0), tw[2 * (2 * kFftN + k) + 1] = std::sin(-2.0 * pi * k / 1024.0);
         int rc = upload(ctx, ctx->fft_tw, tw.data(), tw.size() * sizeof(double));
         if (rc) return rc;
     }
@@ -649,6 +654,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     memset(&a, 0, sizeof a);
     a.tw = static_cast<const double2*>(ctx->fft_tw.p);
     a.tw512 = a.tw + kFftN;
+    a.tw1024 = a.tw + 2 * kFftN;
     a.ny = ny, a.nx = nx;
     a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
     a.ax = set.kw / 2 - b[2];
@@ -658,7 +664,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     if (rc) return rc;
     for (int i = 0; i < nch; ++i) {
         const int c = chans[i];
-        if (ctx->fft_kf_valid[which][c] && ctx->fft_kf_dims[which][c] == ny * 1024 + nx) continue;
+        if (ctx->fft_kf_valid[which][c] && ctx->fft_kf_dims[which][c] == ny * 4096 + nx) continue;
         // the kernel's spectrum: the same two forward passes on its zero-padded image
         std::vector<float> kimg(img, 0.f);
         const int kc = set.kc == 1 ? 0 : c;
@@ -679,7 +685,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         R2F_HIP(ctx, launch_fft_rows_fwd(k, s));
         R2F_HIP(ctx, launch_fft_cols(k, 1, s));
         ctx->fft_kf_valid[which][c] = true;
-        ctx->fft_kf_dims[which][c] = ny * 1024 + nx;
+        ctx->fft_kf_dims[which][c] = ny * 4096 + nx;
     }
     a.src = to_dev(src);
     a.dst = to_dev(dst);
@@ -959,8 +965,13 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_window")) {
-        if (value != 0 && value != 256 && value != 512) return fail(ctx, R2F_EINVAL, "stencil_fft_window must be 0, 256 or 512");
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, R2F_EINVAL, "stencil_fft_window must be 0, 256, 512 or 1024");
         ctx->opt_fft_window = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_window_max")) {
+        if (value != 256 && value != 512 && value != 1024) return fail(ctx, R2F_EINVAL, "stencil_fft_window_max must be 256, 512 or 1024");
+        ctx->opt_fft_window_max = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fixed")) {

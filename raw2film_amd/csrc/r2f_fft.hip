@@ -228,6 +228,57 @@ __device__ __forceinline__ void fft512_rev(cplx (&v)[16], const cplx w1, double*
     dft16<INV>(v);
 }
 
+// A lane's double moved to / from lane ^ 2 of its quad (DPP quad_perm [2, 3, 0, 1]).
+__device__ __forceinline__ double swap_lane2(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x4E, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x4E, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kTPitch1024 = 68;  // transpose tile row pitch of a 1024-point line: 64 + 4 (conflict-free both ways); 16 rows = 1 088 doubles
+
+// 1024-point transform by a whole wave: element (l + 64 j) sits in v[j] of lane l.  1024 = 64 x 16: a 16-point DFT over j,
+// the twiddles W_1024^(l p), a transpose after which the lane quad (4 p .. 4 p + 3) holds the l = 4 i + h of residue p,
+// a second 16-point DFT over i, the twiddles W_64^(h c), and a radix-4 step across the quad as two DPP exchanges.
+// On return v[c] of lane l holds output element (l >> 2) + 16 c + 256 g, g = the bit reversal of l & 3.
+// w1 = exp(-2 pi i l / 1024).  tbuf: this WAVE's transpose buffer (all of it).
+template <bool INV>
+__device__ __forceinline__ void fft1024(cplx (&v)[16], const cplx w1, double* t, int lane) {
+    dft16<INV>(v);
+    twiddle_powers<INV>(v, w1);
+    const int h = lane & 3;
+    const double* rd = t + (lane >> 2) * kTPitch1024 + h;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t[p * kTPitch1024 + lane] = v[p].x;
+    __builtin_amdgcn_wave_barrier();
+    double re[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) re[i] = rd[4 * i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t[p * kTPitch1024 + lane] = v[p].y;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = make_double2(re[i], rd[4 * i]);
+    __builtin_amdgcn_wave_barrier();
+    dft16<INV>(v);  // lane (p, h): E_h[c] over the l = 4 i + h
+    // W_64^h, h < 4
+    const cplx wh = make_double2(h == 0 ? 1.0 : (h == 1 ? 0.9951847266721969 : (h == 2 ? 0.9807852804032304 : 0.9569403357322088)),
+                                 h == 0 ? 0.0 : (h == 1 ? -0.0980171403295606 : (h == 2 ? -0.19509032201612825 : -0.2902846772544623)));
+    twiddle_powers<INV>(v, wh);
+    // 4-point DFT across the quad, decimation in frequency: b0 = a0 + a2, b1 = a1 + a3, b2 = a0 - a2, b3 = (a1 - a3) W_4;
+    // X0 = b0 + b1 (lane 0), X2 = b0 - b1 (lane 1), X1 = b2 + b3 (lane 2), X3 = b2 - b3 (lane 3)
+    const bool upper = h & 2, odd = h & 1, rot = h == 3;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        cplx o = make_double2(swap_lane2(v[c].x), swap_lane2(v[c].y));
+        cplx b = upper ? csub(o, v[c]) : cadd(v[c], o);
+        if (rot) b = INV ? make_double2(-b.y, b.x) : make_double2(b.y, -b.x);  // W_4 = -i (forward), +i (inverse)
+        o = make_double2(swap_lane1(b.x), swap_lane1(b.y));
+        v[c] = odd ? csub(o, b) : cadd(b, o);
+    }
+}
+
 // window origin (first input row / column) and validity of window `t` of the launch
 __device__ __forceinline__ bool window_of(const FftConvArgs& a, int t, int& wy, int& wx) {
     if (t >= a.ntiles) return false;
@@ -305,24 +356,36 @@ __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) 
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 1
-// grid (ny / rows per workgroup, pairs).  X512 = false: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
-// X512 = true: 32 lanes per (512-point) row, 8 rows per workgroup, 2 per wave.
+// grid (ny / rows per workgroup, pairs).  256-point rows: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
+// 512-point rows: 32 lanes per row, 8 rows per workgroup, 2 per wave; 1024-point rows: a wave per row, 4 rows per workgroup.
 #ifndef R2F_FFT_EXP
 #define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
 #endif
-template <bool X512>
+// XL: row length 256 << XL
+template <int XL>
 struct RowGeom {
-    static constexpr int NX = X512 ? 512 : 256, NBX = NX / 16, LPL = X512 ? 32 : 16, ROWS = kFftThreads / LPL;
+    static constexpr int NX = 256 << XL, NBX = NX / 16, LPL = 16 << XL, ROWS = kFftThreads / LPL;
     // column (or frequency) held in register q of lane l after a transform
-    static __device__ __forceinline__ int out_col(int l, int q) { return X512 ? 256 * (l & 1) + 16 * q + (l >> 1) : l + 16 * q; }
+    static __device__ __forceinline__ int out_col(int l, int q) {
+        return XL == 2 ? (l >> 2) + 16 * q + 256 * (((l & 1) << 1) | ((l >> 1) & 1)) : (XL == 1 ? 256 * (l & 1) + 16 * q + (l >> 1) : l + 16 * q);
+    }
     static __device__ __forceinline__ double* line_buf(double* wave_buf, int lane) {
-        return wave_buf + (X512 ? (lane >> 5) * kTLine512 : (lane >> 4) * kTLine);
+        return XL == 2 ? wave_buf : wave_buf + (XL == 1 ? (lane >> 5) * kTLine512 : (lane >> 4) * kTLine);
+    }
+    template <bool INV>
+    static __device__ __forceinline__ void fft(cplx (&v)[16], const FftConvArgs& a, int l, double* wave_buf, int lane) {
+        if (XL == 2)
+            fft1024<INV>(v, a.tw1024[l], wave_buf, lane);
+        else if (XL == 1)
+            fft512<INV>(v, a.tw512[l], wave_buf, lane);
+        else
+            fft256<INV>(v, a.tw[l], wave_buf, lane);
     }
 };
 
-template <bool X512, int ST>
+template <int XL, int ST>
 __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* fsm) {
-    typedef RowGeom<X512> G;
+    typedef RowGeom<XL> G;
     constexpr int NX = G::NX, LPL = G::LPL;
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
     const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
@@ -379,10 +442,7 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
         for (int m = 0; m < 16; ++m) v[m] = make_double2((double)fa[m], (double)fb[m]);
     }
     if (!(R2F_FFT_EXP & 4)) {
-        if (X512)
-            fft512<false>(v, a.tw512[l], wave_tbuf(fsm), lane);
-        else
-            fft256<false>(v, a.tw[l], wave_tbuf(fsm), lane);
+        G::template fft<false>(v, a, l, wave_tbuf(fsm), lane);
     }
     char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
     if (R2F_FFT_EXP & 2) {
@@ -393,10 +453,10 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     for (int q = 0; q < 16; ++q) sst<ST>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
 }
 
-template <bool X512, int ST>
+template <int XL, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_fwd_body<X512, ST>(a, fsm);
+    fft_rows_fwd_body<XL, ST>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
@@ -479,9 +539,9 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 #ifndef R2F_FFT_CURVE_BATCH
 #define R2F_FFT_CURVE_BATCH 16
 #endif
-template <bool X512, bool EPI, int ST>
+template <int XL, bool EPI, int ST>
 __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
-    typedef RowGeom<X512> G;
+    typedef RowGeom<XL> G;
     constexpr int NX = G::NX, LPL = G::LPL;
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
     const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
@@ -496,10 +556,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
         for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
     }
     if (!(R2F_FFT_EXP3 & 4)) {
-        if (X512)
-            fft512<true>(v, a.tw512[l], wave_tbuf(fsm), lane);
-        else
-            fft256<true>(v, a.tw[l], wave_tbuf(fsm), lane);
+        G::template fft<true>(v, a, l, wave_tbuf(fsm), lane);
     }
     if (!live) return;
     if (R2F_FFT_EXP3 & 2) {
@@ -558,10 +615,10 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #ifndef R2F_FFT_WPE3
 #define R2F_FFT_WPE3 2
 #endif
-template <bool X512, bool EPI, int ST>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (X512 ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
+template <int XL, bool EPI, int ST>
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (XL ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_inv_body<X512, EPI, ST>(a, fsm);
+    fft_rows_inv_body<XL, EPI, ST>(a, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
@@ -569,25 +626,24 @@ static size_t fft_lds_bytes() { return (size_t)(kFftThreads / 64) * 4 * kTLine *
 
 hipError_t fft_init_attributes() { return hipSuccess; }
 
+template <int XL>
+static void launch_rows_fwd(const FftConvArgs& a, hipStream_t s) {
+    const dim3 block(kFftThreads), grid(a.ny / RowGeom<XL>::ROWS, a.npairs);
+    if (a.s32 == 1)
+        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 1>), grid, block, fft_lds_bytes(), s, a);
+    else if (a.s32 == 2)
+        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 2>), grid, block, fft_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 0>), grid, block, fft_lds_bytes(), s, a);
+}
+
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
-    const dim3 block(kFftThreads);
-    if (a.nx == 512) {
-        const dim3 grid(a.ny / RowGeom<true>::ROWS, a.npairs);
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, 1>), grid, block, fft_lds_bytes(), s, a);
-        else if (a.s32 == 2)
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, 2>), grid, block, fft_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<true, 0>), grid, block, fft_lds_bytes(), s, a);
-    } else {
-        const dim3 grid(a.ny / RowGeom<false>::ROWS, a.npairs);
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, 1>), grid, block, fft_lds_bytes(), s, a);
-        else if (a.s32 == 2)
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, 2>), grid, block, fft_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((fft_rows_fwd_kernel<false, 0>), grid, block, fft_lds_bytes(), s, a);
-    }
+    if (a.nx == 1024)
+        launch_rows_fwd<2>(a, s);
+    else if (a.nx == 512)
+        launch_rows_fwd<1>(a, s);
+    else
+        launch_rows_fwd<0>(a, s);
     return hipGetLastError();
 }
 
@@ -602,47 +658,51 @@ static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
         hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 0>), grid, block, fft_lds_bytes(), s, a, mode);
 }
 
+template <bool Y512>
+static void launch_cols_nx(const FftConvArgs& a, int mode, hipStream_t s) {
+    if (a.nx == 1024)
+        launch_cols<64, Y512>(a, mode, s);
+    else if (a.nx == 512)
+        launch_cols<32, Y512>(a, mode, s);
+    else
+        launch_cols<16, Y512>(a, mode, s);
+}
+
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    if (a.ny == 512) {
-        if (a.nx == 512)
-            launch_cols<32, true>(a, mode, s);
-        else
-            launch_cols<16, true>(a, mode, s);
-    } else {
-        if (a.nx == 512)
-            launch_cols<32, false>(a, mode, s);
-        else
-            launch_cols<16, false>(a, mode, s);
-    }
+    if (a.ny == 512)
+        launch_cols_nx<true>(a, mode, s);
+    else
+        launch_cols_nx<false>(a, mode, s);
     return hipGetLastError();
 }
 
-template <bool X512>
+template <int XL, bool EPI>
 static void launch_rows_inv(const FftConvArgs& a, hipStream_t s) {
-    const int rows = RowGeom<X512>::ROWS;
+    const int rows = RowGeom<XL>::ROWS;
     const dim3 grid((a.vy + rows - 1) / rows, a.npairs);  // rows beyond the valid outputs are never stored
-    if (a.epilogue == 1) {
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, 1>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        else if (a.s32 == 2)
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, 2>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, true, 0>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-    } else {
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, 1>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        else if (a.s32 == 2)
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, 2>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((fft_rows_inv_kernel<X512, false, 0>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-    }
+    if (a.s32 == 1)
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 1>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+    else if (a.s32 == 2)
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 2>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 0>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+}
+
+template <int XL>
+static void launch_rows_inv_epi(const FftConvArgs& a, hipStream_t s) {
+    if (a.epilogue == 1)
+        launch_rows_inv<XL, true>(a, s);
+    else
+        launch_rows_inv<XL, false>(a, s);
 }
 
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s) {
-    if (a.nx == 512)
-        launch_rows_inv<true>(a, s);
+    if (a.nx == 1024)
+        launch_rows_inv_epi<2>(a, s);
+    else if (a.nx == 512)
+        launch_rows_inv_epi<1>(a, s);
     else
-        launch_rows_inv<false>(a, s);
+        launch_rows_inv_epi<0>(a, s);
     return hipGetLastError();
 }
 

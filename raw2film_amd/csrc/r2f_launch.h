@@ -175,13 +175,14 @@ struct FftConvArgs {
     int ppc;                  // window pairs per channel
     int y0, y1, W, H_global;  // output rows [y0, y1) of the global frame
     int ay, ax;               // anchor inside the cropped kernel box
-    int ny, nx;               // window rows, columns: 256 or 512 each
+    int ny, nx;               // window rows: 256 or 512; columns: 256, 512 or 1024
     int vy, vx;               // valid outputs per window: ny - kh + 1, nx - kw + 1 (vx rounded down to a multiple of 4)
     int gx, ntiles;           // windows per row of windows, windows in total
     int pair0, npairs;
     int raw;                  // 1: src is the zero-padded ny x nx kernel image itself (kernel-spectrum build)
     const double2* tw;        // exp(-2 pi i k / 256), k < 256
     const double2* tw512;     // exp(-2 pi i k / 512), k < 256 (the 512-point lines use k < 32)
+    const double2* tw1024;    // exp(-2 pi i k / 1024), k < 64
     const double2* kfs[3];    // per launch channel: conj of the kernel's 2-D spectrum (scratch layout)
     double2* kf_out;          // pass 2, mode 1
     double2* s1;              // npairs x ny x nx scratch images, transformed in place (layout: sidx in r2f_fft.hip)

@@ -43,7 +43,7 @@ def uses_fft(ctx, which):
     return [c["fft"] for c in ctx.stencil_stats(which)]
 
 
-WINDOWS = [(256, 256), (256, 512), (512, 256), (512, 512)]  # rows x columns
+WINDOWS = [(256, 256), (256, 512), (512, 256), (512, 512), (256, 1024), (512, 1024)]  # rows x columns
 
 
 def force_window(ctx, window):
@@ -161,7 +161,7 @@ def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
     def want(H, W):
         best = None
         for y in (256, 512):
-            for x in (256, 512):
+            for x in (256, 512):  # 1024 columns only when forced (stencil_fft_window / stencil_fft_window_max)
                 vy, vx = y - bh + 1, (x - bw + 1) & ~3
                 n = y * x
                 part, p2 = n * vy / y, (1.3 if y == 512 else 1.0)
@@ -171,7 +171,7 @@ def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
         return best[1]
 
     seen = set()
-    for H, W in ((40, 160), (40, 300), (40, 430), (300, 160), (400, 420), (180, 1700), (700, 100)):
+    for H, W in ((40, 160), (40, 300), (40, 430), (300, 160), (400, 420), (180, 1700), (700, 100), (100, 938), (600, 3000)):
         seen.add(want(H, W))
         img = rng.uniform(0, 2, (H, W, 3)).astype(np.float32)
         out = run(ctx, 0, img, k, 1)

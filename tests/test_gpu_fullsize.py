@@ -87,7 +87,7 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
     ctx.set_option("stencil_fft", 1)
 
 
-@pytest.mark.parametrize("rows, cols", [(256, 256), (512, 256), (512, 512)])
+@pytest.mark.parametrize("rows, cols", [(256, 256), (512, 256), (512, 512), (256, 1024)])
 def test_the_100mp_render_does_not_depend_on_the_fft_window_shape(full, rows, cols):
     """The fixture rendered with the window shape the cost model picks (256 x 512 here); any other shape tiles the frame
     differently but computes the same correlation.  With complex128 scratch everywhere the results agree to an fp32 ulp on a

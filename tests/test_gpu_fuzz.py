@@ -25,7 +25,7 @@ def _cases(n=int(os.environ.get("R2F_FUZZ_CASES", "24"))):  # R2F_FUZZ_CASES=400
             hal_size=float(rng.choice([0.5, 1.0, 1.7])), strength=float(rng.choice([0.0, 0.0, 0.6])),
             grain_size=float(rng.choice([2.0, 6.0, 12.0])), layout=str(rng.choice(["hwc3", "hwc4", "chw"])),
             burn=float(rng.choice([0.0, 0.0, 0.5])), nr=int(rng.choice([0, 0, 2])), seed=int(rng.integers(0, 2**31)),
-            win_rows=int(rng.choice([0, 256, 512])), win_cols=int(rng.choice([0, 256, 512])),  # FFT window shape (0: by cost)
+            win_rows=int(rng.choice([0, 256, 512])), win_cols=int(rng.choice([0, 256, 512, 1024])),  # FFT window shape (0: by cost)
         ))
     return out
 
