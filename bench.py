@@ -341,7 +341,7 @@ def main():
             win = next((c["window"] for c in stats if c["fft"]), None)
             g = bytes_alg / (tot_ms * 1e-3) / 1e9
             dk = {
-                "kernel": f"r2f::fft_cols_kernel<{win[1] // 16}, {'true' if win[0] == 512 else 'false'}, {'true' if dom == 4 else 'false'}> "
+                "kernel": f"r2f::fft_cols_kernel<{win[1] // 16}, {'true' if win[0] == 512 else 'false'}, {1 if dom == 4 else 0}> "
                           f"(pass 2 of the fp64 overlap-save FFT of the {'MTF' if dom == 4 else 'halation'} stencil, windows of {win[0]} rows x "
                           f"{win[1]} columns, {'complex64' if dom == 4 else 'complex128'} scratch: column FFT, x kernel spectrum, inverse "
                           "column FFT, in place)",
