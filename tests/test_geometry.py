@@ -102,3 +102,15 @@ def test_blit_transform_matches_the_reference_uniform_block(golden_dir):
         got = np.array([t["scale_x"], t["scale_y"], t["offset_x"], t["offset_y"], t["canvas_min_x"], t["canvas_min_y"],
                         t["canvas_max_x"], t["canvas_max_y"], *t["canvas_color"], 0.0], dtype=np.float32)
         np.testing.assert_array_equal(got, want)
+
+
+def test_add_canvas_matches_the_reference_function():
+    """tests/golden/add_canvas.npz: effects.add_canvas itself, run by tools/make_golden_canvas.py, for every canvas mode."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "add_canvas.npz"))
+    modes = [str(m) for m in g["modes"]]
+    for i in range(int(g["n"])):
+        h, w, mi, scale, ratio = g[f"case_{i}"]
+        got = geometry.add_canvas(g[f"image_{i}"], modes[int(mi)], float(scale), float(ratio))
+        want = g[f"out_{i}"]
+        assert got.shape == want.shape and got.dtype == want.dtype, (i, modes[int(mi)])
+        np.testing.assert_array_equal(got, want)
