@@ -313,8 +313,11 @@ def main():
 
     # L2 <-> fabric bytes of one step from the committed PMC capture, only when it was taken from these very sources on this
     # configuration (tools/profile_round.sh writes the file; it cannot be measured inside an un-profiled run)
-    tfile = os.path.join(ROOT, "profiles", f"r02_{args.config}_hbm_traffic.json")
-    if os.path.exists(tfile) and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain:
+    import glob
+
+    captures = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{args.config}_hbm_traffic.json")))  # latest round last
+    tfile = captures[-1] if captures else ""
+    if tfile and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain:
         rec = json.load(open(tfile))
         meta = rec.get("_meta", {})
         match = meta.get("source_hash") == source_hash() and meta.get("config") == args.config and meta.get("frame") == args.frame
