@@ -50,6 +50,7 @@ def _worker(rank, world, port, H, W, fw, path, burn=0.0):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # no hostname lookup (the box's name may not resolve)
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -198,6 +199,7 @@ def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tm
     common = ["--config", "cfg3_45mp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alone", "--checksum",
               "--direct-stencils"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
                           "--backend", "gloo", "--same-device"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root)

@@ -132,6 +132,7 @@ def _inputs(H, W, scale, burn=0.0, **kw):
 
 def _worker(rank, world, port, H, W, scale, flags, result_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # no hostname lookup (the box's name may not resolve)
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
