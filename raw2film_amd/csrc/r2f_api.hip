@@ -81,6 +81,7 @@ struct r2f_ctx {
     hipStream_t fft_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fft_ev_in = nullptr, fft_ev_out[4] = {nullptr, nullptr, nullptr, nullptr};
     int opt_fft_streams = 2;
+    int opt_fft_even = 1;        // batches sized so that every internal stream gets the same number of launch triples
     int opt_fft_batch = 192;     // window pairs per launch triple: 192 MB of scratch stay inside the 256 MB Infinity Cache
     // bit `which`: that stencil's FFT scratch images hold complex64 instead of complex128 elements (r2f_fft.hip, sld / sst).
     // Default: the MTF only -- it acts on density, whose values are bounded, so two fp32 roundings of the spectrum cost ~1e-7
@@ -709,7 +710,14 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     // opt_fft_batch counts MiB of scratch in flight (a 256 x 256 complex128 pair is 1 MiB)
     const int fft_batch = std::max(1, (int)((size_t)ctx->opt_fft_batch * kFftN * kFftN * sizeof(double2) / img_bytes));
     const int nstreams = pairs > fft_batch ? ctx->opt_fft_streams : 1;
-    const int batch = std::min(pairs, std::max(1, fft_batch / nstreams));
+    int batch = std::min(pairs, std::max(1, fft_batch / nstreams));
+    if (ctx->opt_fft_even) {
+        // as many launch triples per stream: 240 pairs in batches of 48 would be 3 + 2 launches on the two streams, and the
+        // stream with two idles for a fifth of the stage; 6 batches of 40 keep both busy
+        int nb = (pairs + batch - 1) / batch;
+        nb = (nb + nstreams - 1) / nstreams * nstreams;
+        batch = (pairs + nb - 1) / nb;
+    }
     rc = ensure_bytes(ctx, ctx->fft_s1, (size_t)batch * nstreams * img_bytes);
     if (rc) return rc;
     hipStream_t lanes[4] = {s, s, s, s};
@@ -972,6 +980,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_window_max")) {
         if (value != 256 && value != 512 && value != 1024) return fail(ctx, R2F_EINVAL, "stencil_fft_window_max must be 256, 512 or 1024");
         ctx->opt_fft_window_max = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_even_batches")) {
+        ctx->opt_fft_even = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fixed")) {

@@ -17,6 +17,7 @@ ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--lib", default=None)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--frame", default="noise")
+ap.add_argument("--effects", action="store_true", help="all stages on, whatever the configuration (cfg2_24mp + --effects = one frame of cfg 5)")
 args = ap.parse_args()
 from raw2film_amd import _lib  # noqa: E402
 
@@ -27,7 +28,7 @@ from raw2film_amd.hip_processor import REC709_TO_XYZ  # noqa: E402
 from raw2film_amd.synthetic import CONFIGS, synthetic_frame_device  # noqa: E402
 
 W, H = CONFIGS[args.config]
-effects = args.config != "cfg2_24mp"
+effects = args.effects or args.config != "cfg2_24mp"
 stocks = filmstock.builtin_stocks()
 neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
 proc = HipProcessor(device=0)
