@@ -453,8 +453,11 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     for (int q = 0; q < 16; ++q) sst<ST>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
 }
 
+#ifndef R2F_FFT_WPE1
+#define R2F_FFT_WPE1 4
+#endif
 template <int XL, int ST>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE1, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     fft_rows_fwd_body<XL, ST>(a, fsm);
 }
@@ -537,7 +540,9 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 #define R2F_FFT_EXP3 0  // development switch for pass 3: bit 0 no loads, bit 1 no stores, bit 2 no transform
 #endif
 #ifndef R2F_FFT_CURVE_BATCH
-#define R2F_FFT_CURVE_BATCH 16
+// outputs of a lane whose curve cells are gathered together.  16 (all of them) keeps 64 VGPRs of cells live and holds the kernel
+// at 2 waves per SIMD; 4 fits 3 waves per SIMD without spills and is the faster one (halation 2.46 -> 2.43 ms at 100 MP)
+#define R2F_FFT_CURVE_BATCH 4
 #endif
 template <int XL, bool EPI, int ST>
 __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
@@ -613,7 +618,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 }
 
 #ifndef R2F_FFT_WPE3
-#define R2F_FFT_WPE3 2
+#define R2F_FFT_WPE3 3
 #endif
 template <int XL, bool EPI, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (XL ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
