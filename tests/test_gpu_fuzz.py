@@ -13,11 +13,14 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+_BIG = int(os.environ.get("R2F_FUZZ_BIG", "1"))  # R2F_FUZZ_BIG=6: frames up to 1320 x 1800 (many FFT windows, several batches)
+
+
 def _cases(n=int(os.environ.get("R2F_FUZZ_CASES", "24"))):  # R2F_FUZZ_CASES=400 for a long soak
     rng = np.random.default_rng(int(os.environ.get("R2F_FUZZ_SEED", "20261002")))
     out = []
     for i in range(n):
-        H, W = int(rng.integers(1, 220)), int(rng.integers(1, 300))
+        H, W = int(rng.integers(1, 220 * _BIG)), int(rng.integers(1, 300 * _BIG))
         out.append(dict(
             H=H, W=W, scale=float(rng.choice([14.22, 40.0, 97.3, 166.67, 260.0, 341.33, 400.0])),
             halation=bool(rng.integers(0, 2)), mtf=bool(rng.integers(0, 2)), grain=int(rng.integers(0, 3)),
