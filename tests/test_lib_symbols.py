@@ -45,3 +45,21 @@ def test_workspace_bytes_needs_no_gpu():
     assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 0
     p.flags, p.burn_cell = _lib.F_GRAIN | _lib.F_BURN, 10  # grain -> planes, burn map 10 x 20 (x4 floats of scratch)
     assert lib.r2f_workspace_bytes(ctypes.byref(p), 100, 200) == 2 * 3 * 100 * 200 * 4 + 4 * 10 * 20 * 4
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/r2f.h is the boundary a cgo / JNI / ctypes binding reads: it has to compile as C99 without any HIP or C++ header."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "r2f.h"\nint main(void) { r2f_ctx* c = 0; r2f_params p; (void)c; (void)p; return 0; }\n')
+    res = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
