@@ -1,0 +1,57 @@
+"""Render the same frame many times (eager launches and HIP graph replay, two internal FFT streams) and check that every
+result is bit-identical to the first: a missing fence between the FFT batches, the internal streams or the graph's branches
+would show up as a frame that differs.
+
+    python tools/determinism_soak.py [--config cfg3_45mp] [--iters 300]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw2film_amd import HipProcessor, filmstock, stencils  # noqa: E402
+from raw2film_amd.hip_processor import REC709_TO_XYZ  # noqa: E402
+from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer  # noqa: E402
+from raw2film_amd.synthetic import CONFIGS, synthetic_frame_device  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="cfg3_45mp")
+ap.add_argument("--iters", type=int, default=300)
+args = ap.parse_args()
+W, H = CONFIGS[args.config]
+stocks = filmstock.builtin_stocks()
+neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+proc = HipProcessor(device=0)
+params = proc.prepare(neg, 6, 0.4, (W, H), seed=20260630, matrix=REC709_TO_XYZ, print_film=prt, halation_green_factor=0.3,
+                      exp_kelvin=6000, color_masking=1.0)
+scale = max(H, W) / 36.0
+backend = HipStageBackend(proc.ctx, params,
+                          halation_taps=stencils.vertical_reach(stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)),
+                          mtf_taps=stencils.vertical_reach(stencils.mtf_stencil(neg, scale, 0.0, 1.0)))
+frame = synthetic_frame_device(H, W, seed=1234)
+out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+
+
+def checksum():
+    return int(out.view(torch.int32).to(torch.int64).sum().item())
+
+
+bad = 0
+for graph in (False, True):
+    r = RowShardedRenderer(backend, H, W, halation=True, mtf=True, rank=0, world=1, graph=graph)
+    r.render(frame, out_f32=out)
+    first = checksum()
+    sums = set()
+    for i in range(args.iters):
+        out.zero_() if i % 7 == 0 else None
+        r.render(frame, out_f32=out)
+        sums.add(checksum())
+    ok = sums == {first}
+    bad += not ok
+    print(f"{args.config} {'graph replay' if graph else 'eager'}: {args.iters} renders, {len(sums)} distinct checksum(s) "
+          f"{'== first' if ok else '!= first: ' + str(sorted(sums)[:4])}", flush=True)
+    eager_sum = first if not graph else eager_sum  # noqa: F821
+print("graph == eager:", first == eager_sum)
+sys.exit(1 if bad or first != eager_sum else 0)
