@@ -315,6 +315,7 @@ def main():
     # configuration (tools/profile_round.sh writes the file; it cannot be measured inside an un-profiled run)
     import glob
 
+    traffic_rec = None
     captures = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{args.config}_hbm_traffic.json")))  # latest round last
     tfile = captures[-1] if captures else ""
     if tfile and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain:
@@ -324,6 +325,7 @@ def main():
         roof["traffic_provenance"] = {"file": os.path.relpath(tfile, ROOT), "collected": meta.get("date"), "command": meta.get("command"),
                                       "source_hash_then": meta.get("source_hash"), "source_hash_now": source_hash(), "match": match}
         if match:
+            traffic_rec = rec
             roof["traffic"] = meta["bytes_per_step"]
             roof["traffic_over_algorithmic"] = meta["bytes_per_step"] / alg_bytes
             roof["traffic_note"] = ("FETCH_SIZE x 2 + WRITE_SIZE per step, separate --pmc passes (gfx950 tallies 128-B reads at 64 B): "
@@ -360,6 +362,12 @@ def main():
                 ms, n, b = solo[dom]
                 dk["alone"] = {"kernel_ms": ms / n, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                "note": "the same launches (twice the pairs each) with one internal stream, two extra steps"}
+            if traffic_rec is not None:  # the same capture, this kernel's launches: L2 <-> fabric bytes per launch
+                kname = dk["kernel"].split(" (")[0]
+                for name, v in traffic_rec.items():
+                    if isinstance(v, dict) and kname in name and "hbm_bytes_per_launch" in v:
+                        dk["traffic"] = v["hbm_bytes_per_launch"]
+                        dk["traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / dk["bytes_per_launch"]
             roof["dominant_kernel"] = dk
         # all FFT passes of both stencils over the two stages' wall time
         sb = (sum(extra[c][2] / 2 for c in (0, 2, 3, 5)) + sum(cols[c][2] / steps_for_cols for c in (1, 4))) / frames_here  # per frame
