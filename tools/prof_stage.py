@@ -19,7 +19,7 @@ stocks = filmstock.builtin_stocks()
 neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
 proc = HipProcessor(device=0)
 ctx = proc.ctx
-img = synthetic_frame_device(H, W)
+img = synthetic_frame_device(H, W, kind=os.environ.get("FRAME", "noise"))  # FRAME=smooth: photograph-like
 params = proc.prepare(neg, 6, 0.4, (W, H), seed=20260630, print_film=prt, halation_green_factor=0.3, exp_kelvin=6000,
                       color_masking=1.0, matrix=REC709_TO_XYZ, frame_width=fw, frame_height=fw * H / W)
 ctx.set_option("stencil_variant", variant)
