@@ -414,24 +414,29 @@ def main():
         n_e2e = min(args.frames, 16)
         host4 = torch.cat([frame, torch.ones_like(frame[..., :1])], dim=-1).cpu().pin_memory()  # gpu_processor.py:765
         payload = {"image_array": host4, "output_resolution": (W, H), "canvas_resolution": None, "pipeline_resolution": (W, H)}
+        host3 = frame.cpu().pin_memory()  # what extract_image_data_cpu hands over with HipProcessor(payload_alpha=False)
+        payload3 = dict(payload, image_array=host3)
         kw = dict(settings, seed=GRAIN_SEED, matrix=REC709_TO_XYZ)
         legs = {}
-        for name, execute, collect in (
+        for name, pay, execute, collect in (
                 # (a frame is "exported" by looking at it and dropping it: holding every result would make each frame allocate
                 # fresh pinned memory instead of reusing the previous frames' buffers)
-                ("serial", lambda t, pl: int(proc.process_preloaded(pl, neg, 6, 0.4, **kw)[0, 0, 0]), None),
-                ("overlapped", lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0]))):
-            BatchSharder(0, 1).run([0, 1], lambda t: payload, execute, collect=collect)  # warm-up (pinned pools, streams)
+                ("serial", payload, lambda t, pl: int(proc.process_preloaded(pl, neg, 6, 0.4, **kw)[0, 0, 0]), None),
+                ("overlapped", payload, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0])),
+                ("overlapped_rgb", payload3, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0]))):
+            BatchSharder(0, 1).run([0, 1], lambda t: pay, execute, collect=collect)  # warm-up (pinned pools, streams)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            res, skipped = BatchSharder(0, 1).run(list(range(n_e2e)), lambda t: payload, execute, collect=collect)
+            res, skipped = BatchSharder(0, 1).run(list(range(n_e2e)), lambda t: pay, execute, collect=collect)
             torch.cuda.synchronize()
             legs[name] = H * W / 1e6 * len(res) / (time.perf_counter() - t0)
         result["pcie_inclusive"] = {
             "value": legs["overlapped"], "unit": "MP/s", "frames": n_e2e, "serial": legs["serial"],
+            "without_alpha_plane": legs["overlapped_rgb"],
             "note": "BatchSharder.run over the two-phase API: pinned fp32 HWC4 frame -> device, render, uint8 result -> pinned host "
                     "memory. value: one frame in flight while the next is submitted (upload, render and download on three streams); "
-                    "serial: process_preloaded frame after frame.  Upload-bound (384 MB per 24 MP frame); not part of `value`"}
+                    "serial: process_preloaded frame after frame.  Upload-bound (384 MB per 24 MP frame); without_alpha_plane: the same "
+                    "with the (H, W, 3) payload of HipProcessor(payload_alpha=False), 288 MB per frame.  Not part of `value`"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -49,12 +49,16 @@ class PendingFrame:
 class HipProcessor:
     """Drop-in for the hot path of CpuProcessor / GpuProcessor (gui.py:1584-1585)."""
 
-    def __init__(self, cameras=None, lenses=None, device: int = 0):
+    def __init__(self, cameras=None, lenses=None, device: int = 0, payload_alpha: bool = True):
+        """payload_alpha: extract_image_data_cpu appends the constant alpha plane like upstream (gpu_processor.py:765: its wgpu
+        texture is rgba32float).  Nothing on this backend reads it -- the device path takes 3- and 4-channel frames alike -- and
+        batch export is bound by the upload of the payload: with payload_alpha=False the frame crosses PCIe a quarter smaller."""
         import torch
 
         self._torch = torch
         self.cameras = cameras
         self.lenses = lenses
+        self.payload_alpha = bool(payload_alpha)
         self.ctx = HipContext(device)
         self.device = self.ctx.device  # NB: a torch device, not a wgpu device (gui.py:1652 uses bitmap mode)
         # comparison dicts, same role as cpu_processor.py:41-45 / gpu_processor.py
@@ -172,7 +176,7 @@ class HipProcessor:
                                cache=True, chroma_nr=0, max_scale=400.0, canvas_mode="No", canvas_scale=1.0,
                                canvas_ratio=1.0, **kwargs):
         """PHASE 1 of the two-phase batch API (gpu_processor.py:715-783): pure host work, touches
-        no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32."""
+        no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32 ((H, W, 3) with payload_alpha=False)."""
         if lens_correction and cam is not None and lens is not None:
             # the reference corrects only when both are given (cpu_processor.py:107-108, effects.py:22-30); lensfun is not
             # part of the accelerated path, and rendering an uncorrected frame in its place would be a silent difference
@@ -228,8 +232,11 @@ class HipProcessor:
         if canvas_mode != "No":  # gpu_processor.py:767-771
             res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
             canvas_res = (res[1], res[0])
-        if image.shape[2] == 3:
+        alpha = getattr(self, "payload_alpha", True)
+        if image.shape[2] == 3 and alpha:
             image = np.concatenate([image, np.ones_like(image[..., :1])], axis=-1)  # gpu_processor.py:765
+        elif image.shape[2] == 4 and not alpha:
+            image = image[..., :3]
         image = np.ascontiguousarray(image, dtype=np.float32)
         return {
             "image_array": image,

@@ -276,3 +276,17 @@ def test_icc_transform_is_applied_to_the_output_lut_in_8_bits(proc):
     np.testing.assert_array_equal(icc, want)
     assert icc.dtype == np.float32 and len(np.unique(np.round(icc * 255))) <= 256
     assert np.abs(icc - plain).max() <= 1.5 / 255 and not np.array_equal(icc, plain)  # 8-bit quantisation happened
+
+
+def test_payload_without_the_alpha_plane():
+    """HipProcessor(payload_alpha=False): phase 1 hands over (H, W, 3) -- nothing on this backend reads upstream's constant alpha
+    (gpu_processor.py:765), and the frame crosses PCIe a quarter smaller; 4-channel sources lose theirs."""
+    proc = HipProcessor.__new__(HipProcessor)
+    proc.payload_alpha = False
+    img = np.random.default_rng(3).uniform(0, 1, (40, 60, 3)).astype(np.float32)
+    p = HipProcessor.extract_image_data_cpu(proc, img, lens_correction=False)
+    assert p["image_array"].shape == (40, 60, 3) and p["image_array"].dtype == np.float32
+    np.testing.assert_array_equal(p["image_array"], img)
+    rgba = np.concatenate([img, np.ones_like(img[..., :1])], axis=-1)
+    p4 = HipProcessor.extract_image_data_cpu(proc, rgba, lens_correction=False)
+    np.testing.assert_array_equal(p4["image_array"], img)
