@@ -416,6 +416,9 @@ def main():
         payload = {"image_array": host4, "output_resolution": (W, H), "canvas_resolution": None, "pipeline_resolution": (W, H)}
         host3 = frame.cpu().pin_memory()  # what extract_image_data_cpu hands over with HipProcessor(payload_alpha=False)
         payload3 = dict(payload, image_array=host3)
+        # ... and as LibRaw's 16-bit output with the conversion of raw_conversion.py:50-52 on the device (r2f_decode_u16)
+        host16 = (frame.clamp(0, 1) * 65535).to(torch.int32).to(torch.int16).cpu().pin_memory()  # the 16 bits of a uint16 frame
+        payload16 = dict(payload, image_array=host16, u16_factor=1.0)
         kw = dict(settings, seed=GRAIN_SEED, matrix=REC709_TO_XYZ)
         legs = {}
         for name, pay, execute, collect in (
@@ -423,7 +426,8 @@ def main():
                 # fresh pinned memory instead of reusing the previous frames' buffers)
                 ("serial", payload, lambda t, pl: int(proc.process_preloaded(pl, neg, 6, 0.4, **kw)[0, 0, 0]), None),
                 ("overlapped", payload, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0])),
-                ("overlapped_rgb", payload3, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0]))):
+                ("overlapped_rgb", payload3, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0])),
+                ("overlapped_u16", payload16, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0]))):
             BatchSharder(0, 1).run([0, 1], lambda t: pay, execute, collect=collect)  # warm-up (pinned pools, streams)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -432,11 +436,12 @@ def main():
             legs[name] = H * W / 1e6 * len(res) / (time.perf_counter() - t0)
         result["pcie_inclusive"] = {
             "value": legs["overlapped"], "unit": "MP/s", "frames": n_e2e, "serial": legs["serial"],
-            "without_alpha_plane": legs["overlapped_rgb"],
+            "without_alpha_plane": legs["overlapped_rgb"], "uint16_payload": legs["overlapped_u16"],
             "note": "BatchSharder.run over the two-phase API: pinned fp32 HWC4 frame -> device, render, uint8 result -> pinned host "
                     "memory. value: one frame in flight while the next is submitted (upload, render and download on three streams); "
                     "serial: process_preloaded frame after frame.  Upload-bound (384 MB per 24 MP frame); without_alpha_plane: the same "
-                    "with the (H, W, 3) payload of HipProcessor(payload_alpha=False), 288 MB per frame.  Not part of `value`"}
+                    "with the (H, W, 3) payload of HipProcessor(payload_alpha=False), 288 MB per frame; uint16_payload: the decoded frame handed over as LibRaw's 16-bit output "
+                    "(144 MB per frame), converted by r2f_decode_u16 on the device.  Not part of `value`"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -223,6 +223,15 @@ int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint3
  * (H, W, 3) / (out_h, out_w, 3) on the device, out_h <= H, out_w <= W. */
 int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
 
+/* The hand-off from RAW decoding: the last two lines of raw_to_linear (raw_conversion.py:50-52) applied to LibRaw's 16-bit
+ * output on the device, so that a decoded frame crosses PCIe as uint16 (6 bytes per pixel) instead of float32 (12 or 16):
+ * dst = float(src) / divisor (65535, one correctly rounded fp32 division) * factor (the float32 of 2 ** calc_exposure(...),
+ * color_processing.py:71-99 -- computed by the caller, raw2film_amd.decode.auto_exposure).  src: uint16 (H, W, channels) on
+ * the device, channels 3 or 4 (a fourth is dropped); dst: float32 (H, W, 3), clamped at 65504 like every frame the GPU path
+ * uploads (gpu_processor.py:275).  Bit-identical to the NumPy expressions. */
+int r2f_decode_u16(r2f_ctx* ctx, const uint16_t* src_hwc, int H, int W, int channels, float divisor, float factor, float* dst_f32_hwc3,
+                   void* stream);
+
 /* The GPU processor's preview blit, shaders/copy_to_int.wgsl as bound by gpu_processor.py:1416-1539: the display-referred float
  * frame (H, W, 3) sampled bilinearly (clamp to edge) into an RGBA8 destination (dst_h, dst_w, 4): inside the scaled image the
  * sample (alpha 255), elsewhere inside the canvas bounds the canvas colour, transparent outside.  The transform is the shader's

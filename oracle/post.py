@@ -169,3 +169,27 @@ def resize_lanczos4_f32(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
         term = (hor[rows[:, k]] * ya[:, k, None, None]).astype(F32)
         out = term if out is None else (out + term).astype(F32)
     return out
+
+
+def decode_u16(frame_u16: np.ndarray, exp_comp: float) -> np.ndarray:
+    """raw_to_linear's last two lines (raw_conversion.py:50-52) on LibRaw's 16-bit output, then the upload clamp of the GPU
+    path (gpu_processor.py:275): float32(u) / 65535.0, times 2 ** exp_comp as NumPy applies a Python float to a float32 array."""
+    rgb = frame_u16[..., :3].astype(np.float32) / 65535.0
+    rgb *= 2**exp_comp
+    return np.clip(rgb, 0, 65504)
+
+
+def calc_exposure(rgb: np.ndarray, ref_exposure: float = 0.18, metadata: dict | None = None) -> float:
+    """color_processing.calc_exposure (color_processing.py:71-99): exposure compensation in stops from the power mean of every
+    second green sample; the exponent comes from the EXIF exposure triangle when there is one (f/4 when EXIF has no aperture)."""
+    lum = rgb[::2, ::2, 1]
+    factor = 3
+    if metadata is not None:
+        n = metadata.get("EXIF:FNumber")
+        if n and n != "undef":
+            factor = n**2 / metadata["EXIF:ISO"] / metadata["EXIF:ExposureTime"]
+        else:
+            factor = 4**2 / metadata["EXIF:ISO"] / metadata["EXIF:ExposureTime"]
+        factor = math.sqrt(factor) + 1
+    average = (lum ** (1 / factor)).mean() ** factor
+    return math.log2(ref_exposure / average)

@@ -144,6 +144,7 @@ _SIGNATURES = {
     ),
     "r2f_lanczos4_table_f32": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "r2f_resize_area_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "r2f_decode_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "r2f_blit_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _P(Blit), C.c_void_p]),
     "r2f_histogram_render": (
         C.c_int,

@@ -385,6 +385,19 @@ class HipContext:
                                                  out.data_ptr(), int(out_h), int(out_w), self._stream()))
         return out
 
+    def decode_u16(self, image_u16, factor: float, divisor: float = 65535.0):
+        """raw_to_linear's last two lines (raw_conversion.py:50-52) on the device: float32(u) / divisor * float32(factor) for a
+        uint16 (H, W, 3 | 4) CUDA tensor (LibRaw's 16-bit output; int16 tensors are read as the same bits) -> float32 (H, W, 3)."""
+        torch = self._torch
+        if not (image_u16.is_cuda and image_u16.dtype in (torch.uint16, torch.int16) and image_u16.is_contiguous()
+                and image_u16.dim() == 3 and image_u16.shape[2] in (3, 4)):
+            raise ValueError("decode_u16 needs a contiguous uint16 (H, W, 3 or 4) CUDA tensor")
+        out = torch.empty((int(image_u16.shape[0]), int(image_u16.shape[1]), 3), dtype=torch.float32, device=self.device)
+        self._check(self._lib.r2f_decode_u16(self._h, image_u16.data_ptr(), int(image_u16.shape[0]), int(image_u16.shape[1]),
+                                             int(image_u16.shape[2]), float(np.float32(divisor)), float(np.float32(factor)),
+                                             out.data_ptr(), self._stream()))
+        return out
+
     def blit_rgba8(self, image_f32, dst_rgba, transform: dict):
         """shaders/copy_to_int.wgsl: the float (H, W, 3) frame letterboxed into the uint8 (h, w, 4) destination tensor.
         `transform`: the dict of geometry.blit_transform (the shader's uniform block)."""

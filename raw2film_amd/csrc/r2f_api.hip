@@ -1679,6 +1679,16 @@ int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8
     return R2F_OK;
 }
 
+int r2f_decode_u16(r2f_ctx* ctx, const uint16_t* src_hwc, int H, int W, int channels, float divisor, float factor, float* dst_f32_hwc3,
+                   void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (!src_hwc || !dst_f32_hwc3 || H <= 0 || W <= 0 || (channels != 3 && channels != 4) || !(divisor > 0.f))
+        return fail(ctx, R2F_EINVAL, "decode_u16: a non-empty 3- or 4-channel frame and a positive divisor are required");
+    R2F_HIP(ctx, launch_decode_u16(src_hwc, (long long)H * W, channels, divisor, factor, dst_f32_hwc3, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
 int r2f_blit_rgba8(r2f_ctx* ctx, const float* src_f32_hwc, int H, int W, uint8_t* dst_rgba, int dst_h, int dst_w, const r2f_blit* t,
                    void* stream) {
     if (!ctx) return R2F_EINVAL;

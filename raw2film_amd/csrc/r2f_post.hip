@@ -273,6 +273,56 @@ __global__ __launch_bounds__(256) void histogram_render_kernel(const HistArgs a)
 
 }  // namespace
 
+namespace {
+
+// The hand-off from RAW decoding, raw_to_linear's last two lines (raw_conversion.py:50-52) on LibRaw's 16-bit output:
+// x = float(u) / 65535 (one correctly rounded fp32 division, like NumPy's), then x *= the float32 exposure factor, then the
+// upload clamp of the GPU path (gpu_processor.py:275: min(x, 65504); the input cannot be negative).
+// One lane = 4 pixels of an (n, ch) uint16 frame -> 12 floats of the (n, 3) float frame.
+struct DecodeU16Args {
+    const uint16_t* src;
+    float* dst;
+    long long n;  // pixels
+    int ch;       // 3 or 4 (a fourth channel is dropped)
+    float divisor, factor;
+    int vec;      // 1: both buffers 16-byte aligned and ch == 3 -> 8-byte loads, 16-byte stores
+};
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void decode_u16_kernel(const DecodeU16Args a) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // quad of pixels
+    const long long p0 = q * 4;
+    if (p0 >= a.n) return;
+    if (a.vec && p0 + 4 <= a.n) {
+        const uint2* s2 = reinterpret_cast<const uint2*>(a.src + p0 * 3);  // 24 bytes = 12 samples
+        const uint2 w0 = s2[0], w1 = s2[1], w2 = s2[2];
+        const unsigned w[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+        float f[12];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f[2 * i] = fminf((float)(w[i] & 0xffffu) / a.divisor * a.factor, 65504.0f);
+            f[2 * i + 1] = fminf((float)(w[i] >> 16) / a.divisor * a.factor, 65504.0f);
+        }
+        float4* d4 = reinterpret_cast<float4*>(a.dst + p0 * 3);
+        d4[0] = make_float4(f[0], f[1], f[2], f[3]);
+        d4[1] = make_float4(f[4], f[5], f[6], f[7]);
+        d4[2] = make_float4(f[8], f[9], f[10], f[11]);
+        return;
+    }
+    for (long long p = p0; p < min(p0 + 4, a.n); ++p)
+        for (int c = 0; c < 3; ++c) a.dst[p * 3 + c] = fminf((float)a.src[p * a.ch + c] / a.divisor * a.factor, 65504.0f);
+}
+
+}  // namespace
+
+hipError_t launch_decode_u16(const uint16_t* src, long long n, int ch, float divisor, float factor, float* dst, hipStream_t s) {
+    DecodeU16Args a{src, dst, n, ch, divisor, factor,
+                    (ch == 3 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) ? 1 : 0};
+    const long long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(decode_u16_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_area_u8(const uint8_t* src, int H, int W, uint8_t* dst, int out_h, int out_w, hipStream_t s) {
     AreaU8Args a{src, dst, H, W, out_h, out_w};
     hipLaunchKernelGGL(resize_area_u8_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);

@@ -174,7 +174,7 @@ class HipProcessor:
     def extract_image_data_cpu(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24,
                                rotation=0.0, zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True,
                                cache=True, chroma_nr=0, max_scale=400.0, canvas_mode="No", canvas_scale=1.0,
-                               canvas_ratio=1.0, **kwargs):
+                               canvas_ratio=1.0, exposure=None, metadata=None, **kwargs):
         """PHASE 1 of the two-phase batch API (gpu_processor.py:715-783): pure host work, touches
         no instance state.  Returns the same payload dict; `image_array` is (H, W, 4) float32 ((H, W, 3) with payload_alpha=False)."""
         if lens_correction and cam is not None and lens is not None:
@@ -183,6 +183,14 @@ class HipProcessor:
             raise NotImplementedError("lens correction (lensfunpy, effects.py:22-43) is outside the accelerated path: "
                                       "pass lens_correction=False or no cam / lens")
         image = self._load_decoded(src)
+        u16_factor = None
+        if image.dtype == np.uint16:
+            # raw_to_linear's tail (raw_conversion.py:50-52) moves to the device: the auto exposure is measured here, on the
+            # whole decoded frame like upstream (before any crop), unless the caller brings the stops along
+            from . import decode
+
+            stops = decode.auto_exposure(image, metadata=metadata) if exposure is None else float(exposure)
+            u16_factor = float(decode.exposure_factor(stops))
         aspect = frame_width / frame_height
         warp = None
         if rotation:
@@ -233,13 +241,17 @@ class HipProcessor:
             res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
             canvas_res = (res[1], res[0])
         alpha = getattr(self, "payload_alpha", True)
-        if image.shape[2] == 3 and alpha:
+        if u16_factor is not None:
+            image = np.ascontiguousarray(image[..., :3])
+        elif image.shape[2] == 3 and alpha:
             image = np.concatenate([image, np.ones_like(image[..., :1])], axis=-1)  # gpu_processor.py:765
         elif image.shape[2] == 4 and not alpha:
             image = image[..., :3]
-        image = np.ascontiguousarray(image, dtype=np.float32)
+        if u16_factor is None:
+            image = np.ascontiguousarray(image, dtype=np.float32)
         return {
             "image_array": image,
+            "u16_factor": u16_factor,  # float32 exposure factor of a uint16 payload (converted on the device), else None
             "final_resolution": final_resolution,
             "output_resolution": (out_w, out_h),
             "canvas_resolution": canvas_res,
@@ -266,6 +278,8 @@ class HipProcessor:
             raise TypeError(f"unsupported src type {type(src)!r}")
         if image.ndim != 3 or image.shape[2] not in (3, 4):
             raise ValueError(f"decoded frame must be (H, W, 3|4), got {image.shape}")
+        if image.dtype == np.uint16:  # LibRaw's 16-bit output: converted on the device (decode.py, r2f_decode_u16)
+            return image
         image = np.asarray(image, dtype=np.float32)
         return np.clip(image, 0, 65504)  # gpu_processor.py:275
 
@@ -279,15 +293,18 @@ class HipProcessor:
                 canvas_ratio=1.0, halation_intensity=1.0, halation=True, halation_size=1.0, halation_green_factor=0.4,
                 sharpness=True, sharpening_strength=0.0, sharpening_sigma=1.0, chroma_nr=0, grain=2,
                 highlight_burn=0.0, burn_scale=50.0, half_size=True, cache=True, color_masking=None, max_scale=400.0,
-                seed=None, **_):
+                seed=None, exposure=None, metadata=None, **_):
         """Load (decoded) frame and render it: np.uint8 (H, W, 3), like cpu_processor.py:414 -- including the CPU processor's
         last step, resolution_scaling of the finished (canvas-framed) frame to the requested resolution (cpu_processor.py:411-412).
         With `dst_texture` (a uint8 (h, w, 4) CUDA tensor standing in for the preview widget's wgpu texture) the call behaves
         like GpuProcessor.process with a destination (gpu_processor.py:1865-1890): the frame is letterboxed into it on the
-        device, `histogram_texture` (same kind of tensor) receives the histogram image, and None is returned."""
+        device, `histogram_texture` (same kind of tensor) receives the histogram image, and None is returned.
+        A uint16 `src` is LibRaw's 16-bit output before raw_to_linear's last two lines (raw_conversion.py:50-52): those run on
+        the device with the auto exposure measured on the host (`metadata`: the EXIF dict calc_exposure reads) or given in stops
+        (`exposure`)."""
         payload = self.extract_image_data_cpu(
             src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
-            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio,
+            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
         )
         if dst_texture is not None:
             self._check_texture(dst_texture, "dst_texture")
@@ -323,13 +340,21 @@ class HipProcessor:
         "cpu" -- like CpuProcessor.process (cpu_processor.py:411-412), the finished frame, canvas included, is scaled to the
         requested resolution (INTER_AREA down, LANCZOS4 up).  dst_texture / histogram_texture: see process()."""
         torch = self._torch
-        image = cpu_payload["image_array"]
-        if isinstance(image, np.ndarray):
-            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        image = self._payload_tensor(cpu_payload)
         image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         out_u8 = self._render_preloaded(image, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture,
                                         final_scaling, **settings)
         return None if out_u8 is None else out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def _payload_tensor(self, cpu_payload):
+        """The payload's frame as a torch tensor: float32, or the 16 bits of a uint16 frame (as int16: same bytes)."""
+        torch = self._torch
+        image = cpu_payload["image_array"]
+        if isinstance(image, np.ndarray):
+            if image.dtype == np.uint16:
+                return torch.from_numpy(np.ascontiguousarray(image).view(np.int16))
+            return torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        return image
 
     def submit_preloaded(self, cpu_payload, negative_film, grain_size, grain_sigma, final_scaling="gpu", **settings):
         """process_preloaded without waiting: the upload runs on a copy stream, the render on the current stream, the download
@@ -341,9 +366,7 @@ class HipProcessor:
         if getattr(self, "_up_stream", None) is None:
             self._up_stream = torch.cuda.Stream(device=self.device)
             self._down_stream = torch.cuda.Stream(device=self.device)
-        image = cpu_payload["image_array"]
-        if isinstance(image, np.ndarray):
-            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        image = self._payload_tensor(cpu_payload)
         if not image.is_cuda and not image.is_pinned():
             image = image.pin_memory()  # (a pageable source would make the "asynchronous" copy a synchronous one)
         compute = torch.cuda.current_stream(self.device)
@@ -373,6 +396,10 @@ class HipProcessor:
                 raise ValueError("histogram_texture needs dst_texture (gpu_processor.py:1883: the histogram is only drawn on the "
                                  "destination-texture branch)")
         torch = self._torch
+        if image.dtype in (torch.int16, torch.uint16):  # a decoded 16-bit frame: raw_conversion.py:50-52 on the device
+            if cpu_payload.get("u16_factor") is None:
+                raise ValueError("a uint16 payload needs its exposure factor (`u16_factor`, extract_image_data_cpu sets it)")
+            image = self.ctx.decode_u16(image.contiguous(), cpu_payload["u16_factor"])
         layout = None  # the payload is (H, W, C) like the reference's; the device pre-path hands on (3, H, W) planes
         warp = cpu_payload.get("warp")
         if warp:  # free rotation (effects.rotate) + the crops behind it + quarter turns (np.rot90 on the planes)
