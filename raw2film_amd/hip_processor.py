@@ -302,16 +302,20 @@ class HipProcessor:
         A uint16 `src` is LibRaw's 16-bit output before raw_to_linear's last two lines (raw_conversion.py:50-52): those run on
         the device with the auto exposure measured on the host (`metadata`: the EXIF dict calc_exposure reads) or given in stops
         (`exposure`)."""
-        payload = self.extract_image_data_cpu(
-            src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
-            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
-        )
         if dst_texture is not None:
             self._check_texture(dst_texture, "dst_texture")
         if histogram_texture is not None:
             self._check_texture(histogram_texture, "histogram_texture")
-        return self.process_preloaded(
-            payload, negative_film, grain_size, grain_sigma, print_film=print_film, exp_comp=exp_comp,
+        # GpuProcessor.load_image_texture (gpu_processor.py:655-719): the pre-processed frame stays on the device while the
+        # load parameters do not change -- a re-render with other film settings neither prepares nor uploads it again
+        self.load_image_texture(
+            src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
+            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
+        )
+        image, layout, payload = self._texture
+        out_u8 = self._render_prepared(
+            image, layout, payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture, "cpu",
+            print_film=print_film, exp_comp=exp_comp,
             red_light=red_light, green_light=green_light, blue_light=blue_light, projector_kelvin=projector_kelvin,
             shadow_comp=shadow_comp, sat_adjust=sat_adjust, gamma_func=gamma_func, exp_kelvin=exp_kelvin, tint=tint,
             inversion_gamma=inversion_gamma, idealized_curve=idealized_curve, inversion=inversion, push_pull=push_pull,
@@ -321,8 +325,41 @@ class HipProcessor:
             sharpening_strength=sharpening_strength, sharpening_sigma=sharpening_sigma, grain=grain,
             highlight_burn=highlight_burn, burn_scale=burn_scale, color_masking=color_masking, seed=seed,
             canvas_mode=canvas_mode, canvas_scale=canvas_scale, canvas_ratio=canvas_ratio,
-            dst_texture=dst_texture, histogram_texture=histogram_texture, final_scaling="cpu",
         )
+        return None if out_u8 is None else out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def load_image_texture(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24, rotation=0.0,
+                           zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True, cache=True, chroma_nr=0,
+                           max_scale=400.0, canvas_mode="No", canvas_scale=1.0, canvas_ratio=1.0, exposure=None, metadata=None):
+        """GpuProcessor.load_image_texture (gpu_processor.py:655-719): prepare and upload the frame unless the load parameters
+        are those of the frame that is already on the device.  A path compares by value like upstream's `src`; an array by
+        identity (the caller hands in the same object again; one that was modified in place needs `cache=False`)."""
+        new_param_dict = {
+            "src": src if isinstance(src, str) else None, "cam": cam, "lens": lens, "lens_correction": lens_correction,
+            "frame_width": frame_width, "frame_height": frame_height, "rotation": rotation, "zoom": zoom,
+            "rotate_times": rotate_times, "flip": flip, "resolution": resolution, "half_size": half_size, "chroma_nr": chroma_nr,
+            "max_scale": max_scale, "canvas_mode": canvas_mode, "canvas_scale": canvas_scale, "canvas_ratio": canvas_ratio,
+            "exposure": exposure, "metadata": metadata,
+        }
+        same_src = isinstance(src, str) or src is getattr(self, "_texture_src", None)
+        if cache and same_src and getattr(self, "_texture", None) is not None and new_param_dict == getattr(self, "image_param_dict", None):
+            return
+        cpu_payload = self.extract_image_data_cpu(
+            src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
+            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
+        )
+        self.prepare_gpu_textures(cpu_payload)
+        self.image_param_dict = new_param_dict
+        self._texture_src = None if isinstance(src, str) else src
+
+    def prepare_gpu_textures(self, cpu_payload):
+        """PHASE 2's stateful half (gpu_processor.py:785-790): upload the payload's frame and run the device pre-path on it
+        (uint16 conversion, free rotation, chroma NR, preview scaling); the result is the frame the pipeline reads."""
+        image = self._payload_tensor(cpu_payload).to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
+        image, layout = self._prepare_device_frame(image, cpu_payload)
+        self._texture = (image, layout, cpu_payload)
+        self.image_param_dict = None  # (a payload from outside: no load parameters to compare the next process() with)
+        self._texture_src = None
 
     def _check_texture(self, t, what):
         import torch
@@ -339,11 +376,10 @@ class HipProcessor:
         final_scaling: "gpu" -- like GpuProcessor, the canvas keeps its size and only a `max_scale` render is scaled back up;
         "cpu" -- like CpuProcessor.process (cpu_processor.py:411-412), the finished frame, canvas included, is scaled to the
         requested resolution (INTER_AREA down, LANCZOS4 up).  dst_texture / histogram_texture: see process()."""
-        torch = self._torch
-        image = self._payload_tensor(cpu_payload)
-        image = image.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
-        out_u8 = self._render_preloaded(image, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture,
-                                        final_scaling, **settings)
+        self.prepare_gpu_textures(cpu_payload)
+        image, layout, _ = self._texture
+        out_u8 = self._render_prepared(image, layout, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture,
+                                       histogram_texture, final_scaling, **settings)
         return None if out_u8 is None else out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
 
     def _payload_tensor(self, cpu_payload):
@@ -388,13 +424,12 @@ class HipProcessor:
     def _render_preloaded(self, image, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture,
                           final_scaling, **settings):
         """The device half of process_preloaded on an uploaded frame; returns the uint8 device result (None with a dst_texture)."""
-        if dst_texture is not None:
-            self._check_texture(dst_texture, "dst_texture")
-        if histogram_texture is not None:
-            self._check_texture(histogram_texture, "histogram_texture")
-            if dst_texture is None:
-                raise ValueError("histogram_texture needs dst_texture (gpu_processor.py:1883: the histogram is only drawn on the "
-                                 "destination-texture branch)")
+        image, layout = self._prepare_device_frame(image, cpu_payload)
+        return self._render_prepared(image, layout, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture,
+                                     histogram_texture, final_scaling, **settings)
+
+    def _prepare_device_frame(self, image, cpu_payload):
+        """The device pre-path on an uploaded payload frame -> (frame, layout) as the pipeline reads it."""
         torch = self._torch
         if image.dtype in (torch.int16, torch.uint16):  # a decoded 16-bit frame: raw_conversion.py:50-52 on the device
             if cpu_payload.get("u16_factor") is None:
@@ -416,6 +451,19 @@ class HipProcessor:
                 image, layout = self.ctx.resize_area(image.contiguous(), *rt, layout=layout), "chw"
             else:  # cv.INTER_LANCZOS4 on the float frame (utils.py:237-242)
                 image, layout = self.ctx.resize_lanczos4_f32(image.contiguous(), *rt, layout=layout), "chw"
+        return image, layout
+
+    def _render_prepared(self, image, layout, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture,
+                         final_scaling, **settings):
+        """The pipeline and the post-path on a prepared device frame (which is only read: it can be rendered again)."""
+        if dst_texture is not None:
+            self._check_texture(dst_texture, "dst_texture")
+        if histogram_texture is not None:
+            self._check_texture(histogram_texture, "histogram_texture")
+            if dst_texture is None:
+                raise ValueError("histogram_texture needs dst_texture (gpu_processor.py:1883: the histogram is only drawn on the "
+                                 "destination-texture branch)")
+        torch = self._torch  # noqa: F841
         out_f32, out_u8 = self._execute_pipeline(image, negative_film, grain_size, grain_sigma, want_f32=dst_texture is not None,
                                                  want_u8=True, layout=layout, **settings)
         if dst_texture is not None:

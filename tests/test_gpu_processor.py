@@ -336,3 +336,43 @@ def test_submitted_frames_equal_processed_frames_and_overlap_is_safe(proc):
     res, skipped = BatchSharder(0, 1).run(list(range(5)), lambda i: payloads[i],
                                           lambda i, p: proc.submit_preloaded(p, neg, 6, 0.4, **kw), collect=lambda i, h: h.result())
     assert skipped == [] and all(np.array_equal(res[i], want[i]) for i in range(5))
+
+
+def test_the_frame_stays_on_the_device_between_renders_with_the_same_load_parameters():
+    """GpuProcessor.load_image_texture's convention (gpu_processor.py:655-719): process() prepares and uploads a frame only when
+    its load parameters (or the source object) change; a re-render with other film settings reads the frame already there."""
+    from raw2film_amd import HipProcessor, filmstock
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    rng = np.random.default_rng(21)
+    img = rng.uniform(0.0, 1.0, (96, 144, 3)).astype(np.float32)
+    proc = HipProcessor(device=0)
+    calls = []
+    extract = proc.extract_image_data_cpu
+    proc.extract_image_data_cpu = lambda *a, **k: (calls.append(1), extract(*a, **k))[1]
+    kw = dict(print_film=prt, lens_correction=False, seed=3)
+    a = proc.process(img, neg, 6, 0.4, **kw)
+    b = proc.process(img, neg, 6, 0.4, exp_comp=1.0, **kw)  # film settings only: no second load
+    assert len(calls) == 1 and not np.array_equal(a, b)
+    c = proc.process(img, neg, 6, 0.4, zoom=1.2, **kw)  # a load parameter: prepared again
+    assert len(calls) == 2 and c.shape != a.shape or not np.array_equal(c, a)
+    d = proc.process(img.copy(), neg, 6, 0.4, zoom=1.2, **kw)  # another array object, same parameters: loaded again
+    assert len(calls) == 3
+    np.testing.assert_array_equal(d, c)
+    img2 = img.copy()
+    e1 = proc.process(img2, neg, 6, 0.4, **kw)
+    img2 *= 0.5  # modified in place: the caller says so with cache=False
+    e2 = proc.process(img2, neg, 6, 0.4, cache=False, **kw)
+    assert len(calls) == 5 and not np.array_equal(e1, e2)
+    # results never depend on what was cached: a fresh processor renders the same frames
+    fresh = HipProcessor(device=0)
+    np.testing.assert_array_equal(fresh.process(img, neg, 6, 0.4, exp_comp=1.0, **kw), b)
+    np.testing.assert_array_equal(fresh.process(img, neg, 6, 0.4, **kw), a)
+    # a payload from outside replaces the cached frame
+    proc.process_preloaded(fresh.extract_image_data_cpu(img * 0.25, lens_correction=False), neg, 6, 0.4, **kw)
+    n = len(calls)
+    np.testing.assert_array_equal(proc.process(img, neg, 6, 0.4, **kw), a)
+    assert len(calls) == n + 1
+    proc.close()
+    fresh.close()
