@@ -182,7 +182,10 @@ class HipProcessor:
             # part of the accelerated path, and rendering an uncorrected frame in its place would be a silent difference
             raise NotImplementedError("lens correction (lensfunpy, effects.py:22-43) is outside the accelerated path: "
                                       "pass lens_correction=False or no cam / lens")
-        image = self._load_decoded(src)
+        # _internal (load_image_texture: the payload never leaves this object): no alpha plane, and the clamp of
+        # gpu_processor.py:275 runs on the device after the upload instead of as a 12 B/px pass over host memory
+        internal = bool(kwargs.get("_internal"))
+        image = self._load_decoded(src, clip=not internal)
         u16_factor = None
         if image.dtype == np.uint16:
             # raw_to_linear's tail (raw_conversion.py:50-52) moves to the device: the auto exposure is measured here, on the
@@ -240,7 +243,7 @@ class HipProcessor:
         if canvas_mode != "No":  # gpu_processor.py:767-771
             res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
             canvas_res = (res[1], res[0])
-        alpha = getattr(self, "payload_alpha", True)
+        alpha = getattr(self, "payload_alpha", True) and not internal
         if u16_factor is not None:
             image = np.ascontiguousarray(image[..., :3])
         elif image.shape[2] == 3 and alpha:
@@ -252,6 +255,7 @@ class HipProcessor:
         return {
             "image_array": image,
             "u16_factor": u16_factor,  # float32 exposure factor of a uint16 payload (converted on the device), else None
+            "clip_on_device": internal and u16_factor is None,  # the float frame still has to be clamped to [0, 65504]
             "final_resolution": final_resolution,
             "output_resolution": (out_w, out_h),
             "canvas_resolution": canvas_res,
@@ -264,7 +268,7 @@ class HipProcessor:
         }
 
     @staticmethod
-    def _load_decoded(src):
+    def _load_decoded(src, clip=True):
         if isinstance(src, np.ndarray):
             image = src
         elif isinstance(src, str) and src.lower().endswith(".npy"):
@@ -281,7 +285,7 @@ class HipProcessor:
         if image.dtype == np.uint16:  # LibRaw's 16-bit output: converted on the device (decode.py, r2f_decode_u16)
             return image
         image = np.asarray(image, dtype=np.float32)
-        return np.clip(image, 0, 65504)  # gpu_processor.py:275
+        return np.clip(image, 0, 65504) if clip else image  # gpu_processor.py:275 (clip=False: clamped after the upload)
 
     # ------------------------------------------------------------------ the operator surface
     def process(self, src, negative_film, grain_size, grain_sigma, dst_texture=None, histogram_texture=None,
@@ -347,6 +351,7 @@ class HipProcessor:
         cpu_payload = self.extract_image_data_cpu(
             src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
             half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
+            _internal=True,
         )
         self.prepare_gpu_textures(cpu_payload)
         self.image_param_dict = new_param_dict
@@ -435,6 +440,8 @@ class HipProcessor:
             if cpu_payload.get("u16_factor") is None:
                 raise ValueError("a uint16 payload needs its exposure factor (`u16_factor`, extract_image_data_cpu sets it)")
             image = self.ctx.decode_u16(image.contiguous(), cpu_payload["u16_factor"])
+        elif cpu_payload.get("clip_on_device"):
+            image = image.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, on the uploaded copy
         layout = None  # the payload is (H, W, C) like the reference's; the device pre-path hands on (3, H, W) planes
         warp = cpu_payload.get("warp")
         if warp:  # free rotation (effects.rotate) + the crops behind it + quarter turns (np.rot90 on the planes)

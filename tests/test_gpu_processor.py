@@ -376,3 +376,24 @@ def test_the_frame_stays_on_the_device_between_renders_with_the_same_load_parame
     assert len(calls) == n + 1
     proc.close()
     fresh.close()
+
+
+def test_process_clamps_the_frame_like_the_reference_load():
+    """load_raw_image clamps the decoded frame to [0, 65504] (gpu_processor.py:275); process() does it on the uploaded copy."""
+    from raw2film_amd import HipProcessor, filmstock
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0.0, 1.0, (64, 96, 3)).astype(np.float32)
+    img[3, 4] = (1e6, -2.0, 70000.0)
+    img[10, 20] = (-1e-3, 0.5, -5.0)
+    proc = HipProcessor(device=0)
+    kw = dict(print_film=prt, lens_correction=False, seed=2)
+    got = proc.process(img, neg, 6, 0.4, **kw)
+    want = proc.process(np.clip(img, 0, 65504), neg, 6, 0.4, **kw)
+    np.testing.assert_array_equal(got, want)
+    payload = proc.extract_image_data_cpu(img, lens_correction=False)  # the public payload is clamped on the host, like upstream's
+    assert payload["image_array"].max() == 65504.0 and payload["image_array"].min() == 0.0 and not payload["clip_on_device"]
+    np.testing.assert_array_equal(proc.process_preloaded(payload, neg, 6, 0.4, **kw), want)
+    proc.close()
