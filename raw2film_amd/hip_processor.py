@@ -74,6 +74,10 @@ class HipProcessor:
         self.last_output = None  # device uint8 (H, W, 3) of the last process()/process_preloaded(): histogram source
 
     def close(self):
+        self._texture = None  # the frame kept on the device for re-renders
+        self._texture_src = None
+        self.image_param_dict = None
+        self.last_output = None
         self.ctx.close()
 
     # ------------------------------------------------------------------ cached loaders
