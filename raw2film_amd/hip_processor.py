@@ -49,16 +49,18 @@ class PendingFrame:
 class HipProcessor:
     """Drop-in for the hot path of CpuProcessor / GpuProcessor (gui.py:1584-1585)."""
 
-    def __init__(self, cameras=None, lenses=None, device: int = 0, payload_alpha: bool = True):
+    def __init__(self, cameras=None, lenses=None, device: int = 0, payload_alpha: bool = True, result_buffers: int = 0):
         """payload_alpha: extract_image_data_cpu appends the constant alpha plane like upstream (gpu_processor.py:765: its wgpu
         texture is rgba32float).  Nothing on this backend reads it -- the device path takes 3- and 4-channel frames alike -- and
-        batch export is bound by the upload of the payload: with payload_alpha=False the frame crosses PCIe a quarter smaller."""
+        batch export is bound by the upload of the payload: with payload_alpha=False the frame crosses PCIe a quarter smaller.
+        result_buffers: see _download (pinned result buffers for interactive use)."""
         import torch
 
         self._torch = torch
         self.cameras = cameras
         self.lenses = lenses
         self.payload_alpha = bool(payload_alpha)
+        self.result_buffers = int(result_buffers)  # 0: process() returns a fresh array; n: views of n pinned buffers in turn (_download)
         self.ctx = HipContext(device)
         self.device = self.ctx.device  # NB: a torch device, not a wgpu device (gui.py:1652 uses bitmap mode)
         # comparison dicts, same role as cpu_processor.py:41-45 / gpu_processor.py
@@ -334,7 +336,7 @@ class HipProcessor:
             highlight_burn=highlight_burn, burn_scale=burn_scale, color_masking=color_masking, seed=seed,
             canvas_mode=canvas_mode, canvas_scale=canvas_scale, canvas_ratio=canvas_ratio,
         )
-        return None if out_u8 is None else out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+        return None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
 
     def load_image_texture(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24, rotation=0.0,
                            zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True, cache=True, chroma_nr=0,
@@ -389,7 +391,25 @@ class HipProcessor:
         image, layout, _ = self._texture
         out_u8 = self._render_prepared(image, layout, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture,
                                        histogram_texture, final_scaling, **settings)
-        return None if out_u8 is None else out_u8.cpu().numpy()  # DEVICE -> HOST, the reference's read_texture/map_sync
+        return None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def _download(self, out_u8):
+        """The uint8 result as a NumPy array.  Default: a fresh array per call, like upstream.  With result_buffers = n > 0 the
+        frame lands in one of n pinned host buffers taken in turn (a 24 MP frame then takes 1.5 instead of 6 ms to come down)
+        and the returned array is a VIEW of it: valid until n more frames of the same size have been returned."""
+        n = getattr(self, "result_buffers", 0)
+        if n <= 0:
+            return out_u8.cpu().numpy()
+        torch = self._torch
+        ring = getattr(self, "_result_ring", None)
+        if ring is None or ring[0].shape != out_u8.shape or len(ring) != n:
+            ring = self._result_ring = [torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(n)]
+            self._result_turn = 0
+        host = ring[self._result_turn % n]
+        self._result_turn += 1
+        host.copy_(out_u8, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return host.numpy()
 
     def _payload_tensor(self, cpu_payload):
         """The payload's frame as a torch tensor: float32, or the 16 bits of a uint16 frame (as int16: same bytes)."""

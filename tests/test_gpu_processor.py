@@ -397,3 +397,26 @@ def test_process_clamps_the_frame_like_the_reference_load():
     assert payload["image_array"].max() == 65504.0 and payload["image_array"].min() == 0.0 and not payload["clip_on_device"]
     np.testing.assert_array_equal(proc.process_preloaded(payload, neg, 6, 0.4, **kw), want)
     proc.close()
+
+
+def test_pinned_result_buffers_return_views_in_turn():
+    from raw2film_amd import HipProcessor, filmstock
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    img = np.random.default_rng(8).uniform(0.0, 1.0, (48, 72, 3)).astype(np.float32)
+    kw = dict(print_film=prt, lens_correction=False, seed=2)
+    plain = HipProcessor(device=0)
+    ring = HipProcessor(device=0, result_buffers=2)
+    want = [plain.process(img, neg, 6, 0.4, exp_comp=e, **kw) for e in (0.0, 0.5, 1.0)]
+    a = ring.process(img, neg, 6, 0.4, exp_comp=0.0, **kw)
+    b = ring.process(img, neg, 6, 0.4, exp_comp=0.5, **kw)
+    np.testing.assert_array_equal(a, want[0])  # two buffers: the first result is still intact after the second call
+    np.testing.assert_array_equal(b, want[1])
+    c = ring.process(img, neg, 6, 0.4, exp_comp=1.0, **kw)
+    np.testing.assert_array_equal(c, want[2])
+    assert np.shares_memory(a, c) and not np.shares_memory(a, b)  # ... and is overwritten by the third
+    fresh = plain.process(img, neg, 6, 0.4, **kw)
+    assert not np.shares_memory(fresh, plain.process(img, neg, 6, 0.4, **kw))  # the default: a new array per call
+    plain.close()
+    ring.close()

@@ -15,7 +15,7 @@ stocks = filmstock.builtin_stocks()
 neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
 rng = np.random.default_rng(0)
 img = (0.18 * 2.0 ** rng.normal(0.0, 1.5, (4000, 6000, 1)) * rng.uniform(0.6, 1.4, (4000, 6000, 3))).astype(np.float32)
-proc = HipProcessor(device=0)
+proc = HipProcessor(device=0, result_buffers=int(os.environ.get("RESULT_BUFFERS", "0")))
 
 
 def timed(**kw):
