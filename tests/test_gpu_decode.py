@@ -76,3 +76,27 @@ def test_uint16_source_renders_like_its_host_decoded_float_frame():
     fixed = proc.process(u16, neg, 6, 0.4, exposure=0.5, **kw)
     np.testing.assert_array_equal(fixed, proc.process(decode.decode_u16_host(u16, 0.5), neg, 6, 0.4, **kw))
     proc.close()
+
+
+def test_uint16_payloads_through_the_pipelined_batch_path():
+    """BatchSharder.run(..., collect=...) with HipProcessor.submit_preloaded on uint16 payloads (upload, device conversion, render
+    and download overlapped across frames) returns what process_preloaded returns frame by frame."""
+    from raw2film_amd import HipProcessor, filmstock
+    from raw2film_amd.sharding import BatchSharder
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    rng = np.random.default_rng(12)
+    frames = [(rng.uniform(0, 1, (90, 132, 3)) ** 2 * 30000).astype(np.uint16) for _ in range(5)]
+    proc = HipProcessor(device=0)
+    kw = dict(print_film=prt, seed=9)
+    prepare = lambda i: proc.extract_image_data_cpu(frames[i], lens_correction=False, exposure=0.25 * i)  # noqa: E731
+    want = [proc.process_preloaded(prepare(i), neg, 6, 0.4, **kw) for i in range(len(frames))]
+    res, skipped = BatchSharder(0, 1).run(list(range(len(frames))), prepare,
+                                          lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw),
+                                          collect=lambda t, h: h.result().copy())
+    assert not skipped and sorted(res) == list(range(len(frames)))
+    for i in range(len(frames)):
+        np.testing.assert_array_equal(res[i], want[i])
+    assert not np.array_equal(want[0], want[1])
+    proc.close()
