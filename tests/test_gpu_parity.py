@@ -860,3 +860,27 @@ def test_identity_halation_channels_are_finished_by_the_front_kernel(ctx, bw):
     ctx.set_option("front_fast", 1)
     assert torch.equal(outs[0], outs[1])
     assert_close(outs[0].cpu().numpy(), ref, 1e-5, 1e-3, "render with the split front")
+
+
+@pytest.mark.parametrize("scale", [229.33, 341.33])
+def test_full_pipeline_on_a_photograph_like_frame(ctx, scale):
+    """Smooth gradients, flat patches (exact ties in the tetrahedron choice, densities sitting on LUT nodes and curve breakpoints),
+    a hard edge and a specular -- the kind of content the white-noise frames never produce -- against the oracle at the contract."""
+    neg, prt, _ = stocks()
+    H, W = 320, 448
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    lum = 0.18 * 2.0 ** (3.0 * np.sin(xx / 97.0) * np.cos(yy / 61.0))
+    img = np.stack([lum * (1.0 + 0.3 * np.sin(yy / 40.0)), lum, lum * (1.0 + 0.3 * np.cos(xx / 53.0))], axis=-1).astype(np.float32)
+    img[40:120, 60:200] = (0.18, 0.18, 0.18)      # a flat grey card: every pixel the same cell, dr == dg == db ties
+    img[150:220, 250:400] = (0.5, 0.25, 0.125)    # a flat colour patch
+    img[:, 300:302] *= 0.02                        # a dark hairline
+    img[200:204, 100:104] = 40.0                   # a specular
+    img[260:, :] = np.float32(0.0)                 # black border: S < 1e-12 in the 2-D LUT
+    p = oracle_inputs(neg, prt, scale)
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    out, u8 = ctx.render(dev(img), params, want_f32=True, want_u8=True)
+    e = assert_close(out.cpu().numpy(), ref, 1e-5, 1e-3, "photograph-like frame")
+    print(f"photograph-like frame scale {scale}: max err {e:.2e}")
+    diff = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4
