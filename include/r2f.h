@@ -276,6 +276,17 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
  * cls = pass (0..2) for launches on complex128 scratch (the halation), pass + 3 for launches on complex64 scratch (the MTF). */
 int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes);
 
+/* Measurement aid for bench.py's `roofline.copy_ceiling` ("state the measured hipMemcpyDtoD / stream-triad
+ * ceiling beside it"): a float4 streaming copy of `bytes` bytes from src to dst on the device -- 2 x bytes of HBM traffic and no
+ * arithmetic.  Nothing upstream corresponds to it; bytes must be a multiple of 16 and both buffers 16-byte aligned. */
+int r2f_stream_copy(r2f_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream);
+
+/* Change counter of everything a captured HIP graph of this context's launches freezes: bumped by every table / stencil /
+ * matrix upload, every option change and every re-allocation of a context-owned buffer (LUTs, stencil forms, FFT scratch and
+ * spectra).  The reference re-binds its resources per dispatch (gpu_processor.py:1756-1877) and has nothing to invalidate; a
+ * caller that replays captured launches must re-capture when this value moves. */
+uint64_t r2f_generation(const r2f_ctx* ctx);
+
 /* Tuning knob for A/B runs: stencil tile variant (0 = auto). */
 int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
 

@@ -50,8 +50,11 @@ def build(force: bool = False, verbose: bool = False, defines: list[str] | None 
     if not force and not defines and not out and not needs_build():
         return LIB_PATH
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "_obj" + ("" if not out else "_" + os.path.basename(out)))
-    os.makedirs(objdir, exist_ok=True)
+    # objects live in a scratch directory outside the tree (development variants used to leave ~80 MB of them under csrc/,
+    # which then rode along with every snapshot pushed to the GPU box)
+    import tempfile
+
+    objdir = tempfile.mkdtemp(prefix="r2f_obj_")
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     with ThreadPoolExecutor(len(SOURCES)) as pool:
         results = list(pool.map(lambda so: _compile_one(hipcc, so[0], so[1], list(defines or [])), zip(SOURCES, objs)))
@@ -67,6 +70,7 @@ def build(force: bool = False, verbose: bool = False, defines: list[str] | None 
     if res.returncode != 0:
         raise RuntimeError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     os.replace(target + ".tmp", target)
+    shutil.rmtree(objdir, ignore_errors=True)
     return target
 
 

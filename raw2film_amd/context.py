@@ -85,6 +85,11 @@ class HipContext:
             raise ValueError("planes: need a contiguous float32 CUDA tensor of shape (3, rows, W)")
         return _lib.Planes(t.data_ptr(), int(t.shape[1]) * int(t.shape[2]), int(gy0), int(t.shape[1]))
 
+    def generation(self) -> int:
+        """Change counter of the context's tables, options and internal buffers (r2f_generation): a captured HIP graph of this
+        context's launches is stale once it moves."""
+        return int(self._lib.r2f_generation(self._h))
+
     def set_option(self, name: str, value: int):
         self._check(self._lib.r2f_set_option(self._h, name.encode(), int(value)))
 
@@ -449,6 +454,13 @@ class HipContext:
             d["window"] = ((word >> 1) // 4096, (word >> 1) % 4096) if word >> 1 else None
             stats.append(d)
         return stats
+
+    def stream_copy(self, src, dst):
+        """dst <- src with a float4 streaming kernel (bench.py's copy ceiling: 2 x the bytes of HBM traffic, no arithmetic)."""
+        nbytes = src.numel() * src.element_size()
+        if dst.numel() * dst.element_size() != nbytes or not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("stream_copy needs two contiguous CUDA tensors of the same size in bytes")
+        self._check(self._lib.r2f_stream_copy(self._h, src.data_ptr(), dst.data_ptr(), nbytes, self._stream()))
 
     def kernel_timing(self, cls: int):
         """(total ms, launches, algorithmic bytes) of FFT pass `cls` since the last call; needs set_option("kernel_timing", 1)."""

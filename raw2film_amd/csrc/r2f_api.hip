@@ -46,6 +46,10 @@ struct StencilSet {
 struct r2f_ctx {
     int device = 0;
     std::string err;
+    // Bumped whenever something a captured HIP graph may have frozen changes: a table or stencil upload, a context buffer that
+    // was re-allocated (its old address is dangling), the matrix, an option.  r2f_generation() reports it; a caller that replays
+    // captured launches (raw2film_amd/sharding.py) re-captures when it moves.
+    uint64_t generation = 0;
     bool has_matrix = false;
     Mat3 mat;
     DeviceBuf lut2d_buf, lut3d_buf, curve_buf, grain_lut_buf;
@@ -167,6 +171,7 @@ int upload(r2f_ctx* ctx, DeviceBuf& buf, const void* host, size_t bytes) {
         buf.bytes = bytes;
     }
     R2F_HIP(ctx, hipMemcpy(buf.p, host, bytes, hipMemcpyHostToDevice));
+    ++ctx->generation;
     return R2F_OK;
 }
 
@@ -500,6 +505,7 @@ int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
     buf.release();
     R2F_HIP(ctx, hipMalloc(&buf.p, bytes));
     buf.bytes = bytes;
+    ++ctx->generation;
     return R2F_OK;
 }
 
@@ -944,8 +950,11 @@ void r2f_destroy(r2f_ctx* ctx) {
 
 const char* r2f_last_error(const r2f_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+uint64_t r2f_generation(const r2f_ctx* ctx) { return ctx ? ctx->generation : 0; }
+
 int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return R2F_EINVAL;
+    ++ctx->generation;  // by-value launch arguments and the choice of kernels depend on the options
     if (!strcmp(name, "stencil_variant")) {
         if (value < -1 || value >= kNumStencilVariants) return fail(ctx, R2F_EINVAL, "stencil_variant out of range");
         ctx->opt_variant = value;
@@ -1054,6 +1063,7 @@ int r2f_set_matrix3x3(r2f_ctx* ctx, const float* m) {
     if (!ctx) return R2F_EINVAL;
     ctx->has_matrix = m != nullptr;
     if (m) memcpy(ctx->mat.m, m, sizeof ctx->mat.m);
+    ++ctx->generation;
     return R2F_OK;
 }
 
@@ -1106,6 +1116,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.kw = kw;
     s.kc = kc;
     s.host.assign(k, k + (size_t)kh * kw * kc);
+    ++ctx->generation;
     s.built_q = 0;
     for (int c = 0; c < 3; ++c) ctx->fft_kf_valid[which][c] = false;
     if (which == R2F_KERNEL_GRAIN) ctx->grain_fixed_valid = false;
@@ -1686,6 +1697,15 @@ int r2f_decode_u16(r2f_ctx* ctx, const uint16_t* src_hwc, int H, int W, int chan
     if (!src_hwc || !dst_f32_hwc3 || H <= 0 || W <= 0 || (channels != 3 && channels != 4) || !(divisor > 0.f))
         return fail(ctx, R2F_EINVAL, "decode_u16: a non-empty 3- or 4-channel frame and a positive divisor are required");
     R2F_HIP(ctx, launch_decode_u16(src_hwc, (long long)H * W, channels, divisor, factor, dst_f32_hwc3, static_cast<hipStream_t>(stream)));
+    return R2F_OK;
+}
+
+int r2f_stream_copy(r2f_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (!src || !dst || bytes % 16 != 0 || !aligned16(src) || !aligned16(dst))
+        return fail(ctx, R2F_EINVAL, "stream_copy: 16-byte aligned buffers and a multiple of 16 bytes are required");
+    R2F_HIP(ctx, launch_stream_copy(src, dst, (long long)bytes, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
 

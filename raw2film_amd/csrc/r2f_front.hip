@@ -51,12 +51,24 @@ __device__ __forceinline__ uint32_t u8_of(float v) {  // cpu_processor.py:407: (
     return (uint32_t)__builtin_amdgcn_fmed3f(v * 255.0f, 0.0f, 255.0f);
 }
 
-// S0, apply_matrix of r2f_device.h on (x, y) pairs: ((m0 r + m1 g) + m2 b) per row
-__device__ __forceinline__ V3 matrix3(const Mat3& M, float r, float g, float b) {
+// S0, apply_matrix of r2f_device.h on (x, y) pairs: ((m0 r + m1 g) + m2 b) per row.  The matrix travels as three column pairs
+// + its last row, built once per kernel from the kernel arguments (indexing Mat3::m pair by pair made hipcc bounce the first
+// four elements through a 24-byte stack slot in the EXPOSURE variants).
+struct Mat3Pairs {
+    float2v c0, c1, c2;  // (m0, m3), (m1, m4), (m2, m5)
+    float r0, r1, r2;    // m6, m7, m8
+};
+__device__ __forceinline__ Mat3Pairs pairs_of(const Mat3& M) {
+    // (readfirstlane: the elements become opaque scalars, so the pairs are assembled with register moves)
+    float m[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(M.m[i])));
+    return Mat3Pairs{(float2v){m[0], m[3]}, (float2v){m[1], m[4]}, (float2v){m[2], m[5]}, M.m[6], M.m[7], M.m[8]};
+}
+__device__ __forceinline__ V3 matrix3(const Mat3Pairs& M, float r, float g, float b) {
     V3 o;
-    o.xy = __builtin_elementwise_fma((float2v){M.m[2], M.m[5]}, splat(b),
-                                     __builtin_elementwise_fma((float2v){M.m[1], M.m[4]}, splat(g), (float2v){M.m[0], M.m[3]} * splat(r)));
-    o.z = fmaf(M.m[8], b, fmaf(M.m[7], g, M.m[6] * r));
+    o.xy = __builtin_elementwise_fma(M.c2, splat(b), __builtin_elementwise_fma(M.c1, splat(g), M.c0 * splat(r)));
+    o.z = fmaf(M.r2, b, fmaf(M.r1, g, M.r0 * r));
     return o;
 }
 
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
     const float* in = static_cast<const float*>(a.in);
     const float s3 = a.lut3d_scale * (float)(a.lut3d.n - 1);
     const long long plane = (long long)a.in_rows * W;
+    const Mat3Pairs mat = pairs_of(a.mat);
     for (int gy = a.y0 + blockIdx.y * BY + threadIdx.y; gy < a.y1; gy += gridDim.y * BY) {
         const long long irow = gy - a.in_gy0;
         float r[4], g[4], b[4];
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            V3 p = a.use_matrix ? matrix3(a.mat, r[q], g[q], b[q]) : V3{(float2v){r[q], g[q]}, b[q]};
+            V3 p = a.use_matrix ? matrix3(mat, r[q], g[q], b[q]) : V3{(float2v){r[q], g[q]}, b[q]};
             p = lut2d(lut_lds, a.lut2d.n, p);
             if (UPTO == R2F_UPTO_EXPOSURE) {
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;

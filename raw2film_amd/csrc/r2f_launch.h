@@ -242,6 +242,7 @@ hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t
 hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s);
 // r2f_post.hip
 hipError_t launch_resize_area_u8(const uint8_t* src, int H, int W, uint8_t* dst, int out_h, int out_w, hipStream_t s);
+hipError_t launch_stream_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 hipError_t launch_decode_u16(const uint16_t* src, long long n, int ch, float divisor, float factor, float* dst, hipStream_t s);
 hipError_t launch_lanczos4_f32(const void* in, int in_layout, int H, int W, const DevPlanes& dst, int out_h, int out_w, const int* xofs,
                                const float* xcoef, const int* yofs, const float* ycoef, hipStream_t s);

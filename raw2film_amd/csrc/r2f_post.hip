@@ -313,7 +313,25 @@ __global__ __launch_bounds__(256) void decode_u16_kernel(const DecodeU16Args a) 
         for (int c = 0; c < 3; ++c) a.dst[p * 3 + c] = fminf((float)a.src[p * a.ch + c] / a.divisor * a.factor, 65504.0f);
 }
 
+// Measurement aid (bench.py's `copy_ceiling`): a float4 streaming copy, 2 x `bytes` of HBM traffic -- what this chip moves when a
+// kernel does nothing but load and store coalesced 16-byte lanes (MI355X_MICROARCH.md quotes 6.29 TB/s for this shape).
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
+
+hipError_t launch_stream_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
+    const long long n = bytes / 16;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, s, static_cast<const float4*>(src), static_cast<float4*>(dst), n);
+    return hipGetLastError();
+}
 
 hipError_t launch_decode_u16(const uint16_t* src, long long n, int ch, float divisor, float factor, float* dst, hipStream_t s) {
     DecodeU16Args a{src, dst, n, ch, divisor, factor,

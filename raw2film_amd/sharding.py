@@ -182,7 +182,8 @@ class RowShardedRenderer:
         self.graph = bool(graph and not burn and not self.side_grain and getattr(backend, "device", None) is not None
                           and torch.cuda.is_available() and (halation or mtf or grain)
                           and (world == 1 or self.single_exchange or not mtf))  # no exchange downstream of the front
-        self._graphs = {}   # key -> [calls seen, CUDAGraph or None]
+        self._graphs = {}   # key -> [calls seen, CUDAGraph or None], most recently used last
+        self._graphs_state = None  # _graph_state() the graphs were captured from
         self._identity_done = 0  # channel mask front_split finished (world == 1 only)
 
     # ------------------------------------------------------------------ neighbour exchange
@@ -259,10 +260,23 @@ class RowShardedRenderer:
         whole = p.world == 1  # no exchange: the front kernel is captured too (then the input buffer is part of the key)
         key = (image_rows.data_ptr() if whole else 0, tuple(image_rows.shape),
                out_f32.data_ptr() if out_f32 is not None else 0, out_u8.data_ptr() if out_u8 is not None else 0)
-        slot = self._graphs.setdefault(key, [0, None])
+        # A capture freezes every by-value launch argument (seed, flags, curve constants, tap weights) and every device pointer
+        # into the context's tables and scratch.  `state` is what they were captured from: the context's change counter (table /
+        # stencil / option uploads and re-allocations of its internal buffers) and the parameter block.  When either moves, every
+        # graph of this renderer is dropped and the frame at hand runs eagerly, like a first frame.
+        state = self._graph_state()
+        if state != self._graphs_state:
+            self._graphs.clear()
+            self._graphs_state = state
+        slot = self._graphs.pop(key, None) or [0, None]
+        self._graphs[key] = slot  # most recently used last
+        while len(self._graphs) > 8:  # callers that hand in fresh buffers every frame: neither graphs nor counters pile up
+            del self._graphs[next(iter(self._graphs))]
         slot[0] += 1
         if slot[0] == 1:  # first frame with these buffers: eager (tables, scratch and spectra get built here)
-            return self._render_eager(image_rows, out_f32, out_u8)
+            res = self._render_eager(image_rows, out_f32, out_u8)
+            self._graphs_state = self._graph_state()  # what that frame built lazily is the state the next one is captured from
+            return res
         if not whole:
             self._front_and_exchange(image_rows)
         if slot[1] is None:
@@ -280,12 +294,32 @@ class RowShardedRenderer:
                 if whole:
                     self._front_and_exchange(image_rows)
                 return self._after_exchange(out_f32, out_u8, None)
+            if self._graph_state() != state:
+                # the capture itself changed the context (a table built lazily on this frame: its upload synchronises and does
+                # not belong in a graph) -- keep this frame's eager result semantics simple: run it again eagerly, capture later
+                self._graphs.clear()
+                self._graphs_state = self._graph_state()
+                torch.cuda.synchronize()
+                if whole:
+                    self._front_and_exchange(image_rows)
+                return self._after_exchange(out_f32, out_u8, None)
             slot[1] = g
-            if len(self._graphs) > 8:  # callers that hand in fresh buffers every frame: do not hoard graphs
-                for k in list(self._graphs)[:-8]:
-                    del self._graphs[k]
         slot[1].replay()
         return out_f32, out_u8
+
+    def _graph_state(self):
+        """(context change counter, parameter block) of the backend -- what a captured graph of this renderer depends on besides
+        its buffers; None for backends without a context."""
+        be = self.backend
+        ctx, params = getattr(be, "ctx", None), getattr(be, "params", None)
+        if ctx is None or not hasattr(ctx, "generation"):
+            return None
+        return (ctx.generation(), bytes(params) if params is not None else b"")
+
+    def reset_graphs(self):
+        """Drop every captured graph (they are re-captured on the frames that follow)."""
+        self._graphs.clear()
+        self._graphs_state = None
 
     def _render_eager(self, image_rows, out_f32=None, out_u8=None):
         p, be = self.plan, self.backend
