@@ -613,12 +613,15 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
 // the GLOBAL frame, so every row shard of a frame (and every call on it) uses the same shape and the kernel spectra are
 // built once.  stencil_fft_window / stencil_fft_window_rows force an axis (ignored for a box over 200 taps on that axis,
 // which needs the 512-point window).
-void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int* ny, int* nx) {
+bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int* ny, int* nx) {
     double best = -1.0;
+    // a box wider than 200 columns needs 512 columns at least, whatever stencil_fft_window_max says (with the accepted
+    // value 256 every candidate used to be rejected and the caller's 256 x 256 default went on to a division by zero)
+    const int window_max = bw > 200 ? std::max(ctx->opt_fft_window_max, 512) : ctx->opt_fft_window_max;
     for (int y = 256; y <= 512; y *= 2) {
         if (bh > 200 ? y != 512 : (ctx->opt_fft_window_rows && y != ctx->opt_fft_window_rows)) continue;
         for (int x = 256; x <= 1024; x *= 2) {
-            if (x > ctx->opt_fft_window_max && x != ctx->opt_fft_window) continue;
+            if (x > window_max && x != ctx->opt_fft_window) continue;
             if (bw > 200 ? (x < 512 || (ctx->opt_fft_window >= 512 && x != ctx->opt_fft_window)) : (ctx->opt_fft_window && x != ctx->opt_fft_window)) continue;
             const int vy = y - bh + 1, vx = (x - bw + 1) & ~3;
             const double n = (double)y * x, part = n * vy / y;
@@ -628,9 +631,11 @@ void fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int*
             const double e = s32 ? 4.0 : 8.0;  // scratch bytes per window element (half a complex64 / complex128)
             const double bytes = 4.0 * n + e * n + p2 * (e * n + e * part) + e * part + 4.0 * vy * vx;
             const double cost = (double)((W + vx - 1) / vx) * ((H + vy - 1) / vy) * bytes;
+            if (vy < 1 || vx < 4) continue;  // the window has to keep outputs
             if (best < 0.0 || cost < best) best = cost, *ny = y, *nx = x;
         }
     }
+    return best >= 0.0;
 }
 
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
@@ -642,7 +647,9 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     tap_box(set, chans[0], b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
     int ny = 256, nx = 256;
-    fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, &ny, &nx);
+    if (!fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, &ny, &nx))
+        return fail(ctx, R2F_EINVAL, "stencil %d: no FFT window shape fits a %d x %d tap box under the current stencil_fft_window* options",
+                    which, bh, bw);
     const size_t img = (size_t)ny * nx;
     if (!ctx->fft_tw.p) {
         // W_256^k, k < 256, then W_512^k, k < 256, then W_1024^k, k < 64

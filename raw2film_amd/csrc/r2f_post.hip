@@ -314,22 +314,21 @@ __global__ __launch_bounds__(256) void decode_u16_kernel(const DecodeU16Args a) 
 }
 
 // Measurement aid (bench.py's `copy_ceiling`): a float4 streaming copy, 2 x `bytes` of HBM traffic -- what this chip moves when a
-// kernel does nothing but load and store coalesced 16-byte lanes (MI355X_MICROARCH.md quotes 6.29 TB/s for this shape).
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n) {
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long stride = (long long)gridDim.x * 256;
-    for (; i + 3 * stride < n; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+// kernel does nothing but load and store coalesced 16-byte lanes.  One float4 per lane, non-temporal both ways, one workgroup per
+// 4 KB: the fastest of the shapes in tools/ubench/copy_rate.hip on MI355X (6.57 TB/s; plain loads / stores 6.23, four float4 per
+// lane 5.84, a persistent grid-stride loop 4.6-4.8, hipMemcpyDtoD 5.10).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f4v* __restrict__ src, f4v* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 }  // namespace
 
 hipError_t launch_stream_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
     const long long n = bytes / 16;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, s, static_cast<const float4*>(src), static_cast<float4*>(dst), n);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const f4v*>(src),
+                       static_cast<f4v*>(dst), n);
     return hipGetLastError();
 }
 

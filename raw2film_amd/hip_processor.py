@@ -226,28 +226,28 @@ class HipProcessor:
         # what CpuProcessor.load_image returns as `orig_resolution` (cpu_processor.py:122) and process() hands to the final
         # resolution_scaling (cpu_processor.py:411-412)
         final_resolution = (int(resolution[0]), int(resolution[1])) if resolution is not None else None
+        scale_factor = 1.0
         if resolution is not None:
             resolution = (int(resolution[0]), int(resolution[1]))
             scale = max(resolution) / max(frame_width, frame_height)
             if max_scale is not None and scale > max_scale:
+                scale_factor = max_scale / scale
                 upscale_to = resolution
-                resolution = tuple(round(x * (max_scale / scale)) for x in resolution)
+                resolution = tuple(round(x * scale_factor) for x in resolution)
             # utils.resolution_scaling (utils.py:226-244), applied on the device in phase 2
             factor = min(resolution[0] / h, resolution[1] / w)
             if factor != 1:
                 # cv.resize(dsize=(round(w f), round(h f))): INTER_AREA down, INTER_LANCZOS4 up (a preview larger than the frame)
                 resize_to = (round(h * factor), round(w * factor))
                 h, w = resize_to
-        out_h, out_w = h, w
-        if upscale_to is not None:  # the uint8 result goes back up with LANCZOS4, same rule (fit inside the target)
-            f = min(upscale_to[0] / h, upscale_to[1] / w)
-            if f > 1:
-                out_h, out_w = round(h * f), round(w * f)
-            else:
-                upscale_to = None
+        # gpu_processor.py:764: the size the frame has once it is back from the max_scale pipeline -- the UN-shrunk output size,
+        # which is also what the canvas is laid out for (:767-771), not the pipeline's
+        out_h, out_w = (round(x / scale_factor) for x in (h, w))
+        if upscale_to is not None and min(upscale_to[0] / h, upscale_to[1] / w) <= 1:
+            upscale_to = None  # (the uint8 result goes back up with LANCZOS4 only when that enlarges it)
         canvas_res = None
         if canvas_mode != "No":  # gpu_processor.py:767-771
-            res, _, _ = geometry.canvas_layout((h, w), canvas_mode, canvas_scale, canvas_ratio)
+            res, _, _ = geometry.canvas_layout((out_h, out_w), canvas_mode, canvas_scale, canvas_ratio)
             canvas_res = (res[1], res[0])
         alpha = getattr(self, "payload_alpha", True) and not internal
         if u16_factor is not None:
@@ -342,16 +342,20 @@ class HipProcessor:
                            zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True, cache=True, chroma_nr=0,
                            max_scale=400.0, canvas_mode="No", canvas_scale=1.0, canvas_ratio=1.0, exposure=None, metadata=None):
         """GpuProcessor.load_image_texture (gpu_processor.py:655-719): prepare and upload the frame unless the load parameters
-        are those of the frame that is already on the device.  A path compares by value like upstream's `src`; an array by
-        identity (the caller hands in the same object again; one that was modified in place needs `cache=False`)."""
+        are those of the frame that is already on the device.  A path compares by value like upstream's `src`.  An array
+        compares by identity AND by a fingerprint of its content (shape, dtype, address, a checksum of up to 32 evenly spaced
+        rows), so a decode buffer that was refilled or edited in place is uploaded again; the processor holds the array by weak
+        reference only (upstream's cache never sees arrays: this is this backend's own rule, kept conservative)."""
         new_param_dict = {
-            "src": src if isinstance(src, str) else None, "cam": cam, "lens": lens, "lens_correction": lens_correction,
+            "src": src if isinstance(src, str) else self._array_fingerprint(src), "cam": cam, "lens": lens,
+            "lens_correction": lens_correction,
             "frame_width": frame_width, "frame_height": frame_height, "rotation": rotation, "zoom": zoom,
             "rotate_times": rotate_times, "flip": flip, "resolution": resolution, "half_size": half_size, "chroma_nr": chroma_nr,
             "max_scale": max_scale, "canvas_mode": canvas_mode, "canvas_scale": canvas_scale, "canvas_ratio": canvas_ratio,
             "exposure": exposure, "metadata": metadata,
         }
-        same_src = isinstance(src, str) or src is getattr(self, "_texture_src", None)
+        held = getattr(self, "_texture_src", None)
+        same_src = isinstance(src, str) or (held is not None and held() is src)
         if cache and same_src and getattr(self, "_texture", None) is not None and new_param_dict == getattr(self, "image_param_dict", None):
             return
         cpu_payload = self.extract_image_data_cpu(
@@ -361,7 +365,28 @@ class HipProcessor:
         )
         self.prepare_gpu_textures(cpu_payload)
         self.image_param_dict = new_param_dict
-        self._texture_src = None if isinstance(src, str) else src
+        self._texture_src = None
+        if not isinstance(src, str):
+            import weakref
+
+            try:
+                self._texture_src = weakref.ref(src)
+            except TypeError:  # an object that cannot be weakly referenced is simply never taken for "the same frame"
+                self._texture_src = None
+
+    @staticmethod
+    def _array_fingerprint(src):
+        """(shape, dtype, address, strides, crc32 of up to 32 evenly spaced rows) of a decoded frame handed in as an array."""
+        if not isinstance(src, np.ndarray):
+            return None
+        import zlib
+
+        rows = src.shape[0] if src.ndim else 0
+        step = max(1, rows // 32)
+        crc = 0
+        for r in range(0, rows, step):
+            crc = zlib.crc32(np.ascontiguousarray(src[r]).view(np.uint8).reshape(-1), crc)
+        return (src.shape, src.dtype.str, src.__array_interface__["data"][0], src.strides, crc)
 
     def prepare_gpu_textures(self, cpu_payload):
         """PHASE 2's stateful half (gpu_processor.py:785-790): upload the payload's frame and run the device pre-path on it

@@ -464,6 +464,13 @@ class BatchSharder:
         th = threading.Thread(target=producer, daemon=True)
         th.start()
         in_flight = None  # (index, task, handle) of the frame submitted but not yet collected
+
+        def finish(frame):
+            """Collect a submitted frame (download + export), then report it: progress counts FINISHED frames."""
+            results[frame[0]] = collect(frame[1], frame[2])
+            if progress is not None:
+                progress(frame[0], len(mine))
+
         try:
             while not self._cancel.is_set():
                 try:
@@ -479,16 +486,25 @@ class BatchSharder:
                     continue
                 if collect is None:
                     results[idx] = execute(task, payload)
+                    if progress is not None:
+                        progress(idx, len(mine))
                 else:
                     handle = execute(task, payload)
-                    if in_flight is not None:
-                        results[in_flight[0]] = collect(in_flight[1], in_flight[2])
-                    in_flight = (idx, task, handle)
-                if progress is not None:
-                    progress(idx, len(mine))
+                    previous, in_flight = in_flight, (idx, task, handle)
+                    if previous is not None:
+                        finish(previous)
             if in_flight is not None:
-                results[in_flight[0]] = collect(in_flight[1], in_flight[2])
-                in_flight = None
+                previous, in_flight = in_flight, None
+                finish(previous)
+        except BaseException:
+            # execute / collect raised with a frame still in flight: it did render -- try to keep its result, else list it as
+            # skipped, then let the error through
+            if collect is not None and in_flight is not None:
+                try:
+                    finish(in_flight)
+                except Exception:  # noqa: BLE001
+                    skipped.append(in_flight[0])
+            raise
         finally:
             # whatever ended the loop (cancel, the sentinel, an exception out of execute): stop the producer and drop what
             # it still holds, so it neither decodes the rest of the batch nor sits on a ~400 MB payload

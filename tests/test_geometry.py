@@ -114,3 +114,30 @@ def test_add_canvas_matches_the_reference_function():
         want = g[f"out_{i}"]
         assert got.shape == want.shape and got.dtype == want.dtype, (i, modes[int(mi)])
         np.testing.assert_array_equal(got, want)
+
+
+def test_payload_geometry_follows_the_reference_phase_one(golden_dir):
+    """output / canvas / pipeline resolution and the payload's shape as the reference's own extract_image_data_cpu derives them
+    (tools/make_golden_payload.py, gpu_processor.py:715-783): 3 344 cases, among them frames finer than `max_scale` WITH a
+    canvas mode -- the canvas is laid out for the un-shrunk output size, not for the pipeline's (:764-771)."""
+    from raw2film_amd.hip_processor import HipProcessor
+
+    g = np.load(os.path.join(golden_dir, "payload_geometry.npz"))
+    modes = [str(m) for m in g["modes"]]
+    proc = HipProcessor.__new__(HipProcessor)  # phase 1 touches no instance state (and needs no GPU)
+    shrunk_with_canvas = 0
+    frames = {}
+    for case, want in zip(g["cases"], g["results"]):
+        H, W, fw, fh, r0, r1, ms, mi, cs, cr = case
+        H, W = int(H), int(W)
+        frame = frames.setdefault((H, W), np.zeros((H, W, 3), dtype=np.float32))
+        p = proc.extract_image_data_cpu(frame, frame_width=fw, frame_height=fh, resolution=None if r0 < 0 else (int(r0), int(r1)),
+                                        max_scale=None if ms < 0 else ms, canvas_mode=modes[int(mi)], canvas_scale=cs, canvas_ratio=cr)
+        got = list(p["output_resolution"]) + list(p["canvas_resolution"] or (-1, -1)) + list(p["pipeline_resolution"])
+        assert got == list(want[:6]), (case, got, want)
+        # the payload frame itself is scaled on the device in phase 2: its shape there is the pipeline's
+        rows, cols = (p["resize_to"] or p["image_array"].shape[:2])
+        assert (rows, cols) == (want[6], want[7]) == (p["pipeline_resolution"][1], p["pipeline_resolution"][0])
+        assert p["image_array"].shape[2] == want[8] == 4
+        shrunk_with_canvas += int(p["canvas_resolution"] is not None and tuple(p["output_resolution"]) != tuple(p["pipeline_resolution"]))
+    assert shrunk_with_canvas > 200

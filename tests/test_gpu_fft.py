@@ -183,6 +183,20 @@ def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
             ctx.set_option(name, 384)
 
 
+def test_a_wide_tap_box_ignores_a_window_cap_it_cannot_live_with(ctx):
+    """`stencil_fft_window_max = 256` is an accepted value, but a tap box wider than 200 columns needs a 512-column
+    window; the cap then used to reject every candidate (a division by zero or tiny windows followed).  The cap is now ignored
+    for such a box, and the result is the oracle's."""
+    rng = np.random.default_rng(10)
+    k = rng.uniform(0.0, 1.0, (9, 231, 1)).astype(np.float32)
+    k /= k.sum()
+    img = rng.uniform(0.0, 2.0, (60, 700, 3)).astype(np.float32)
+    out = run(ctx, 0, img, k, 1, stencil_fft_window_max=256)
+    assert uses_fft(ctx, 0) == [1, 1, 1]
+    assert ctx.stencil_stats(0)[0]["window"][1] >= 512
+    assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-3, "231-column box under a 256-column cap")
+
+
 def test_kernel_change_rebuilds_the_spectrum(ctx):
     rng = np.random.default_rng(6)
     img = rng.uniform(0, 1, (90, 120, 3)).astype(np.float32)

@@ -177,6 +177,62 @@ def test_max_scale_round_trip_through_the_processor(proc):
     assert d.max() <= 3 and (d > 0).mean() <= 5e-3  # a 1-LSB truncation flip before the filter spreads over 8 x 8 taps
 
 
+@pytest.mark.parametrize("mode", ["Uniform white", "Fixed black"])
+def test_max_scale_below_the_frame_scale_with_a_canvas(proc, mode):
+    """a small-gauge frame rendered at max_scale AND framed by a canvas.  process(): CpuProcessor's order --
+    pipeline at max_scale, canvas pasted on the pipeline-size frame (cpu_processor.py:409), then resolution_scaling of the framed
+    frame back to the requested size (:411-412, LANCZOS4).  process_preloaded(dst_texture=...): the blit transform comes from
+    the payload's output / canvas / pipeline resolutions, which follow gpu_processor.py:764-771 (canvas laid out for the
+    UN-shrunk output size; pinned by tests/golden/payload_geometry.npz) -- compared with the oracle's blit of the same frame."""
+    from oracle import post
+    from raw2film_amd import geometry
+
+    neg, prt, _ = stocks()
+    img = _xyz(160, 240, seed=52)
+    canvas = dict(canvas_mode=mode, canvas_scale=1.15, canvas_ratio=1.25)
+    kw = dict(print_film=prt, halation=True, sharpness=True, grain=0, exp_kelvin=6000, color_masking=1.0,
+              frame_width=5.79, frame_height=3.86, max_scale=20.0, **canvas)
+    out = proc.process(img, neg, 6, 0.4, **kw)
+    pre = geometry.crop_to_frame(img, 5.79, 3.86, 1.0, 0, False)
+    h, w = pre.shape[:2]
+    f = 20.0 / (max(h, w) / 5.79)
+    res = [round(h * f), round(w * f)]
+    g = min(res[0] / h, res[1] / w)
+    small = np.stack([st.resize_area(np.ascontiguousarray(pre[..., c]), round(h * g), round(w * g)) for c in range(3)], axis=-1)
+    p = oracle_inputs(neg, prt, max(small.shape[:2]) / 5.79, halation=True, mtf=True, grain=0, matrix=False, halation_green_factor=0.4)
+    rendered = st.render(small, p)
+    framed = geometry.add_canvas(st.to_uint8(rendered), **canvas)  # (pinned against effects.add_canvas: tests/golden/add_canvas.npz)
+    ref = st.resolution_scaling_u8_up(framed, (h, w))
+    assert out.shape == ref.shape and framed.shape[0] > small.shape[0]
+    d = np.abs(out.astype(int) - ref.astype(int))
+    assert d.max() <= 3 and (d > 0).mean() <= 5e-3
+    # the GPU processor's destination branch
+    payload = proc.extract_image_data_cpu(img, frame_width=5.79, frame_height=3.86, max_scale=20.0, **canvas)
+    ow, oh = payload["output_resolution"]
+    assert (oh, ow) == (h, w) and payload["pipeline_resolution"] == (small.shape[1], small.shape[0])
+    want_canvas, color, _ = geometry.canvas_layout((h, w), mode, 1.15, 1.25)  # the un-shrunk output size
+    assert payload["canvas_resolution"] == (want_canvas[1], want_canvas[0])
+    dst = torch.zeros((300, 400, 4), dtype=torch.uint8, device="cuda")
+    settings = {k: v for k, v in kw.items() if k not in ("max_scale",)}
+    assert proc.process_preloaded(payload, neg, 6, 0.4, dst_texture=dst, **settings) is None
+    t = geometry.blit_transform((small.shape[1], small.shape[0]), (400, 300), pipeline_resolution=payload["pipeline_resolution"],
+                                output_resolution=payload["output_resolution"], canvas_resolution=payload["canvas_resolution"],
+                                canvas_color=color)
+    want = post.blit_rgba8(rendered, 300, 400, t)
+    got = dst.cpu().numpy()
+    np.testing.assert_array_equal(got[..., 3], want[..., 3])
+    dd = np.abs(got.astype(int) - want.astype(int))
+    assert dd.max() <= 1 and (dd > 0).mean() <= 2e-3
+    # the image occupies output / canvas of the canvas area on both axes (the bug this guards against: a canvas laid out for the
+    # pipeline size next to an output size in final pixels shrank the image inside its frame)
+    inside = (got[..., :3] != np.array(color, dtype=np.uint8)).any(axis=2) & (got[..., 3] == 255)
+    rows, cols = np.where(inside.any(axis=1))[0], np.where(inside.any(axis=0))[0]
+    area = got[..., 3] == 255
+    arows, acols = np.where(area.any(axis=1))[0], np.where(area.any(axis=0))[0]
+    assert abs((rows[-1] - rows[0] + 1) / (arows[-1] - arows[0] + 1) - h / want_canvas[0]) < 0.02
+    assert abs((cols[-1] - cols[0] + 1) / (acols[-1] - acols[0] + 1) - w / want_canvas[1]) < 0.02
+
+
 def test_uploads_happen_only_on_change(proc):
     neg, prt, _ = stocks()
     img = _xyz(48, 64, seed=45)
@@ -362,9 +418,22 @@ def test_the_frame_stays_on_the_device_between_renders_with_the_same_load_parame
     np.testing.assert_array_equal(d, c)
     img2 = img.copy()
     e1 = proc.process(img2, neg, 6, 0.4, **kw)
-    img2 *= 0.5  # modified in place: the caller says so with cache=False
-    e2 = proc.process(img2, neg, 6, 0.4, cache=False, **kw)
+    img2 *= 0.5  # modified in place: the content fingerprint notices, no cache=False needed
+    e2 = proc.process(img2, neg, 6, 0.4, **kw)
     assert len(calls) == 5 and not np.array_equal(e1, e2)
+    e3 = proc.process(img2, neg, 6, 0.4, cache=False, **kw)  # cache=False always loads
+    assert len(calls) == 6
+    np.testing.assert_array_equal(e3, e2)
+    # the processor does not keep the host frame alive
+    import gc
+    import weakref
+
+    img3 = img.copy()
+    ref3 = weakref.ref(img3)
+    proc.process(img3, neg, 6, 0.4, **kw)
+    del img3
+    gc.collect()
+    assert ref3() is None
     # results never depend on what was cached: a fresh processor renders the same frames
     fresh = HipProcessor(device=0)
     np.testing.assert_array_equal(fresh.process(img, neg, 6, 0.4, exp_comp=1.0, **kw), b)

@@ -300,3 +300,32 @@ def test_batch_sharder_pipelined_collect_keeps_one_frame_in_flight():
     results, skipped = bs.run([0, 1, 2, 3], prepare, execute, collect=collect)
     assert results == {0: 0, 1: 10, 3: 30} and skipped == [2]
     assert log == [("submit", 0), ("submit", 1), ("collect", 0), ("submit", 3), ("collect", 1), ("collect", 3)]
+
+
+def test_batch_sharder_progress_counts_finished_frames_and_a_failure_keeps_the_frame_in_flight():
+    """in collect mode `progress` used to fire when a frame was SUBMITTED (a GUI bar ran one frame ahead); it now
+    fires when the frame has been collected.  And when execute() raises, the frame already in flight is still collected (its
+    export runs) before the error leaves run()."""
+    log = []
+    bs = sharding.BatchSharder(0, 1)
+    results, skipped = bs.run([0, 1, 2], lambda t: t, lambda t, p: (log.append(("submit", t)), t)[1],
+                              progress=lambda i, n: log.append(("done", i, n)), collect=lambda t, h: (log.append(("collect", t)), t)[1])
+    assert results == {0: 0, 1: 1, 2: 2} and skipped == []
+    assert log == [("submit", 0), ("submit", 1), ("collect", 0), ("done", 0, 3), ("submit", 2), ("collect", 1), ("done", 1, 3),
+                   ("collect", 2), ("done", 2, 3)]
+    # serial form: after each execute
+    log.clear()
+    bs.run([0, 1], lambda t: t, lambda t, p: (log.append(("exec", t)), t)[1], progress=lambda i, n: log.append(("done", i, n)))
+    assert log == [("exec", 0), ("done", 0, 2), ("exec", 1), ("done", 1, 2)]
+
+    log.clear()
+
+    def execute(t, payload):
+        if t == 2:
+            raise RuntimeError("submit failed")
+        log.append(("submit", t))
+        return t
+
+    with pytest.raises(RuntimeError, match="submit failed"):
+        bs.run([0, 1, 2, 3], lambda t: t, execute, collect=lambda t, h: log.append(("collect", t)))
+    assert log == [("submit", 0), ("submit", 1), ("collect", 0), ("collect", 1)]  # frame 1 was in flight when frame 2 failed
