@@ -393,7 +393,9 @@ class HipProcessor:
         (uint16 conversion, free rotation, chroma NR, preview scaling); the result is the frame the pipeline reads."""
         image = self._payload_tensor(cpu_payload).to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         image, layout = self._prepare_device_frame(image, cpu_payload)
-        self._texture = (image, layout, cpu_payload)
+        # (what is kept next to the device frame is the payload's geometry, not its host frame: the processor must not keep a
+        # 1.2 GB decode buffer alive)
+        self._texture = (image, layout, {k: v for k, v in cpu_payload.items() if k != "image_array"})
         self.image_param_dict = None  # (a payload from outside: no load parameters to compare the next process() with)
         self._texture_src = None
 
