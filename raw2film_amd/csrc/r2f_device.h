@@ -172,6 +172,10 @@ __device__ __forceinline__ void apply_matrix(const Mat3& M, float& r, float& g, 
 
 // S1: chromaticity-triangle 2-D LUT, lut_2d.wgsl:18-108.
 __device__ __forceinline__ void apply_lut2d(const DevLut2D& L, float& X, float& Y, float& Z) {
+// fract() of the ROUNDED coordinate, like the shader's (and the oracle's) float32 r: left to itself hipcc contracts r - floor(r)
+// into fma(X, inv_sum, -floor(r)), i.e. the fraction of the unrounded product -- up to an ulp of r (8e-6 of a texel at n = 128)
+// away, which a rough table turns into 3e-5 of the value (tests/test_gpu_hostile.py).  The blend below is explicit fmaf.
+#pragma clang fp contract(off)
     const float S = (X + Y) + Z;
     if (S < 1e-12f) {
         X = Y = Z = 0.f;
@@ -217,7 +221,10 @@ __device__ __forceinline__ void lut3d_axis(float x, float s, int n, int& lo, int
         i0 = n - 2;
         d = 1.0f;
     } else {
-        d = t - (float)i0;
+        // the fraction of the UNROUNDED product: numba runs utils.py:262-289 with a float32 pixel times a float64 scale, so r and
+        // dr are float64 there (oracle/stages.py pins that against the golden vectors); one fused multiply-add is that value
+        // rounded once.  (hipcc used to contract t - i0 into this by itself; now it is explicit.)
+        d = fmaf(x, s, -(float)i0);
     }
     int i1 = i0 + 1;
     // negative indices wrap like Python/numba indexing; clamp what would be out of bounds there
@@ -265,7 +272,7 @@ __device__ __forceinline__ void lut3d_axis_nonneg(float x, float s, int n, int& 
     const float t = x * s;
     const int i0 = (int)t;
     lo = min(i0, n - 2);
-    d = i0 >= n - 1 ? 1.0f : t - (float)i0;
+    d = i0 >= n - 1 ? 1.0f : fmaf(x, s, -(float)i0);  // fraction of the unrounded product, see lut3d_axis
 }
 
 __device__ __forceinline__ float4 lut3d_texel(const float4* tex, unsigned off) {

@@ -80,6 +80,7 @@ __device__ __forceinline__ V3 texel_lds(const float4* base, unsigned off) {
 
 // S1, apply_lut2d of r2f_device.h (lut_2d.wgsl:18-108); the LUT's texels are in LDS
 __device__ __forceinline__ V3 lut2d(const float4* tex, const int n, const V3 p) {
+#pragma clang fp contract(off)  // fract() of the rounded coordinate (see apply_lut2d); the blend is explicit fma
     const float S = (p.xy.x + p.xy.y) + p.z;
     const bool dark = S < 1e-12f;
     const float inv_sum = (float)(n - 1) / (dark ? 1.0f : S);
@@ -109,7 +110,7 @@ __device__ __forceinline__ void axis_nonneg(float x, float s, int n, int& lo, fl
     const float t = x * s;
     const int i0 = (int)t;
     lo = min(i0, n - 2);
-    d = i0 >= n - 1 ? 1.0f : t - (float)i0;
+    d = i0 >= n - 1 ? 1.0f : fmaf(x, s, -(float)i0);  // fraction of the unrounded product, see lut3d_axis
 }
 
 __device__ __forceinline__ V3 lut3d_tetra_nonneg(const float4* tex, const int n, const float s, const float r, const float g,

@@ -52,5 +52,5 @@ def rel_err(a, b, floor):
 
 def assert_close(a, b, tol=1e-5, floor=1e-3, what=""):
     e = rel_err(a, b, floor)
-    assert e <= tol, f"{what}: max rel err {e:.3e} > {tol:.1e} (floor {floor})"
+    assert e <= tol, f"max rel err {e:.3e} > {tol:.1e} (floor {floor}): {what}"
     return e

@@ -1,0 +1,231 @@
+"""Parity battery with hostile tables (Next 3): the four stages whose reference lives in spectral_film_lut (S1, S3 + S4,
+S6c) and S8, against the oracle with table contents no analytic stand-in stock produces -- random texels, other sizes than the
+defaults (2-D LUT n = 17 / 64 / 128, curves m = 256 / 4096 on NON-uniform axes, 3-D LUT n = 17 / 33 / 65), steps in the grain LUT,
+exact 0 / 1 plateaus and blacks below the contract's 1e-3 floor -- and one full render through a BundleStock that went through
+save_bundle / load_bundle.
+
+Two kinds of test:
+  * per stage, both sides fed IDENTICAL inputs, fully random tables (rough = 1): what is compared is the stage's own arithmetic;
+    the bound is the contract's plus, where the stage's input is itself a rounded intermediate, the local slope of the table times
+    a few ulp of that input (a table that jumps by 1 across a cell turns one ulp of its argument into 1e-5 of its value: that is
+    the table's conditioning, not an error of either implementation);
+  * the whole path with tables whose roughness the contract can bear (rough <= 0.25, bounded curve slopes), at the contract's own
+    numbers: |hip - oracle| <= 1e-5 max(|oracle|, 1e-3), uint8 <= 1 LSB on <= 1e-4 of the samples.
+Layouts: gpu_processor.py:307-409, 565-611; lut_1d.wgsl:43-51; grain.wgsl:78-89; utils.py:247-380."""
+
+import numpy as np
+import pytest
+
+from oracle import kernels as ok
+from oracle import stages as st
+
+import hostile
+from helpers import SEED, oracle_inputs, rel_err, stocks, synthetic_frame
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from test_gpu_parity import dev, from_planes, setup_ctx, to_planes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from raw2film_amd.context import HipContext
+
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def _frame(H, W, seed):
+    img = synthetic_frame(H, W, seed=seed)
+    img[0, :5] = 0.0  # S < 1e-12 -> 0 (lut_2d.wgsl:24)
+    img[1, :5] = 1e-9
+    img[2, :5] = 60000.0
+    return img
+
+
+@pytest.mark.parametrize("layout", ["hwc3", "chw"])
+@pytest.mark.parametrize("n", [17, 64, 128])
+def test_random_input_lut_of_any_size(ctx, n, layout):
+    """S1 with independent random texels (and one near-black texel), XYZ in: both sides index the table with the same float32
+    quotient, so what differs is the rounding of the blend.  n = 128 (256 KB of float4 texels) does not fit LDS: the generic
+    front kernel; n <= 64: the LDS kernel.  Weights and texels are non-negative, so the blend has no cancellation: a few ulp.
+    (With S0 in front, one ulp of X moves the chromaticity index by 8e-6 of a texel; next to the near-black texel that alone is
+    2e-4 of the value -- the table's conditioning, measured here before the matrix was taken out.)"""
+    rng = np.random.default_rng(100 + n)
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0, halation=False, mtf=False, grain=0, matrix=False)
+    p.lut_2d = hostile.lut2d(rng, n, 1.0)
+    H, W = 96, 132
+    img = _frame(H, W, n)
+    ref = st.apply_2d_lut(img, p.lut_2d)
+    params = setup_ctx(ctx, p)
+    E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_front(dev(img) if layout == "hwc3" else to_planes(img), params, 0, dst=E, layout=layout)
+    got = from_planes(E)
+    err = rel_err(got, ref, 1e-6)
+    assert err <= 2e-6, err
+    assert (got[0, :5] == 0).all()
+
+
+def _curve_slopes(lut):
+    xp = lut[0].astype(np.float64)
+    dx = np.diff(xp)
+    return [np.where(dx > 0, np.abs(np.diff(lut[1 + c].astype(np.float64))) / np.maximum(dx, 1e-300), 0.0) for c in range(3)]
+
+
+def _local_slope(lut, x):
+    """max |slope| of the curve's cell at x and of its two neighbours, per channel of x (..., 3)."""
+    xp = lut[0].astype(np.float64)
+    out = np.zeros(x.shape)
+    sl = _curve_slopes(lut)
+    for c in range(3):
+        i = np.clip(np.searchsorted(xp, x[..., c].astype(np.float64), side="right") - 1, 0, len(xp) - 2)
+        s = sl[c]
+        out[..., c] = np.maximum(np.maximum(s[np.maximum(i - 1, 0)], s[i]), s[np.minimum(i + 1, len(s) - 1)])
+    return out
+
+
+@pytest.mark.parametrize("m,uniform", [(256, False), (4096, False), (1024, True), (2, False), (37, False)])
+def test_density_curve_on_a_non_uniform_axis(ctx, m, uniform):
+    """S3 + S4 (np.interp semantics, lut_1d.wgsl:43-51 without the half-texel shift) on curves whose axis the device cannot
+    index arithmetically: the exact cell walk.  m = 4096 (196 KB of cells) also exceeds LDS.  The input of the curve is
+    log10 of an exposure both sides compute (flat 2-D LUT: exposure = X + Y + Z to an ulp); the device's v_log_f32-based log10
+    and NumPy's differ by an ulp or two of the logarithm, which the curve's local slope turns into density."""
+    rng = np.random.default_rng(200 + m)
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0, halation=False, mtf=False, grain=0, matrix=False)
+    p.lut_2d = np.ones((8, 8, 3), dtype=np.float32)
+    p.lut_1d = hostile.curve(rng, m, max_slope=6.0, uniform=uniform)
+    H, W = 128, 164
+    img = _frame(H, W, m)
+    expo = st.apply_2d_lut(img, p.lut_2d)
+    loge = st.log_clip(expo)
+    ref = st.multi_channel_interp(loge, p.lut_1d)
+    params = setup_ctx(ctx, p)
+    D = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_front(dev(img), params, 1, dst=D)
+    got = from_planes(D)
+    bound = 1e-5 * np.maximum(np.abs(ref), 1e-3) + _local_slope(p.lut_1d, loge) * 4.0 * np.spacing(np.abs(loge).astype(np.float32))
+    over = np.abs(got.astype(np.float64) - ref) > bound
+    assert not over.any(), (int(over.sum()), float(np.max(np.abs(got - ref) / bound)))
+    # clamped at both ends like np.interp
+    assert np.array_equal(got[0, :5], np.broadcast_to(p.lut_1d[1:, 0], (5, 3)))  # exposure 0 -> log clip -> below the axis
+
+
+@pytest.mark.parametrize("mode", ["tetrahedral", "trilinear"])
+@pytest.mark.parametrize("n", [2, 17, 33, 65, 40])
+def test_random_output_lut_with_plateaus(ctx, n, mode):
+    """S8 alone on given density planes, independent random texels with exact 0 / 1 entries: both sides index with the same
+    float32 product, so this is the interpolation arithmetic itself.  Densities include exact grid points, ties and the upper
+    edge (>= 4 -> last cell, d = 1: utils.py:270-289)."""
+    rng = np.random.default_rng(300 + n)
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 100.0, halation=False, mtf=False, grain=0)
+    p.lut_3d = hostile.lut3d(rng, n, 1.0)
+    p.lut3d_mode = mode
+    H, W = 96, 128
+    dens = rng.uniform(0.0, 4.4, (H, W, 3)).astype(np.float32)
+    grid = (np.arange(n) * (4.0 / (n - 1))).astype(np.float32)
+    dens[0, :n] = grid[:W, None][:n]
+    dens[1, :, 1] = dens[1, :, 0]  # ties dr == dg
+    dens[2, :, 2] = dens[2, :, 1]
+    dens[3] = 4.0
+    ref = st.apply_lut_tetrahedral(dens, p.lut_3d, 0.25) if mode == "tetrahedral" else st.apply_lut_trilinear(dens, p.lut_3d, 0.25)
+    params = setup_ctx(ctx, p)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    ctx.stage_tail(to_planes(dens), params, out_f32=out, out_u8=u8, y0=0, y1=H, H_global=H)
+    got = out.cpu().numpy()
+    # (trilinear, lut_3d.wgsl:27-40, is the optional GPU-twin mode, off the parity path: the device keeps the shader's float32
+    # coordinate, the oracle a float64 one -- an ulp of a coordinate of up to 64, i.e. 8e-6 of a cell, times random texel
+    # differences of up to 1)
+    assert np.max(np.abs(got - ref)) <= (4e-7 if mode == "tetrahedral" else 1e-5)
+    d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= (2e-4 if mode == "tetrahedral" else 2e-3)
+    assert (ref == 0).any() or n == 2 or mode == "trilinear"  # (exact-grid densities return the plateau texels themselves)
+
+
+@pytest.mark.parametrize("m", [256, 64, 1000])
+@pytest.mark.parametrize("mono", [False, True])
+def test_grain_lut_with_steps(ctx, m, mono):
+    """S6 with a piecewise-constant grain LUT (jumps across single cells, amplitudes up to 0.06: three times the stand-in
+    stocks'), planes -> planes: out = max(D + G * lut(D), 0).  Densities from 0.35 up at the contract's bound; the
+    field itself is good to 4e-6 (hardware transcendentals), i.e. 2.4e-7 of density at this amplitude, so the row of
+    exact-zero densities -- where the clip at 0 (cpu_processor.py:397) decides -- is held to that absolute figure instead."""
+    rng = np.random.default_rng(400 + m)
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 166.67, halation=False, mtf=False, grain=1 if mono else 2)
+    p.grain_lut = hostile.grain_lut(rng, m)
+    H, W = 100, 140
+    dens = rng.uniform(0.35, 4.0, (H, W, 3)).astype(np.float32)  # (0.35 - 5 sigma x 0.06 > 0: the contract rows stay off the clip)
+    dens[0] = np.linspace(0.35, 4, W, dtype=np.float32)[:, None]
+    dens[1] = 0.0
+    ref = np.maximum(st.apply_grain(dens, p.grain_lut, p.grain_kernel, p.seed, p.grain_mono), 0)
+    params = setup_ctx(ctx, p)
+    G = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_grain(to_planes(dens), G, params, y0=0, y1=H, H_global=H)
+    got = from_planes(G)
+    assert rel_err(np.delete(got, 1, axis=0), np.delete(ref, 1, axis=0), 1e-3) <= 1e-5
+    assert (got[1] >= 0).all() and (got[1] == 0).any() and np.max(np.abs(got[1] - ref[1])) <= 3e-7
+
+
+def _hostile_inputs(rng, neg, prt, scale, n2, m1, n3, **kw):
+    return hostile.roughen(rng, oracle_inputs(neg, prt, scale, **kw), n2, m1, n3)
+
+
+@pytest.mark.parametrize("n2,m1,n3", [(17, 256, 17), (64, 4096, 33), (128, 256, 65), (33, 1000, 24)])
+def test_whole_path_with_hostile_tables_at_the_contract(ctx, n2, m1, n3):
+    """S0..S8 with halation, MTF and grain on tables of moderate roughness, every size off the defaults, a print-like output LUT
+    that falls to exact 0: the contract as written, with samples below its 1e-3 floor (the stand-in stocks never get under 5e-3)."""
+    rng = np.random.default_rng(n2 * 1000 + n3)
+    neg, prt, _ = stocks()
+    scale = 229.33
+    p = _hostile_inputs(rng, neg, prt, scale, n2, m1, n3)
+    H, W = 200, 280
+    img = synthetic_frame(H, W, seed=n2)
+    img[40:90, 60:150] *= 0.02  # a shadow region: thin negative -> the output LUT's exact-1 plateau
+    img[110:170, 20:120] *= 1000.0  # ... and blown highlights: the black end, down to its exact zeros
+    ref = st.render(img, p)
+    params = setup_ctx(ctx, p)
+    out, u8 = ctx.render(dev(img), params, want_f32=True, want_u8=True)
+    got = out.cpu().numpy()
+    err = rel_err(got, ref, 1e-3)
+    below = int((ref < 1e-3).sum())
+    assert below > 100, below
+    assert (ref == 0).any() and (ref == 1).any()
+    assert err <= 1e-5, (err, below)
+    d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-4, (d.max(), (d > 0).mean())
+
+
+def test_full_render_through_a_round_tripped_bundle(tmp_path):
+    """filmstock.save_bundle -> load_bundle -> HipProcessor: the LUT-bundle route by which real spectral_film_lut exports reach this
+    backend (filmstock.py), with hostile arrays in the bundle; compared with the oracle fed the same arrays."""
+    from raw2film_amd import HipProcessor, filmstock
+
+    rng = np.random.default_rng(77)
+    neg, prt, _ = stocks()
+    H, W, fw = 160, 240, 1.2
+    scale = max(H, W) / fw
+    p = _hostile_inputs(rng, neg, prt, scale, 48, 777, 21, grain_size=6.0, grain_sigma=0.4, halation_green_factor=0.3)
+    path = str(tmp_path / "hostile_stock.npz")
+    filmstock.save_bundle(path, lut_2d=p.lut_2d, lut_1d=p.lut_1d, lut_3d=p.lut_3d, grain_lut=p.grain_lut,
+                          mtf_logf=np.stack([m[0] for m in neg.mtf]), mtf_vals=np.stack([m[1] for m in neg.mtf]),
+                          rms_density=neg.rms_density, d_ref=np.asarray(neg.d_ref), density_measure="status_m")
+    stock = filmstock.load_bundle(path, name="hostile bundle")
+    assert stock.mtf is not None and stock.rms_density is not None
+    for a, b in ((stock.get_input_lut(), p.lut_2d), (stock.get_density_curve(), p.lut_1d), (stock.get_grain_curve(scale), p.grain_lut),
+                 (filmstock.create_lut(stock, None), p.lut_3d)):
+        np.testing.assert_array_equal(a, b)
+    p.mtf_kernel = ok.mtf_kernel(stock.mtf, scale, 0.0, 1.0)
+    img = synthetic_frame(H, W, seed=9)
+    proc = HipProcessor(device=0)
+    try:
+        out = proc.process_array(img, stock, 6, 0.4, colorspace="linear-rec709", seed=SEED, return_float=True, frame_width=fw,
+                                 frame_height=fw * H / W, halation_green_factor=0.3)
+    finally:
+        proc.close()
+    ref = st.render(img, p)
+    assert rel_err(out, ref, 1e-3) <= 1e-5
