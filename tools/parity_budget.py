@@ -30,10 +30,17 @@ def stats(a, b, floor=FLOOR):
     return f"rel max {e.max():.2e} p99.99 {np.quantile(e, 0.9999):.2e} over-bar {float((e > TOL).mean()):.1e} | ulp max {ulp.max():.1f} rms {np.sqrt((ulp ** 2).mean()):.2f}"
 
 
-def run(ctx, H, W, scale, seed=21, **kw):
+def run(ctx, H, W, scale, seed=21, tables=None, **kw):
     neg, prt, _ = stocks()
     p = oracle_inputs(neg, prt, scale, **kw)
     img = synthetic_frame(H, W, seed=seed)
+    if tables:  # hostile table contents (tests/hostile.py): noisy 2-D LUT, non-uniform curve axis, stepped grain LUT, 3-D LUT 0..1
+        import hostile
+
+        hostile.roughen(np.random.default_rng(seed), p, *tables)
+        img[H // 5:H // 2, W // 5:W // 2] *= 0.02
+        img[H // 2:3 * H // 4, W // 10:W // 2] *= 1000.0
+        print(f"--- hostile tables: 2-D LUT {tables[0]}^2, curve {tables[1]} points (non-uniform axis), 3-D LUT {tables[2]}^3")
     ref = st.render(img, p, keep_stages=True)
     S = p.stages
     params = setup_ctx(ctx, p)
@@ -71,7 +78,8 @@ def run(ctx, H, W, scale, seed=21, **kw):
     print("output r2f_render            ", stats(o.cpu().numpy(), ref))
     d = np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int))
     print(f"uint8: max diff {d.max()}  mismatch rate {float((d > 0).mean()):.2e}  ({int((d > 0).sum())} of {d.size})")
-    print(f"oracle output range [{ref.min():.4g}, {ref.max():.4g}]")
+    print(f"oracle output range [{ref.min():.4g}, {ref.max():.4g}]; samples below the 1e-3 floor: {int((ref < 1e-3).sum())} of {ref.size}, "
+          f"exact 0: {int((ref == 0).sum())}, exact 1: {int((ref == 1).sum())}")
 
 
 if __name__ == "__main__":
@@ -80,6 +88,8 @@ if __name__ == "__main__":
     run(ctx, 160, 240, 166.67)
     run(ctx, 131, 203, 341.33)
     run(ctx, 256, 384, 229.33)
+    for tb in ((17, 256, 17), (64, 4096, 33), (128, 256, 65), (33, 1000, 24)):
+        run(ctx, 200, 280, 229.33, seed=tb[0], tables=tb)
     if "--big" in sys.argv:
         run(ctx, 1024, 1536, 341.33, seed=5)
         run(ctx, 1024, 1536, 166.67, seed=6, halation=False, mtf=False, grain=0)
