@@ -14,8 +14,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
-SOURCES = ["r2f_kernels.hip", "r2f_fft.hip", "r2f_front.hip", "r2f_post.hip", "r2f_api.hip"]
-HEADERS = ["r2f_device.h", "r2f_launch.h", os.path.join("..", "..", "include", "r2f.h")]
+SOURCES = ["r2f_kernels.hip", "r2f_fft.hip", "r2f_fft2d.hip", "r2f_front.hip", "r2f_post.hip", "r2f_api.hip"]
+HEADERS = ["r2f_device.h", "r2f_launch.h", "r2f_fft_math.h", os.path.join("..", "..", "include", "r2f.h")]
 ARCH = "gfx950"
 
 

@@ -92,6 +92,10 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
+    // Tap boxes up to this many taps a side take the on-chip form (r2f_fft2d.hip: 128 x 128 windows held in registers, no scratch
+    // image) instead of the three passes; 0 = never (the default: it moves a third of the bytes but is the slower one, 2.65 against
+    // 1.68 ms for the 35-tap MTF at 100 MP -- one workgroup per CU serialises its load, spectrum and store phases).
+    int opt_fft_onchip_max = 0;
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
     int lanczos_key[4] = {0, 0, 0, 0};
@@ -638,6 +642,77 @@ bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int*
     return best >= 0.0;
 }
 
+// The on-chip form (r2f_fft2d.hip) of the same correlation for a small tap box b: 128 x 128 windows, one workgroup per window
+// pair and channel, one launch, no scratch image and no internal streams.  The kernel spectra (16 x 1024 complex128 per channel,
+// in the kernel's own register order) are built by the same kernel in its mode 1.
+int run_stencil_fft_onchip(r2f_ctx* ctx, int which, const int* chans, int nch, const int* b, const r2f_planes* src, const r2f_planes* dst,
+                           int y0, int y1, int W, int H, int epilogue, float log_eps, hipStream_t s) {
+    StencilSet& set = ctx->stencil[which];
+    const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1, n = kFft2dN;
+    const size_t img = (size_t)n * n;
+    FftConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.ny = a.nx = n;
+    a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
+    a.ax = set.kw / 2 - b[2];
+    a.vy = n - bh + 1;
+    a.vx = (n - bw + 1) & ~3;  // a multiple of 4: window origins stay 16-byte aligned for the float4 stores
+    for (int i = 0; i < nch; ++i) {
+        const int c = chans[i];
+        if (ctx->fft_kf_valid[which][c] && ctx->fft_kf_dims[which][c] == n * 4096 + n) continue;
+        std::vector<float> kimg(img, 0.f);
+        const int kc = set.kc == 1 ? 0 : c;
+        for (int y = 0; y < bh; ++y)
+            for (int x = 0; x < bw; ++x) kimg[(size_t)y * n + x] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
+        int rc = upload(ctx, ctx->fft_kimg, kimg.data(), img * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_bytes(ctx, ctx->fft_kf[which][c], img * sizeof(double2));
+        if (rc) return rc;
+        FftConvArgs k = a;
+        k.src.data = static_cast<float*>(ctx->fft_kimg.p);
+        k.raw = 1;
+        k.nch = 1, k.chan[0] = 0, k.ppc = 1;
+        k.ntiles = 1, k.gx = 1, k.npairs = 1, k.pair0 = 0;
+        k.kf_out = static_cast<double2*>(ctx->fft_kf[which][c].p);
+        R2F_HIP(ctx, launch_fft2d(k, 1, s));
+        ctx->fft_kf_valid[which][c] = true;
+        ctx->fft_kf_dims[which][c] = n * 4096 + n;
+    }
+    a.src = to_dev(src);
+    a.dst = to_dev(dst);
+    a.nch = nch;
+    for (int i = 0; i < nch; ++i) {
+        a.chan[i] = chans[i];
+        a.kfs[i] = static_cast<const double2*>(ctx->fft_kf[which][chans[i]].p);
+    }
+    a.y0 = y0, a.y1 = y1, a.W = W, a.H_global = H;
+    a.gx = (W + a.vx - 1) / a.vx;
+    a.ntiles = a.gx * ((y1 - y0 + a.vy - 1) / a.vy);
+    a.ppc = (a.ntiles + 1) / 2;
+    a.epilogue = epilogue;
+    a.curve = ctx->curve;
+    a.log_eps = log_eps;
+    a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
+    a.pair0 = 0;
+    a.npairs = a.ppc * nch;
+    // algorithmic bytes: the window floats in (the overlap is served by L2), the valid outputs out
+    const double bytes = (double)a.npairs * 2.0 * (img + (double)a.vy * a.vx) * sizeof(float);
+    if (ctx->opt_timing & 2) {  // reported with the column passes of its scratch class (bench.py's per-pass table)
+        hipEvent_t e0, e1;
+        R2F_HIP(ctx, hipEventCreate(&e0));
+        R2F_HIP(ctx, hipEventCreate(&e1));
+        R2F_HIP(ctx, hipEventRecord(e0, s));
+        R2F_HIP(ctx, launch_fft2d(a, 0, s));
+        R2F_HIP(ctx, hipEventRecord(e1, s));
+        const int cls = 1 + 3 * (((ctx->opt_fft_s32 >> which) & 1) ? 1 : 0);
+        ctx->timing_ev[cls].push_back({e0, e1});
+        ctx->timing_bytes[cls] += bytes;
+        return R2F_OK;
+    }
+    R2F_HIP(ctx, launch_fft2d(a, 0, s));
+    return R2F_OK;
+}
+
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
 // their window pairs share the launches.
 int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2f_planes* src, const r2f_planes* dst, int y0, int y1,
@@ -646,6 +721,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     int b[4];
     tap_box(set, chans[0], b);
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
+    if (std::max(bh, bw) <= ctx->opt_fft_onchip_max && !ctx->opt_fft_window && !ctx->opt_fft_window_rows)
+        return run_stencil_fft_onchip(ctx, which, chans, nch, b, src, dst, y0, y1, W, H, epilogue, log_eps, s);
     int ny = 256, nx = 256;
     if (!fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, &ny, &nx))
         return fail(ctx, R2F_EINVAL, "stencil %d: no FFT window shape fits a %d x %d tap box under the current stencil_fft_window* options",
@@ -917,7 +994,8 @@ int r2f_create(int device, r2f_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return R2F_EHIP;
     DeviceGuard guard(device);  // the caller's current device is restored on return
     if (guard.status != hipSuccess) return R2F_EHIP;
-    if (init_kernel_attributes() != hipSuccess || fft_init_attributes() != hipSuccess || front_fast_init_attributes() != hipSuccess)
+    if (init_kernel_attributes() != hipSuccess || fft_init_attributes() != hipSuccess || fft2d_init_attributes() != hipSuccess ||
+        front_fast_init_attributes() != hipSuccess)
         return R2F_EHIP;
     r2f_ctx* ctx = new r2f_ctx();
     ctx->device = device;
@@ -1045,6 +1123,11 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_scratch32")) {
         if (value < 0 || value > 7) return fail(ctx, R2F_EINVAL, "stencil_fft_scratch32 is a mask over the three stencils (0..7)");
         ctx->opt_fft_s32 = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_onchip_max")) {
+        if (value < 0 || value > 96) return fail(ctx, R2F_EINVAL, "stencil_fft_onchip_max must be in [0, 96]");
+        ctx->opt_fft_onchip_max = value;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_batch")) {
