@@ -74,6 +74,32 @@ struct DevPlanes {
     int rows;
 };
 
+// ---------------------------------------------------------------------------- streaming accesses
+// Non-temporal 16-byte accesses for frame-sized buffers that are written once and read back a stage later (1.2 GB per plane set
+// at 100 MP, far beyond the 256 MB Infinity Cache).  On MI355X a float4 copy runs 6.57 TB/s that way against 6.23 with plain loads
+// and stores (tools/ubench/copy_rate.hip).  Measured per use (A/B, 100 MP): the output stores of FFT pass 3 gain (halation 2.52 ->
+// 2.48 ms, MTF 1.69 -> 1.66); the front kernel's loads and stores LOSE (0.50 -> 0.55 ms; the fused LUT-only pass 0.247 -> 0.266),
+// the tail is indifferent -- so only pass 3 uses them.  R2F_NT=0 for A/B runs.
+#ifndef R2F_NT
+#define R2F_NT 1
+#endif
+typedef float r2f_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#if R2F_NT
+    const r2f_f4v v = __builtin_nontemporal_load(reinterpret_cast<const r2f_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st4_stream(float* p, const float4 v) {
+#if R2F_NT
+    __builtin_nontemporal_store((r2f_f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<r2f_f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------- helpers
 // BORDER_REFLECT_101 (what cv.filter2D uses on the reference's CPU path): ... c b | a b c d | c b ...
 __device__ __forceinline__ int reflect101(int i, int n) {

@@ -532,7 +532,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
             for (int j = 0; j < 4; ++j) {
                 const int c = 4 * (l + LPL * j);
                 const float4 val = *reinterpret_cast<const float4*>(tf + c);
-                if (c < c_end) *reinterpret_cast<float4*>(dbase + c) = val;
+                if (c < c_end) st4_stream(dbase + c, val);  // (a plane set: read back a stage later, 1.2 GB on)
             }
             __builtin_amdgcn_wave_barrier();
         } else {
