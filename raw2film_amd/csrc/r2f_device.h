@@ -101,6 +101,15 @@ __device__ __forceinline__ void st4_stream(float* p, const float4 v) {
 }
 
 // ---------------------------------------------------------------------------- helpers
+// The thread id as a value the compiler has to take as new: what is derived from it is computed where it is used instead of being
+// kept (and, at a kernel's VGPR cap, spilled: 20 bytes per lane of the generic stencil kernel in round 2) across the accumulation loops.
+__device__ __forceinline__ int fresh_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+
 // BORDER_REFLECT_101 (what cv.filter2D uses on the reference's CPU path): ... c b | a b c d | c b ...
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (i >= 0 && i < n) return i;

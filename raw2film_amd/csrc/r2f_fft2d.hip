@@ -131,24 +131,23 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     float* imgA = reinterpret_cast<float*>(sm);
     float* imgB = imgA + kW * kPitchF;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane >> 3, x = lane & 7;
+    const int tid = threadIdx.x, x = tid & 7;
     const int gp = a.pair0 + blockIdx.x, ci = gp / a.ppc, pc = gp - ci * a.ppc;
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
     const bool hasA = MODE == 1 ? true : window_of2(a, 2 * pc, wyA, wxA);
     const bool hasB = MODE == 1 ? false : window_of2(a, 2 * pc + 1, wyB, wxB);
-    // per slice: the row held in the row layouts (virtual wave w: rows (w / 2) * 16 + (w & 1) + 2 li), the column (frequency)
-    // held in the column layouts (virtual tid / 8), the line tile, and the bases of the 2-D image (element (row, x + c) at
-    // by_row[c]; element (x + r, col) at by_col[r * kPitch2D], rows 64 .. 127 past the 16-bit immediate: by_col + 64 rows)
-    int row[kSlices];
-    double *tile[kSlices], *by_row[kSlices], *by_col[kSlices];
-#pragma unroll
-    for (int s = 0; s < kSlices; ++s) {
-        const int vt = tid + kThreads * s, w = vt >> 6;
-        row[s] = (w >> 1) * 16 + (w & 1) + 2 * li;
-        tile[s] = sm + (vt >> 3) * kLineStride;
-        by_row[s] = sm + row[s] * kPitch2D + x;
-        by_col[s] = sm + x * kPitch2D + (vt >> 3);
-    }
+    // per slice s (virtual thread tid + 512 s, virtual wave w): the row held in the row layouts, (w / 2) * 16 + (w & 1) + 2 li;
+    // the column (frequency) held in the column layouts = the line tile slot, virtual tid / 8; the bases of the 2-D image: element
+    // (row, x + c) at by_row[c], element (x + r, col) at by_col[r * kPitch2D] (rows 64 .. 127 past the 16-bit immediate:
+    // by_col + 64 rows).  Made from a fresh read of the thread id wherever they are used: carried through the whole kernel they
+    // are what the allocator spills first.
+    auto row_of = [&](int s) {
+        const int vt = fresh_tid() + kThreads * s, w = vt >> 6;
+        return (w >> 1) * 16 + (w & 1) + 2 * ((vt & 63) >> 3);
+    };
+    auto tile_of = [&](int s) { return sm + ((fresh_tid() + kThreads * s) >> 3) * kLineStride; };
+    auto by_row_of = [&](int s) { return sm + row_of(s) * kPitch2D + (fresh_tid() & 7); };
+    auto by_col_of = [&](int s) { return sm + (fresh_tid() & 7) * kPitch2D + ((fresh_tid() + kThreads * s) >> 3); };
     // ---- window floats -> fp32 staging images (coalesced: 128 consecutive lanes read one row)
     {
         const float* src = a.src.data + (long long)a.chan[ci] * a.src.plane_stride;
@@ -185,38 +184,46 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
     cplx v[kSlices][16];  // rows, layout A: element (row, x + 8 q) in v[s][q]
 #pragma unroll
     for (int s = 0; s < kSlices; ++s) {
-        const float* pa = imgA + row[s] * kPitchF + x;
+        const float* pa = imgA + row_of(s) * kPitchF + x;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[s][q] = make_double2((double)pa[8 * q], (double)pa[kW * kPitchF + 8 * q]);
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<false>(v[s], tile[s], x);  // v[f1 + 8 h]: row frequency 16 f1 + x + 8 h
+    for (int s = 0; s < kSlices; ++s) line_fft<false>(v[s], tile_of(s), x);  // v[f1 + 8 h]: row frequency 16 f1 + x + 8 h
     // ---- 2-D exchange: row threads -> column threads (layout A along the rows: thread (col, r1 = x) holds rows x + 8 q)
     double re[kSlices][16];
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        double* const br = by_row_of(s);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) by_row[s][16 * (m & 7) + 8 * (m >> 3)] = v[s][m].x;
+        for (int m = 0; m < 16; ++m) br[16 * (m & 7) + 8 * (m >> 3)] = v[s][m].x;
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        const double* const bc = by_col_of(s);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) re[s][q] = (q < 8 ? by_col[s] : by_col[s] + 64 * kPitch2D)[8 * (q & 7) * kPitch2D];
+        for (int q = 0; q < 16; ++q) re[s][q] = (q < 8 ? bc : bc + 64 * kPitch2D)[8 * (q & 7) * kPitch2D];
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        double* const br = by_row_of(s);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) by_row[s][16 * (m & 7) + 8 * (m >> 3)] = v[s][m].y;
+        for (int m = 0; m < 16; ++m) br[16 * (m & 7) + 8 * (m >> 3)] = v[s][m].y;
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        const double* const bc = by_col_of(s);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[s][q] = make_double2(re[s][q], (q < 8 ? by_col[s] : by_col[s] + 64 * kPitch2D)[8 * (q & 7) * kPitch2D]);
+        for (int q = 0; q < 16; ++q) v[s][q] = make_double2(re[s][q], (q < 8 ? bc : bc + 64 * kPitch2D)[8 * (q & 7) * kPitch2D]);
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<false>(v[s], tile[s], x);  // v[f1 + 8 h]: 2-D frequency (16 f1 + x + 8 h, col)
+    for (int s = 0; s < kSlices; ++s) line_fft<false>(v[s], tile_of(s), x);  // v[f1 + 8 h]: 2-D frequency (16 f1 + x + 8 h, col)
     if (MODE == 1) {  // conj of the kernel's spectrum, in the order the correlation reads it
 #pragma unroll
         for (int s = 0; s < kSlices; ++s)
@@ -232,31 +239,39 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
         b_to_a(v[s]);
     }
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<true>(v[s], tile[s], x);  // v[r1 + 8 h]: row 16 r1 + x + 8 h of column-frequency col
+    for (int s = 0; s < kSlices; ++s) line_fft<true>(v[s], tile_of(s), x);  // v[r1 + 8 h]: row 16 r1 + x + 8 h of column-frequency col
     // ---- 2-D exchange back: column threads -> row threads (layout A along the columns: thread (row, i1 = x) holds x + 8 i2)
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        double* const bc = by_col_of(s);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) ((m & 7) < 4 ? by_col[s] : by_col[s] + 64 * kPitch2D)[(16 * (m & 3) + 8 * (m >> 3)) * kPitch2D] = v[s][m].x;
+        for (int m = 0; m < 16; ++m) ((m & 7) < 4 ? bc : bc + 64 * kPitch2D)[(16 * (m & 3) + 8 * (m >> 3)) * kPitch2D] = v[s][m].x;
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        const double* const br = by_row_of(s);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) re[s][q] = by_row[s][8 * q];
+        for (int q = 0; q < 16; ++q) re[s][q] = br[8 * q];
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        double* const bc = by_col_of(s);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) ((m & 7) < 4 ? by_col[s] : by_col[s] + 64 * kPitch2D)[(16 * (m & 3) + 8 * (m >> 3)) * kPitch2D] = v[s][m].y;
+        for (int m = 0; m < 16; ++m) ((m & 7) < 4 ? bc : bc + 64 * kPitch2D)[(16 * (m & 3) + 8 * (m >> 3)) * kPitch2D] = v[s][m].y;
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s)
+    for (int s = 0; s < kSlices; ++s) {
+        const double* const br = by_row_of(s);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[s][q] = make_double2(re[s][q], by_row[s][8 * q]);
+        for (int q = 0; q < 16; ++q) v[s][q] = make_double2(re[s][q], br[8 * q]);
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<true>(v[s], tile[s], x);  // v[k1 + 8 h]: output (row, 16 k1 + x + 8 h); .x window A, .y window B
+    for (int s = 0; s < kSlices; ++s) line_fft<true>(v[s], tile_of(s), x);  // v[k1 + 8 h]: output (row, 16 k1 + x + 8 h); .x window A, .y window B
     // ---- outputs -> fp32 staging images -> coalesced stores of the valid region
     __syncthreads();
     {
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
         const int ch = a.chan[ci];
 #pragma unroll
         for (int s = 0; s < kSlices; ++s) {
-            float* po = imgA + row[s] * kPitchF + x;
+            float* po = imgA + row_of(s) * kPitchF + x;
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 float oa = (float)(v[s][m].x * scale), ob = (float)(v[s][m].y * scale);

@@ -301,7 +301,8 @@ template <int NT>
 __device__ __forceinline__ void fill_tile_reflect(float* lds, int RS, int rows, int cols_valid, const float* src,
                                                   int src_gy0, int src_rows, int W, int H_global, int ty0, int tx0) {
     constexpr int NW = NT / 64, KR = 4, KC = 4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = fresh_tid();
+    const int wave = tid >> 6, lane = tid & 63;
     for (int cb = 0; cb < RS; cb += 64 * KC) {  // column blocks of 256 (one pass for stencils up to 128 taps wide)
         int sx[KC];
 #pragma unroll
@@ -391,13 +392,14 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         }
     }
 
-    const int gx = tile_x0 + 4 * tx;
+    const int tid_out = fresh_tid();  // (the output coordinates are made here, not carried through the loops above)
+    const int gx = tile_x0 + 4 * (tid_out % BX);
     if (gx >= a.W) return;
     const int nv = min(4, a.W - gx);
     float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int gy = tile_y0 + ty * Q + q;
+        const int gy = tile_y0 + (tid_out / BX) * Q + q;
         if (gy >= a.y1) break;
         float v[4] = {acc[q / 2][0][q & 1], acc[q / 2][1][q & 1], acc[q / 2][2][q & 1], acc[q / 2][3][q & 1]};
         if (EPI == 1) {
