@@ -22,13 +22,15 @@ def _free_port():
     return p
 
 
-def _render(rank, world, H, W, fw, burn=0.0):
+def _render(rank, world, H, W, fw, burn=0.0, direct=False):
     from raw2film_amd import HipProcessor, stencils
     from raw2film_amd.hip_processor import REC709_TO_XYZ
     from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
 
     neg, prt, _ = stocks()
     proc = HipProcessor(device=0)
+    if direct:
+        proc.ctx.set_option("stencil_fft", 0)  # tile-independent tap order: shards and whole frame agree bit for bit
     params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
                           frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0,
                           highlight_burn=burn, burn_scale=20)
@@ -46,7 +48,7 @@ def _render(rank, world, H, W, fw, burn=0.0):
     return out.cpu().numpy(), proc, params, img
 
 
-def _worker(rank, world, port, H, W, fw, path, burn=0.0):
+def _worker(rank, world, port, H, W, fw, path, burn=0.0, direct=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -54,7 +56,7 @@ def _worker(rank, world, port, H, W, fw, path, burn=0.0):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out, _, _, _ = _render(rank, world, H, W, fw, burn)
+        out, _, _, _ = _render(rank, world, H, W, fw, burn, direct)
         np.save(f"{path}.{rank}.npy", out)
     finally:
         dist.destroy_process_group()
@@ -71,6 +73,24 @@ def test_two_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
     np.testing.assert_array_equal(sharded, whole)
     ref, _ = proc.ctx.render(img, params)
     np.testing.assert_array_equal(whole, ref.cpu().numpy())
+
+
+def test_four_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
+    """Four ranks (gloo, all on cuda:0): ranks 1 and 2 have a neighbour on BOTH sides, which a 2-rank world never exercises --
+    two sends and two receives in one batch, halos above and below.  Direct stencils: bit-identical to the whole frame."""
+    import torch.multiprocessing as mp
+
+    H, W, fw = 280, 192, 1.0  # 192 px/mm -> 49-tap halation, 19-tap MTF; shards of 70 rows, halos of 24 + 9
+    path = str(tmp_path / "shard")
+    for direct in (True, False):
+        mp.spawn(_worker, args=(4, _free_port(), H, W, fw, path, 0.0, direct), nprocs=4, join=True)
+        sharded = np.concatenate([np.load(f"{path}.{r}.npy") for r in range(4)])
+        whole, proc, params, img = _render(0, 1, H, W, fw, direct=direct)
+        if direct:
+            np.testing.assert_array_equal(sharded, whole)
+        else:  # FFT windows are anchored at a shard's first row: an fp32 ulp on a handful of pixels
+            assert np.max(np.abs(sharded - whole) / np.maximum(np.abs(whole), 1e-3)) <= 2e-6
+        proc.close()
 
 
 def test_two_rank_hip_row_shards_with_highlight_burn(tmp_path):

@@ -183,6 +183,20 @@ def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("world,H,W,scale,flags", [
+    (4, 131, 48, 100.0, dict()),            # interior ranks talk to BOTH neighbours (a 2-rank world never does); shards of 33 / 33 / 33 / 32
+    (3, 100, 40, 80.0, dict(burn=0.7)),     # odd world, S7's all-reduce over three ranks
+])
+def test_interior_ranks_exchange_with_both_neighbours(tmp_path, world, H, W, scale, flags):
+    path = str(tmp_path / "out.npy")
+    mp.spawn(_worker, args=(world, _free_port(), H, W, scale, flags, path), nprocs=world, join=True)
+    got = np.load(path)
+    p, img = _inputs(H, W, scale, **flags)
+    ref = st.render(img, p)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
 def test_shard_rows_partition():
     for H in (1, 7, 8192, 8191):
         for world in (1, 2, 3, 8):

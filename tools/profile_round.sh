@@ -7,7 +7,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 CFG=${2:-cfg4_100mp}
 OUT=gpurun_out/profile_${TAG}_$CFG
 STEPS=5; WARM=2; PSTEPS=2; PWARM=1
@@ -37,7 +37,7 @@ with open(f"{out}/summary/{tag}_{cfg}_kernel_stats.csv", "w") as fh:
     fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     other = [0, 0.0]
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
-        if "r2f::" in r["Name"]:
+        if "r2f::" in r["Name"] and "stream_copy_kernel" not in r["Name"]:
             fh.write('"%s",%s,%s,%s,%.2f,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                      100 * float(r["TotalDurationNs"]) / total, r["MinNs"], r["MaxNs"]))
         else:
@@ -47,7 +47,7 @@ print(open(f"{out}/summary/{tag}_{cfg}_kernel_stats.csv").read())
 tot = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "r2f::" in row["Kernel_Name"]:
+        if "r2f::" in row["Kernel_Name"] and "stream_copy_kernel" not in row["Kernel_Name"]:  # (bench.py's copy-ceiling measurement is not part of a step)
             tot[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
 once = [len(d["FETCH_SIZE"]) for k, d in tot.items() if any(n in k for n in ("tail_kernel", "front_fast_kernel", "front_kernel", "lut3d_kernel"))]
