@@ -392,6 +392,9 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 // grid (nx / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.  NBX = nx / 16.
 // mode 0: forward along r, multiply by the kernel spectrum, inverse, store back
 // mode 1: forward only; the conjugate IS the kernel spectrum (input = the padded kernel image)
+#ifndef R2F_FFT_EXP2
+#define R2F_FFT_EXP2 0  // development switch for pass 2: bit 0 no scratch loads, bit 1 no stores, bit 2 no spectrum loads
+#endif
 template <int NBX, int ST>
 __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
@@ -399,7 +402,7 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
     char* s1 = simg<ST>(a.s1, pair, (long long)kN * (NBX * 16));
     cplx v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(l + 16 * m, k, NBX));
+    for (int m = 0; m < 16; ++m) v[m] = (R2F_FFT_EXP2 & 1) ? make_double2(1.0 + m + l, 0.5 * k) : sld<ST>(s1, sidx(l + 16 * m, k, NBX));
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
@@ -410,8 +413,12 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(l + 16 * q, k, NBX)));
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (R2F_FFT_EXP2 & 4) ? make_double2(0.5, 0.25 * q) : at(kf, sidx(l + 16 * q, k, NBX)));
     fft256<true>(v, w1, tbuf, lane);
+    if (R2F_FFT_EXP2 & 2) {
+        if (v[3].x == 1.2345e300) sst<ST>(s1, 0, v[5]);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q)
         if (l + 16 * q < a.vy) sst<ST>(s1, sidx(l + 16 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
