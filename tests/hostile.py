@@ -18,9 +18,11 @@ import numpy as np
 F32 = np.float32
 
 
-def lut2d(rng, n: int, rough: float = 1.0, base=None) -> np.ndarray:
+def lut2d(rng, n: int, rough: float = 1.0, base=None, black_texel: bool = True) -> np.ndarray:
     """(n, n, 3) input LUT: positive layer exposures per unit (X+Y+Z).  rough = 1: independent uniform texels in [0.05, 2];
-    smaller values blend towards `base` (resampled to n) or a smooth ramp, keeping +-rough relative noise per texel."""
+    smaller values blend towards `base` (resampled to n) or a smooth ramp, keeping +-rough relative noise per texel.
+    black_texel: one texel at 1e-5 among neighbours of order 1 -- exposures next to it dive towards the log clip with a relative
+    slope of 1e5 per texel; for the per-stage test (identical inputs on both sides), not for the whole path."""
     g = np.linspace(0.0, 1.0, n)
     x, y = np.meshgrid(g, g, indexing="ij")
     if base is not None and base.shape[0] == n:
@@ -40,7 +42,8 @@ def lut2d(rng, n: int, rough: float = 1.0, base=None) -> np.ndarray:
         out = rng.uniform(0.05, 2.0, (n, n, 3))
     else:
         out = smooth * (1.0 + rough * noise)
-    out[rng.integers(0, n), rng.integers(0, n)] = 1e-5  # one near-black texel (exposures next to it dive towards the log clip)
+    if black_texel:
+        out[rng.integers(0, n), rng.integers(0, n)] = 1e-5
     return np.maximum(out, 1e-6).astype(F32)
 
 
@@ -109,7 +112,7 @@ def roughen(rng, p, n2: int, m1: int, n3: int, rough2: float = 0.2, rough3: floa
     # a relative error of the exposure -- does not grow with n2; and n3 >= 17: across a coarser cell a print-like fall-off drops by
     # a factor of 25, and linear interpolation inside it has 7 times the relative slope of the curve it samples.  Measured with
     # R2F_FUZZ_CASES=150: 11 of 50 hostile cases over 1e-5, up to 3.9e-5, all with n3 = 9 or n2 >= 100 at full noise)
-    p.lut_2d = lut2d(rng, n2, rough2 * min(1.0, 32.0 / (n2 - 1)), base=p.lut_2d)
+    p.lut_2d = lut2d(rng, n2, rough2 * min(1.0, 32.0 / (n2 - 1)), base=p.lut_2d, black_texel=False)
     p.lut_1d = curve(rng, m1, v_lo=0.08, v_hi=3.6, max_slope=1.5, monotone=True)
     p.lut_3d = lut3d(rng, n3, rough3)
     if p.grain_lut is not None:
