@@ -171,8 +171,10 @@ def test_max_scale_round_trip_is_planned_like_the_cpu_processor(proc):
     assert (round(400 * f), round(600 * f)) == (154, 232)
     assert p["resize_to"] == (154, 231) and p["pipeline_resolution"] == (231, 154)
     assert p["upscale_to"] == (400, 600)
-    g = min(400 / 154, 600 / 231)
-    assert p["output_resolution"] == (round(231 * g), round(154 * g)) == (600, 400)
+    # `output_resolution` is what GpuProcessor.extract_image_data_cpu reports (gpu_processor.py:764: the PIPELINE size divided by
+    # the clamp factor, rounded -- not the size of the finished frame, which follows `upscale_to`): pinned for 3 344 cases by
+    # tests/golden/payload_geometry.npz
+    assert p["output_resolution"] == (round(231 / f), round(154 / f)) == (598, 399)
     # below the limit nothing happens; max_scale=None switches the clamp off
     q = proc.extract_image_data_cpu(img, frame_width=36, frame_height=24, max_scale=40.0)
     assert q["resize_to"] is None and q["upscale_to"] is None and q["output_resolution"] == (600, 400)
