@@ -266,7 +266,8 @@ def test_graph_replay_follows_parameter_table_and_buffer_changes():
     proc.close()
 
 
-def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tmp_path):
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tmp_path, ranks):
     """bench.py's N > 1 path end to end on a one-GPU box: torch.distributed.run with two ranks over gloo that share cuda:0 (RCCL
     refuses two ranks on one device; only the transport differs from the real run).  The line must say n_gpus 2 and strong
     scaling, and with the direct stencils (tile-independent tap order) the sharded frame's checksum equals the whole frame's."""
@@ -280,7 +281,8 @@ def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tm
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # no launcher: `python bench.py --gpus 2` starts its two ranks itself (as a child running torch.distributed.run)
-    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device"] + common,
+    # (4 ranks: the middle two have a neighbour on both sides)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--same-device"] + common,
                          capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900,
@@ -288,12 +290,12 @@ def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tm
     assert one.returncode == 0, one.stderr[-2000:]
     l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
-    assert l2["n_gpus"] == 2 and l2["scaling"] == "strong" and l1["n_gpus"] == 1
+    assert l2["n_gpus"] == ranks and l2["scaling"] == "strong" and l1["n_gpus"] == 1
     assert l2["metric"] == l1["metric"] and l2["unit"] == "MP/s" and l2["value"] > 0
-    assert "row-sharded over 2 GPUs" in l2["config"]["sharding"]
+    assert f"row-sharded over {ranks} GPUs" in l2["config"]["sharding"]
     assert l2["checksum"] == l1["checksum"]
-    assert l2["roofline"]["peak"] == 2 * l1["roofline"]["peak"]
-    assert l2["gloo_ranks"] == 2 and "rccl_ranks" not in l2  # (RCCL's count appears with --backend nccl: tests/test_gpu_multi.py)
+    assert l2["roofline"]["peak"] == ranks * l1["roofline"]["peak"]
+    assert l2["gloo_ranks"] == ranks and "rccl_ranks" not in l2  # (RCCL's count appears with --backend nccl: tests/test_gpu_multi.py)
     for line in (l1, l2):
         assert line["ms_per_step_min"] <= line["ms_per_step_median"] <= line["ms_per_step_max"]
         assert line["roofline"]["copy_ceiling_GBps"] > 1000 and 0 < line["roofline"]["frac_of_copy_ceiling"] < 1
