@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4_100mp|cfg3_45mp|cfg2_24mp|cfg5_batch]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`--gpus N` > 1 without a launcher: bench.py starts its N ranks itself, as a child process running torch.distributed.run.)
 
 A "step" is one pass of the hot path (S0..S8, float32 output) over one synthetic decoded frame that is already
 resident in HBM.  N = 1: the whole frame on one MI355X.  N > 1: the SAME frame, row-sharded over N GPUs with the RCCL
@@ -15,6 +16,10 @@ Objects on that line besides the contract's keys:
                 capture does not match what is running; provenance beside it); `dominant_kernel` = the FFT pass with the
                 largest share of the step, timed live with HIP events on its launch streams; `fp64_valu` = the FFT
                 passes' fp64 work against the 78.6 TFLOP/s vector peak.
+                `copy_ceiling_GBps` / `frac_of_copy_ceiling`: a float4 streaming copy of the frame's own 12 B/px in -> 12 B/px
+                out, measured in this run (r2f_stream_copy) -- the practical ceiling beside the spec peak.
+  ms_per_step_median / _min / _max   HIP events between consecutive steps on the launch stream (ms_per_step is the wall clock).
+  rccl_ranks    N > 1: an all-reduce (SUM) of ones over the process group that carried the halo exchange.
   stage_ms      per-stage device time (events on the launch stream, inside the timed steps).
   cpu_baseline  the NumPy oracle ("port") timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
