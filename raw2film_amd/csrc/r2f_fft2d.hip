@@ -190,7 +190,10 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<false>(v[s], tile_of(s), x);  // v[f1 + 8 h]: row frequency 16 f1 + x + 8 h
+    for (int s = 0; s < kSlices; ++s) {
+        line_fft<false>(v[s], tile_of(s), x);
+        __builtin_amdgcn_sched_barrier(0);  // one slice's transform at a time: interleaved, the two overflow the 256 VGPRs
+    }  // v[f1 + 8 h]: row frequency 16 f1 + x + 8 h
     // ---- 2-D exchange: row threads -> column threads (layout A along the rows: thread (col, r1 = x) holds rows x + 8 q)
     double re[kSlices][16];
     __syncthreads();
@@ -223,7 +226,10 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<false>(v[s], tile_of(s), x);  // v[f1 + 8 h]: 2-D frequency (16 f1 + x + 8 h, col)
+    for (int s = 0; s < kSlices; ++s) {
+        line_fft<false>(v[s], tile_of(s), x);
+        __builtin_amdgcn_sched_barrier(0);  // one slice's transform at a time: interleaved, the two overflow the 256 VGPRs
+    }  // v[f1 + 8 h]: 2-D frequency (16 f1 + x + 8 h, col)
     if (MODE == 1) {  // conj of the kernel's spectrum, in the order the correlation reads it
 #pragma unroll
         for (int s = 0; s < kSlices; ++s)
@@ -239,7 +245,10 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
         b_to_a(v[s]);
     }
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<true>(v[s], tile_of(s), x);  // v[r1 + 8 h]: row 16 r1 + x + 8 h of column-frequency col
+    for (int s = 0; s < kSlices; ++s) {
+        line_fft<true>(v[s], tile_of(s), x);
+        __builtin_amdgcn_sched_barrier(0);
+    }  // v[r1 + 8 h]: row 16 r1 + x + 8 h of column-frequency col
     // ---- 2-D exchange back: column threads -> row threads (layout A along the columns: thread (row, i1 = x) holds x + 8 i2)
     __syncthreads();
 #pragma unroll
@@ -271,7 +280,10 @@ __global__ __launch_bounds__(kThreads) void fft2d_kernel(const FftConvArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < kSlices; ++s) line_fft<true>(v[s], tile_of(s), x);  // v[k1 + 8 h]: output (row, 16 k1 + x + 8 h); .x window A, .y window B
+    for (int s = 0; s < kSlices; ++s) {
+        line_fft<true>(v[s], tile_of(s), x);
+        __builtin_amdgcn_sched_barrier(0);
+    }  // v[k1 + 8 h]: output (row, 16 k1 + x + 8 h); .x window A, .y window B
     // ---- outputs -> fp32 staging images -> coalesced stores of the valid region
     __syncthreads();
     {
