@@ -180,14 +180,24 @@ def main():
                               halation_taps=stencils.vertical_reach(hal_k) if effects else (0, 0),
                               mtf_taps=stencils.vertical_reach(mtf_k) if effects else (0, 0))
     use_graph = not args.no_graph and effects and not args.side_grain
-    if batch:  # whole frames per rank: a renderer of world size 1, and this rank's share of the frames per step
-        renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, rank=0, world=1, graph=use_graph)
-        frames_here = len([i for i in range(args.frames) if i % world == rank])
+    # N = 1 (and every rank of the frame-per-GPU batch): the product's own entry -- HipProcessor.process_array on device tensors,
+    # i.e. prepare() + r2f_render, with a NEW grain seed every frame like the reference's renders (gpu_processor.py:585-597).
+    # r2f_render replays the frame's launches from a HIP graph (one submit per frame); the seed travels in a device-side block.
+    # N > 1: one frame row-sharded over the ranks (RowShardedRenderer: halo exchange + the stage entry points, graph replay
+    # downstream of the exchange), also with a new seed every step.
+    use_processor = (batch or world == 1) and not args.side_grain
+    renderer = None
+    if use_processor:
+        if args.no_graph:
+            proc.ctx.set_option("render_graph", 0)
+        frames_here = len([i for i in range(args.frames) if i % world == rank]) if batch else 1
+        r0, r1 = 0, H
     else:
         renderer = RowShardedRenderer(backend, H, W, halation=effects, mtf=effects, grain=effects, side_grain=args.side_grain,
                                       graph=use_graph)
         frames_here = 1
-    r0, r1 = renderer.plan.r0, renderer.plan.r1
+        r0, r1 = renderer.plan.r0, renderer.plan.r1
+    replaying = (use_graph and effects) if use_processor else renderer.graph
 
     # this rank's rows of the synthetic frame, resident in HBM before the clock starts
     if args.checksum:
@@ -202,8 +212,13 @@ def main():
     from raw2film_amd.tracing import TimedBackend
 
     timed = TimedBackend(backend)
-    if not renderer.graph:
+    if renderer is not None and not renderer.graph:
         renderer.backend = timed
+    frame_no = [0]
+
+    def next_seed():
+        frame_no[0] += 1  # (--checksum compares frames across --gpus values: one seed)
+        return GRAIN_SEED if args.checksum else (GRAIN_SEED + frame_no[0]) & 0xFFFFFFFF
 
     def barrier():
         torch.cuda.synchronize()
@@ -213,20 +228,25 @@ def main():
 
     def step():
         for _ in range(frames_here):
-            renderer.render(frame, out_f32=out)
+            if use_processor:
+                proc.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=next_seed(), return_float=True,
+                                   output="device", out=out, **settings)
+            else:
+                renderer.render(frame, out_f32=out, seed=next_seed())
 
     def drain_timing():
         return [proc.ctx.kernel_timing(cls) for cls in range(6)]  # (total ms, launches, algorithmic bytes) per class
 
-    for _ in range(max(args.warmup, 2 if renderer.graph else 0)):  # (the graph is captured on the second frame)
+    for _ in range(max(args.warmup, 2 if replaying else 0)):  # (the graph is captured on the second frame)
         step()
     barrier()
     timed.reset()
     # events around every launch of the FFT column passes (the kernels with the largest share), on their launch streams
     # (eager launches only: a replayed graph carries no events -- its breakdown comes from two eager steps afterwards)
-    if not renderer.graph:
+    if not replaying and not use_processor:
         proc.ctx.set_option("kernel_timing", 2)
     drain_timing()
+    stats0 = proc.ctx.render_stats()
     # per-step device times (median of event-timed runs): one event between consecutive steps on the launch stream;
     # the contract's number stays the wall clock around all K steps
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -280,8 +300,17 @@ def main():
         },
     }
 
-    result["config"]["launch"] = ("HIP graph replay of the frame's launches" + (" downstream of the halo exchange" if world > 1 else "")
-                                  if renderer.graph else "one host launch per kernel")
+    if use_processor:
+        stats1 = proc.ctx.render_stats()
+        result["config"]["launch"] = (
+            "HipProcessor.process_array (device tensors in and out) -> prepare() + r2f_render, a new grain seed every frame; "
+            + ("r2f_render replays the frame's captured HIP graph: one seed write + one graph launch per frame"
+               if replaying else "one host launch per kernel (render_graph = 0)"))
+        result["config"]["render_stats_timed_steps"] = {k: stats1[k] - stats0[k] for k in stats1}
+    else:
+        result["config"]["launch"] = ("RowShardedRenderer, a new grain seed every step; "
+                                      + ("HIP graph replay of the frame's launches downstream of the halo exchange"
+                                         if renderer.graph else "one host launch per kernel"))
     if use_dist:
         # how many ranks the collective backend really joined: an all-reduce (SUM) of ones over the process group that carried
         # the halo exchange ("nccl" = RCCL over xGMI on the GPU box)
@@ -297,14 +326,15 @@ def main():
             dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         result["checksum"] = int(cs.item())
     eager = None
-    if renderer.graph:  # the breakdowns below need per-launch events: the same frame through the eager path
+    if replaying or use_processor:  # the breakdowns below need per-launch events: the same frame, stage by stage, eagerly
         eager = RowShardedRenderer(timed, H, W, halation=effects, mtf=effects, grain=effects,
-                                   **({"rank": 0, "world": 1} if batch else {}))
-        eager.E, eager.D, eager.D2 = renderer.E, renderer.D, renderer.D2  # share the planes (no second 2.4 GB set)
+                                   **({"rank": 0, "world": 1} if use_processor else {}))
+        if renderer is not None:
+            eager.E, eager.D, eager.D2 = renderer.E, renderer.D, renderer.D2  # share the planes (no second 2.4 GB set)
 
         def step():  # noqa: F811 -- from here on the eager renderer
             for _ in range(frames_here):
-                eager.render(frame, out_f32=out)
+                eager.render(frame, out_f32=out, seed=next_seed())
 
         proc.ctx.set_option("kernel_timing", 2)
         drain_timing()
@@ -317,8 +347,8 @@ def main():
         steps_for_cols = args.steps
     stage_ms = timed.summary()
     result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
-    if renderer.graph:
-        result["stage_ms_note"] = "two eager steps after the timed (graph-replay) steps"
+    if eager is not None:
+        result["stage_ms_note"] = "two eager stage-by-stage steps (RowShardedRenderer over the stage entry points) after the timed steps"
     cols = drain_timing()  # only the column passes (classes 1 and 4) were on
     # the other two passes, for the breakdown only: two extra steps outside the timed region
     proc.ctx.set_option("kernel_timing", 5)
@@ -371,7 +401,7 @@ def main():
             t = torch.tensor([ceil_gbps], dtype=torch.float64, device=frame.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             ceil_gbps = float(t.item())
-        else:
+        elif not args.same_device:  # (ranks that share one GPU share one ceiling: ADVICE r3)
             ceil_gbps *= world
         roof["copy_ceiling_GBps"] = ceil_gbps
         roof["copy_ceiling_ms"] = best

@@ -53,9 +53,12 @@ enum {
     R2F_F_GRAIN = 1u << 3,    /* S6 (+ the clip of cpu_processor.py:397) */
     R2F_F_GRAIN_MONO = 1u << 4, /* grain == 1: noise_bw.wgsl */
     R2F_F_BURN = 1u << 5,       /* S7 highlight burn (effects.py:396-418), needs burn_* below */
-    R2F_F_IDENTITY_DONE = 1u << 6 /* r2f_stage_halation only: the channels whose halation stencil is a single tap at the anchor
+    R2F_F_IDENTITY_DONE = 1u << 6, /* r2f_stage_halation only: the channels whose halation stencil is a single tap at the anchor
                                      (the blue layer of a colour stock, effects.py:248-263) were already finished into the
                                      density planes by r2f_stage_front_split for rows [y0, y1) -- skip them */
+    R2F_F_FRAME_RESIDENT = 1u << 7 /* stage entry points: do NOT write p->seed into the context's device-side frame block first;
+                                     the kernels read what r2f_write_frame_params last wrote there (in stream order).  For callers
+                                     that replay captured launches: the write stays outside the capture, the launches inside */
 };
 
 /* `upto` of r2f_stage_front */
@@ -63,7 +66,8 @@ enum { R2F_UPTO_EXPOSURE = 0, R2F_UPTO_DENSITY = 1, R2F_UPTO_OUTPUT = 2 };
 
 typedef struct r2f_params {
     uint32_t flags;
-    uint32_t seed;      /* grain seed; upstream: random per render (gpu_processor.py:586-592) */
+    uint32_t seed;      /* grain seed; upstream: random per render (gpu_processor.py:586-592).  Never a launch argument: it is
+                           written to a device-side block the grain kernels read (r2f_write_frame_params) */
     float log_eps;      /* lut_1d.wgsl:24 -> 1e-6 */
     float lut3d_scale;  /* cpu_processor.py:405 -> 0.25 */
     int32_t lut3d_mode; /* 0 tetrahedral (utils.py:247, the parity target), 1 trilinear (lut_3d.wgsl) */
@@ -108,10 +112,25 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int 
  * workspace: device scratch of at least r2f_workspace_bytes(...) bytes (caller-owned): the plane sets between the stages.
  * Stencils of >= 400 taps run as fp64 overlap-save FFTs (like cv.filter2D's own DFT branch above 11 x 11 taps, which the
  * reference's CPU path takes for both of them); their pass scratch (1 MiB per window pair in flight, 192 by default) and
- * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use. */
+ * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use.
+ *
+ * One submit per frame, like the reference's single command encoder (gpu_processor.py:1760 create_command_encoder ...
+ * :1877 queue.submit): the second time a frame arrives with the same buffers, shape and parameters (the seed excepted) its
+ * launches are captured into a HIP graph on a stream of the context's own and, from then on, a frame costs one write of the
+ * frame block (the seed: the reference re-creates its uniform buffer `buffer_params_grain` per render, gpu_processor.py:585-597) plus one graph
+ * launch on `stream`.  Any table / stencil / option change (r2f_generation) drops the graphs.  Results are the eager
+ * launches', bit for bit.  r2f_set_option(ctx, "render_graph", 0) turns the replay off (A/B). */
 size_t r2f_workspace_bytes(const r2f_params* p, int H, int W);
 int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32_hwc,
                uint8_t* out_u8_hwc, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+/* Counters of r2f_render since r2f_create: out[0] frames replayed from a graph, out[1] graphs captured, out[2] frames launched
+ * kernel by kernel, out[3] graphs dropped (context changes, evictions, failed captures). */
+int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
+
+/* The per-render uniform write: p->seed -> the context's device-side frame block, asynchronously on `stream`
+ * (gpu_processor.py:585-597: the uniform buffer `buffer_params_grain` with a fresh random seed, made ahead of the dispatches;
+ * noise.wgsl:1-6 reads it).  r2f_render and, unless R2F_F_FRAME_RESIDENT is set, every stage entry point that makes grain does this itself. */
+int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream);
 
 /* --- stage entry points (row-shard aware): one per compute pass of
  *     gpu_processor.py:1763-1862; used by the multi-GPU row tiler and by the parity tests.

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
 # enums of include/r2f.h
 LAYOUT_HWC3, LAYOUT_HWC4, LAYOUT_CHW = 0, 1, 2
 KERNEL_HALATION, KERNEL_MTF, KERNEL_GRAIN = 0, 1, 2
-F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO, F_BURN, F_IDENTITY_DONE = 1, 2, 4, 8, 16, 32, 64
+F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO, F_BURN, F_IDENTITY_DONE, F_FRAME_RESIDENT = 1, 2, 4, 8, 16, 32, 64, 128
 UPTO_EXPOSURE, UPTO_DENSITY, UPTO_OUTPUT = 0, 1, 2
 OK, EINVAL, EHIP, ETOOLARGE = 0, -1, -2, -3
 
@@ -147,6 +147,8 @@ _SIGNATURES = {
     "r2f_decode_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "r2f_blit_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _P(Blit), C.c_void_p]),
     "r2f_generation": (C.c_uint64, [C.c_void_p]),
+    "r2f_render_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "r2f_write_frame_params": (C.c_int, [C.c_void_p, _P(Params), C.c_void_p]),
     "r2f_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "r2f_histogram_render": (
         C.c_int,

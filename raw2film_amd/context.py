@@ -90,6 +90,18 @@ class HipContext:
         context's launches is stale once it moves."""
         return int(self._lib.r2f_generation(self._h))
 
+    def render_stats(self) -> dict:
+        """Counters of `render` (r2f_render_stats): frames replayed from a captured HIP graph, graphs captured, frames launched
+        kernel by kernel, graphs dropped."""
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.r2f_render_stats(self._h, out))
+        return {"replays": int(out[0]), "captures": int(out[1]), "eager": int(out[2]), "dropped": int(out[3])}
+
+    def write_frame_params(self, params):
+        """The per-render uniform write (r2f_write_frame_params): params.seed -> the context's device-side frame block, in
+        stream order.  Stage calls whose params carry F_FRAME_RESIDENT read it instead of writing their own seed."""
+        self._check(self._lib.r2f_write_frame_params(self._h, C.byref(params), self._stream()))
+
     def set_option(self, name: str, value: int):
         self._check(self._lib.r2f_set_option(self._h, name.encode(), int(value)))
 

@@ -119,6 +119,33 @@ struct r2f_ctx {
     int opt_front_fast = 1;    // the fused LUT-only pass may take the specialised kernel (r2f_front.hip); 0 = always the generic one (A/B)
     int opt_front_blocks = 6;  // front kernel with the curve in LDS: workgroups per CU in its grid (3 are resident at 48 KB each)
     int opt_lds_kb = 80;  // LDS budget per stencil workgroup; 80 KB -> two workgroups per CU
+    // Per-render values the kernels read through a pointer (FrameParams: the grain seed), so that a captured frame can be
+    // replayed with a new seed; written in stream order by write_frame_params ahead of a frame's launches.
+    DeviceBuf frame_buf;
+    // r2f_render's graph cache: one entry per (buffers, shape, parameters without the seed).  An entry is rendered kernel by
+    // kernel the first time the context sees its structure (tables, scratch and spectra get built then), captured on
+    // `cap_stream` afterwards and replayed on the caller's stream from then on.  Everything is dropped when `generation` moves.
+    struct RenderGraph {
+        const void* in = nullptr;
+        int in_layout = 0;
+        float* out_f32 = nullptr;
+        uint8_t* out_u8 = nullptr;
+        int H = 0, W = 0;
+        void* workspace = nullptr;
+        r2f_params p{};  // seed zeroed
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t last_use = 0;
+        bool never = false;  // a capture of this entry failed: kernel by kernel from now on
+    };
+    std::vector<RenderGraph> graphs;
+    uint64_t graphs_generation = 0;  // `generation` the entries (and `warm`) belong to
+    uint64_t graph_clock = 0;
+    RenderGraph warm;                // structure (shape, layout, parameters) of the last frame launched kernel by kernel
+    bool warm_valid = false;
+    hipStream_t cap_stream = nullptr;
+    int opt_render_graph = 1;
+    uint64_t stat_replays = 0, stat_captures = 0, stat_eager = 0, stat_dropped = 0;
 };
 
 namespace {
@@ -513,6 +540,24 @@ int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
     return R2F_OK;
 }
 
+// p->seed -> the context's device-side frame block, in stream order (a one-lane kernel: its by-value argument is copied at
+// launch time, so no host staging buffer has to outlive the call).
+int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s) {
+    FrameParams v{};
+    v.seed = p->seed;
+    R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, s));
+    return R2F_OK;
+}
+
+void drop_render_graphs(r2f_ctx* ctx) {
+    for (auto& g : ctx->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec), ++ctx->stat_dropped;
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->graphs.clear();
+    ctx->warm_valid = false;
+}
+
 // Bounding box of channel c's non-zero taps: {i_lo, i_hi, j_lo, j_hi}; an all-zero plane keeps its centre tap.
 void tap_box(const StencilSet& s, int c, int box[4]) {
     const int kc = s.kc == 1 ? 0 : c;
@@ -628,6 +673,7 @@ bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int*
             if (x > window_max && x != ctx->opt_fft_window) continue;
             if (bw > 200 ? (x < 512 || (ctx->opt_fft_window >= 512 && x != ctx->opt_fft_window)) : (ctx->opt_fft_window && x != ctx->opt_fft_window)) continue;
             const int vy = y - bh + 1, vx = (x - bw + 1) & ~3;
+            if (vy < 1 || vx < 4) continue;  // the window has to keep outputs (and vx, vy divide below)
             const double n = (double)y * x, part = n * vy / y;
             // per window: pass 1 (floats in, image out), pass 2 (image in, valid rows out), pass 3 (valid rows in, floats out);
             // two windows share one complex image.  The 512-row pass 2 moves its bytes ~1.3 x slower (r2f_fft.hip).
@@ -635,7 +681,6 @@ bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int*
             const double e = s32 ? 4.0 : 8.0;  // scratch bytes per window element (half a complex64 / complex128)
             const double bytes = 4.0 * n + e * n + p2 * (e * n + e * part) + e * part + 4.0 * vy * vx;
             const double cost = (double)((W + vx - 1) / vx) * ((H + vy - 1) / vy) * bytes;
-            if (vy < 1 || vx < 4) continue;  // the window has to keep outputs
             if (best < 0.0 || cost < best) best = cost, *ny = y, *nx = x;
         }
     }
@@ -985,7 +1030,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
 // =============================================================================== C ABI
 extern "C" {
 
-const char* r2f_version(void) { return "r2f-hip 0.3 gfx950 abi3"; }
+const char* r2f_version(void) { return "r2f-hip 0.4 gfx950 abi4"; }
 
 int r2f_create(int device, r2f_ctx** out) {
     if (!out) return R2F_EINVAL;
@@ -999,6 +1044,11 @@ int r2f_create(int device, r2f_ctx** out) {
         return R2F_EHIP;
     r2f_ctx* ctx = new r2f_ctx();
     ctx->device = device;
+    if (hipMalloc(&ctx->frame_buf.p, sizeof(FrameParams)) != hipSuccess || hipMemset(ctx->frame_buf.p, 0, sizeof(FrameParams)) != hipSuccess) {
+        delete ctx;
+        return R2F_EHIP;
+    }
+    ctx->frame_buf.bytes = sizeof(FrameParams);
     *out = ctx;
     return R2F_OK;
 }
@@ -1006,6 +1056,10 @@ int r2f_create(int device, r2f_ctx** out) {
 void r2f_destroy(r2f_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
+    (void)hipDeviceSynchronize();  // nothing in flight may still read what is freed below
+    drop_render_graphs(ctx);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    ctx->frame_buf.release();
     ctx->lut2d_buf.release();
     ctx->lut3d_buf.release();
     ctx->curve_buf.release();
@@ -1043,6 +1097,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_variant")) {
         if (value < -1 || value >= kNumStencilVariants) return fail(ctx, R2F_EINVAL, "stencil_variant out of range");
         ctx->opt_variant = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "render_graph")) {
+        ctx->opt_render_graph = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_lds_kb")) {
@@ -1472,7 +1530,7 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         a.grain_lut = ctx->grain_lut;
     }
     a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
-    a.seed = p->seed;
+    a.frame = static_cast<const FrameParams*>(ctx->frame_buf.p);
     a.lut3d = ctx->lut3d;
     a.lut3d_scale = p->lut3d_scale;
     a.lut3d_mode = p->lut3d_mode;
@@ -1531,6 +1589,10 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         if (tail_lds_bytes(a.gk, a.mono) > kMaxLds)
             return fail(ctx, R2F_ETOOLARGE, "grain stencil %dx%d does not fit the LDS noise tile", a.gk[0].kh, a.gk[0].kw);
         a.grain_lut = ctx->grain_lut;
+    }
+    if (a.grain && !(p->flags & R2F_F_FRAME_RESIDENT)) {  // the seed of THIS call, ahead of the kernel that reads it
+        rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
     }
     R2F_HIP(ctx, launch_tail(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
@@ -1914,8 +1976,12 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
     a.y0 = y0;
     a.y1 = y1;
     a.W = W;
-    a.seed = p->seed;
+    a.frame = static_cast<const FrameParams*>(ctx->frame_buf.p);
     a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
+    if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
+        int rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
     R2F_HIP(ctx, launch_noise(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
@@ -1948,18 +2014,11 @@ size_t r2f_workspace_bytes(const r2f_params* p, int H, int W) {
     return (sets * plane_set_floats(H, W) + burn_scratch_floats(p, H, W)) * sizeof(float);
 }
 
-int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32, uint8_t* out_u8, int H,
-               int W, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!ctx || !p) return R2F_EINVAL;
-    R2F_GUARD(ctx);
-    if (H <= 0 || W <= 0) return fail(ctx, R2F_EINVAL, "render: empty frame");
-    const size_t need = r2f_workspace_bytes(p, H, W);
-    if (need > workspace_bytes || (need && !workspace)) return fail(ctx, R2F_EINVAL, "render: workspace too small (%zu needed)", need);
-    if (need && !aligned16(workspace)) return fail(ctx, R2F_EINVAL, "render: workspace must be 16-byte aligned");
+// The launches of one frame, in order, on stream `stream` (a capturing stream of the context's own or the caller's).
+static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32, uint8_t* out_u8, int H,
+                           int W, void* workspace, void* stream) {
     const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF, grain = p->flags & R2F_F_GRAIN;
     const bool burn = p->flags & R2F_F_BURN;
-    if (!(hal || mtf || grain || burn))  // config "LUTs only": one fused pointwise pass
-        return r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_OUTPUT, nullptr, out_f32, out_u8, 0, 0, H, W, H, stream);
     const size_t set_floats = plane_set_floats(H, W);
     float* base = static_cast<float*>(workspace);
     r2f_planes A{base, (int64_t)(set_floats / 3), 0, H};
@@ -2005,6 +2064,138 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     r2f_params q = *p;
     q.flags &= ~(uint32_t)R2F_F_GRAIN;
     return r2f_stage_tail(ctx, &q, cur, map, out_f32, out_u8, 0, 0, H, W, H, stream);
+}
+
+int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32, uint8_t* out_u8, int H,
+               int W, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (H <= 0 || W <= 0) return fail(ctx, R2F_EINVAL, "render: empty frame");
+    const size_t need = r2f_workspace_bytes(p, H, W);
+    if (need > workspace_bytes || (need && !workspace)) return fail(ctx, R2F_EINVAL, "render: workspace too small (%zu needed)", need);
+    if (need && !aligned16(workspace)) return fail(ctx, R2F_EINVAL, "render: workspace must be 16-byte aligned");
+    const bool hal = p->flags & R2F_F_HALATION, mtf = p->flags & R2F_F_MTF, grain = p->flags & R2F_F_GRAIN;
+    const bool burn = p->flags & R2F_F_BURN;
+    if (!(hal || mtf || grain || burn))  // config "LUTs only": one fused pointwise pass (one submit as it is)
+        return r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_OUTPUT, nullptr, out_f32, out_u8, 0, 0, H, W, H, stream);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // per-launch event timing (bench.py's breakdowns) creates and records events per launch: kernel by kernel only
+    if (!ctx->opt_render_graph || ctx->opt_timing) {
+        ++ctx->stat_eager;
+        return render_launches(ctx, p, in, in_layout, out_f32, out_u8, H, W, workspace, stream);
+    }
+    if (ctx->graphs_generation != ctx->generation) {  // a table, stencil, option or internal buffer moved: frozen pointers are stale
+        drop_render_graphs(ctx);
+        ctx->graphs_generation = ctx->generation;
+    }
+    r2f_ctx::RenderGraph key;
+    key.in = in, key.in_layout = in_layout, key.out_f32 = out_f32, key.out_u8 = out_u8, key.H = H, key.W = W, key.workspace = workspace;
+    key.p = *p;
+    key.p.seed = 0;
+    key.p.flags &= ~(uint32_t)R2F_F_FRAME_RESIDENT;
+    auto same_structure = [](const r2f_ctx::RenderGraph& a, const r2f_ctx::RenderGraph& b) {
+        return a.in_layout == b.in_layout && a.H == b.H && a.W == b.W && !memcmp(&a.p, &b.p, sizeof a.p);
+    };
+    auto same_entry = [&](const r2f_ctx::RenderGraph& a, const r2f_ctx::RenderGraph& b) {
+        return a.in == b.in && a.out_f32 == b.out_f32 && a.out_u8 == b.out_u8 && a.workspace == b.workspace && same_structure(a, b);
+    };
+    int slot = -1;
+    for (size_t i = 0; i < ctx->graphs.size(); ++i)
+        if (same_entry(ctx->graphs[i], key)) slot = (int)i;
+    auto eager = [&]() -> int {
+        ++ctx->stat_eager;
+        const uint64_t g0 = ctx->generation;
+        const int rc = render_launches(ctx, p, in, in_layout, out_f32, out_u8, H, W, workspace, stream);
+        if (ctx->generation != g0) {  // this frame built something (a lazy table, a larger scratch): every captured pointer may dangle
+            drop_render_graphs(ctx);
+            ctx->graphs_generation = ctx->generation;
+        }
+        if (rc == R2F_OK) ctx->warm = key, ctx->warm_valid = true;
+        return rc;
+    };
+    if (slot >= 0 && ctx->graphs[slot].exec) {
+        r2f_ctx::RenderGraph& g = ctx->graphs[slot];
+        g.last_use = ++ctx->graph_clock;
+        if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // (a caller that wrote the frame block itself says so with the flag)
+            int rc = write_frame_params(ctx, p, s);
+            if (rc) return rc;
+        }
+        R2F_HIP(ctx, hipGraphLaunch(g.exec, s));
+        ++ctx->stat_replays;
+        return R2F_OK;
+    }
+    // Not captured yet.  The first frame of a structure runs kernel by kernel (uploads and allocations synchronise and cannot be
+    // captured); once the context has rendered this structure at this generation, an entry is captured on first sight.
+    if ((slot >= 0 && ctx->graphs[slot].never) || !ctx->warm_valid || !same_structure(ctx->warm, key)) return eager();
+    if (!ctx->cap_stream) R2F_HIP(ctx, hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+    if (slot < 0) {
+        if (ctx->graphs.size() >= 8) {  // callers that hand in fresh buffers every frame: bounded bookkeeping, least recently used out
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->graphs.size(); ++i)
+                if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+            if (ctx->graphs[lru].exec) {
+                // a replay of it may still be running: its executable graph must outlive that
+                R2F_HIP(ctx, hipDeviceSynchronize());
+                (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
+                ++ctx->stat_dropped;
+            }
+            if (ctx->graphs[lru].graph) (void)hipGraphDestroy(ctx->graphs[lru].graph);
+            ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+        }
+        ctx->graphs.push_back(key);
+        slot = (int)ctx->graphs.size() - 1;
+    }
+    const uint64_t gen0 = ctx->generation;
+    r2f_params q = *p;
+    q.flags |= R2F_F_FRAME_RESIDENT;  // the seed write stays outside the graph
+    hipGraph_t graph = nullptr;
+    // thread-local mode: other threads of the process (RCCL's watchdog, a producer thread) may keep calling into HIP meanwhile
+    hipError_t e = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal);
+    int rc = R2F_OK;
+    if (e == hipSuccess) {
+        rc = render_launches(ctx, &q, in, in_layout, out_f32, out_u8, H, W, workspace, ctx->cap_stream);
+        e = hipStreamEndCapture(ctx->cap_stream, &graph);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (e == hipSuccess && rc == R2F_OK && graph && ctx->generation == gen0) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess || rc != R2F_OK || !exec || ctx->generation != gen0) {
+        // a failed capture must not cost the frame: clear the sticky error, remember not to try again, launch kernel by kernel
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        ++ctx->stat_dropped;
+        if (ctx->generation != gen0) {
+            drop_render_graphs(ctx);
+            ctx->graphs_generation = ctx->generation;
+        } else {
+            ctx->graphs[slot].never = true;
+        }
+        return eager();
+    }
+    r2f_ctx::RenderGraph& g = ctx->graphs[slot];
+    g.graph = graph;
+    g.exec = exec;
+    g.last_use = ++ctx->graph_clock;
+    ++ctx->stat_captures;
+    if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
+        rc = write_frame_params(ctx, p, s);
+        if (rc) return rc;
+    }
+    R2F_HIP(ctx, hipGraphLaunch(g.exec, s));
+    ++ctx->stat_replays;
+    return R2F_OK;
+}
+
+int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4) {
+    if (!ctx || !out4) return R2F_EINVAL;
+    out4[0] = ctx->stat_replays, out4[1] = ctx->stat_captures, out4[2] = ctx->stat_eager, out4[3] = ctx->stat_dropped;
+    return R2F_OK;
+}
+
+int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream) {
+    if (!ctx || !p) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    return write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -74,6 +74,15 @@ struct DevPlanes {
     int rows;
 };
 
+// What changes from one render of a session to the next without changing which kernels run: kept in a small device-resident
+// block owned by the context and read through a pointer (wave-uniform scalar loads), so that a captured HIP graph of a
+// frame's launches can be replayed with new values.  The reference keeps the same data in a uniform buffer it rewrites per
+// render (gpu_processor.py:585-597 `buffer_params_grain`, read at noise.wgsl:1-6).
+struct FrameParams {
+    uint32_t seed;  // grain seed of this render
+    uint32_t reserved[3];
+};
+
 // ---------------------------------------------------------------------------- streaming accesses
 // Non-temporal 16-byte accesses for frame-sized buffers that are written once and read back a stage later (1.2 GB per plane set
 // at 100 MP, far beyond the 256 MB Infinity Cache).  On MI355X a float4 copy runs 6.57 TB/s that way against 6.23 with plain loads

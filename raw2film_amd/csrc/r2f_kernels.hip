@@ -465,6 +465,7 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
     const int plane_sz = rows * RS + 16;  // + slack: the prefetch of the dummy entry reads past the last row
     const int cols_valid = TW + g0.kw - 1;
     const bool mono = a.mono != 0;
+    const uint32_t seed = a.frame->seed;  // wave-uniform: one scalar load
     // The lane's own density samples (2 rows x 4 pixels x 3 planes) are requested NOW: the kernel's only reads from HBM then
     // travel while the noise is hashed and filtered, instead of starting after it (by ablation the 0.44 ms of memory time
     // used to add to the 0.7 ms of compute; neither the compiler nor the hardware moves a load across the barriers below).
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
         float nr, ng, nb;
         const int sx = clampi(tile_x0 - g0.ax + c, 0, a.W - 1);
         const int sy = clampi(tile_y0 - g0.ay + r, 0, a.H_global - 1);
-        gaussian_noise((uint32_t)sx, (uint32_t)sy, a.seed, mono, nr, ng, nb);
+        gaussian_noise((uint32_t)sx, (uint32_t)sy, seed, mono, nr, ng, nb);
         const int at = r * RS + c;
         smem[at] = nr;
         if (!mono) {
@@ -997,8 +998,9 @@ __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     const long long rows = a.y1 - a.y0;
     const long long plane = rows * a.W;
     const long long o = (long long)(gy - a.y0) * a.W + x;
+    const uint32_t seed = a.frame->seed;
     if (a.hash) {
-        uint32_t vx = (uint32_t)x, vy = (uint32_t)gy, vz = a.seed;
+        uint32_t vx = (uint32_t)x, vy = (uint32_t)gy, vz = seed;
         pcg3d(vx, vy, vz);
         a.hash[o] = vx;
         a.hash[plane + o] = vy;
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(256) void noise_kernel(const NoiseArgs a) {
     }
     if (a.noise) {
         float nr, ng, nb;
-        gaussian_noise((uint32_t)x, (uint32_t)gy, a.seed, a.mono != 0, nr, ng, nb);
+        gaussian_noise((uint32_t)x, (uint32_t)gy, seed, a.mono != 0, nr, ng, nb);
         a.noise[o] = nr;
         a.noise[plane + o] = ng;
         a.noise[2 * plane + o] = nb;
@@ -1306,6 +1308,13 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     dim3 block(256), grid((a.W + 255) / 256, a.y1 - a.y0);
     hipLaunchKernelGGL(noise_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void frame_params_kernel(FrameParams* dst, const FrameParams v) { *dst = v; }
+
+hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, hipStream_t s) {
+    hipLaunchKernelGGL(frame_params_kernel, dim3(1), dim3(1), 0, s, dst, v);
     return hipGetLastError();
 }
 

@@ -571,11 +571,13 @@ class HipProcessor:
                                             ctx=self.ctx)
 
     def process_array(self, image, negative_film, grain_size=6, grain_sigma=0.4, *, colorspace="XYZ", seed=None,
-                      return_float=False, output="host", **settings):
+                      return_float=False, output="host", out=None, **settings):
         """Render a decoded frame given as an array / CUDA tensor (synthetic benchmark frames).
 
         colorspace: "XYZ" (S0 skipped) or "linear-rec709" (S0 = data.py:128-135).
         return_float: float32 display-referred (H, W, 3) instead of uint8.  output: "host" | "device".
+        out: a device tensor (H, W, 3) of the result's dtype to render into (a stream of frames then keeps its buffers, and
+        r2f_render its captured graph).
         """
         torch = self._torch
         if colorspace not in ("XYZ", "linear-rec709"):
@@ -583,9 +585,15 @@ class HipProcessor:
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
         image = image.to(self.device).contiguous()
+        if out is not None:
+            _, H, W = self.ctx.layout_of(image, settings.get("layout"))
+            want = torch.float32 if return_float else torch.uint8
+            if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == want and tuple(out.shape) == (H, W, 3) and out.is_contiguous()):
+                raise ValueError(f"out must be a contiguous {want} CUDA tensor of shape {(H, W, 3)}")
         f32, u8 = self._execute_pipeline(
             image, negative_film, grain_size, grain_sigma, want_f32=return_float, want_u8=not return_float,
-            matrix=REC709_TO_XYZ if colorspace == "linear-rec709" else None, seed=seed, **settings,
+            matrix=REC709_TO_XYZ if colorspace == "linear-rec709" else None, seed=seed,
+            out_f32=out if return_float else None, out_u8=None if return_float else out, **settings,
         )
         out = f32 if return_float else u8
         return out if output == "device" else out.cpu().numpy()
@@ -634,7 +642,10 @@ class HipProcessor:
                                     log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE, **burn_kw)
 
     def _execute_pipeline(self, image, negative_film, grain_size, grain_sigma, want_f32=False, want_u8=True, layout=None,
-                          **settings):
+                          out_f32=None, out_u8=None, **settings):
+        """Tables (re-uploaded only when their parameters changed) + ONE r2f_render: the frame's launches are captured into a
+        HIP graph the second time the same buffers come by and replayed from then on -- the counterpart of the reference's
+        single command encoder and submit (gpu_processor.py:1760, 1877); the per-render seed travels in a device-side block."""
         _, H, W = self.ctx.layout_of(image, layout)
         params = self.prepare(negative_film, grain_size, grain_sigma, (W, H), **settings)
-        return self.ctx.render(image, params, want_f32=want_f32, want_u8=want_u8, layout=layout)
+        return self.ctx.render(image, params, out_f32=out_f32, out_u8=out_u8, want_f32=want_f32, want_u8=want_u8, layout=layout)

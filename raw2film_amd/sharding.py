@@ -77,6 +77,26 @@ class HipStageBackend:
     def empty(self, rows, W):
         return self.torch.empty((3, rows, W), dtype=self.torch.float32, device=self.device)
 
+    def begin_frame(self, seed=None):
+        """Ahead of a frame's stage calls: the grain seed (a new one when given) goes to the context's device-side frame block
+        (r2f_write_frame_params) and the stage calls are told to read it there (F_FRAME_RESIDENT) -- so a captured graph of
+        those calls does not freeze the seed (the reference makes a new seed per render, gpu_processor.py:585-597)."""
+        from . import _lib
+
+        if seed is not None:
+            self.params.seed = int(seed) & 0xFFFFFFFF
+        self.params.flags |= _lib.F_FRAME_RESIDENT
+        self.ctx.write_frame_params(self.params)
+
+    def graph_key(self) -> bytes:
+        """The parameter block as a captured graph sees it: everything but the seed."""
+        from . import _lib
+
+        p = _lib.Params.from_buffer_copy(self.params)
+        p.seed = 0
+        p.flags |= _lib.F_FRAME_RESIDENT
+        return bytes(p)
+
     def front(self, image_rows, in_gy0, upto, dst, dst_gy0, y0, y1, H):
         self.ctx.stage_front(image_rows, self.params, upto, in_gy0=in_gy0, dst=dst, dst_gy0=dst_gy0, y0=y0, y1=y1, H_global=H)
 
@@ -251,9 +271,12 @@ class RowShardedRenderer:
         return self.dist.get_global_rank(self.group, group_rank)
 
     # ------------------------------------------------------------------ one frame
-    def render(self, image_rows, out_f32=None, out_u8=None):
+    def render(self, image_rows, out_f32=None, out_u8=None, seed=None):
         """image_rows: this rank's own rows of the decoded frame ((rows, W, 3|4) or (3, rows, W)).
-        out_*: this rank's own rows of the result, (rows, W, 3)."""
+        out_*: this rank's own rows of the result, (rows, W, 3).  seed: the grain seed of this frame (every rank the same);
+        None keeps the backend's.  A new seed does not cost a captured graph: it lives in a device-side block."""
+        if hasattr(self.backend, "begin_frame"):
+            self.backend.begin_frame(seed)
         if not self.graph:
             return self._render_eager(image_rows, out_f32, out_u8)
         torch, p = self.torch, self.plan
@@ -275,7 +298,12 @@ class RowShardedRenderer:
         slot[0] += 1
         if slot[0] == 1:  # first frame with these buffers: eager (tables, scratch and spectra get built here)
             res = self._render_eager(image_rows, out_f32, out_u8)
-            self._graphs_state = self._graph_state()  # what that frame built lazily is the state the next one is captured from
+            new_state = self._graph_state()  # what that frame built lazily is the state the next one is captured from
+            if new_state != state:
+                # the eager frame moved the context (a lazy table upload, a re-allocated scratch): graphs captured for OTHER
+                # buffer keys froze the old pointers -- drop them, keep only this key's counter
+                self._graphs = {key: slot}
+            self._graphs_state = new_state
             return res
         if not whole:
             self._front_and_exchange(image_rows)
@@ -314,6 +342,8 @@ class RowShardedRenderer:
         ctx, params = getattr(be, "ctx", None), getattr(be, "params", None)
         if ctx is None or not hasattr(ctx, "generation"):
             return None
+        if hasattr(be, "graph_key"):  # the seed is not part of it: it lives in the device-side frame block
+            return (ctx.generation(), be.graph_key())
         return (ctx.generation(), bytes(params) if params is not None else b"")
 
     def reset_graphs(self):

@@ -1,0 +1,148 @@
+"""One submit per frame on the product surface: r2f_render captures a frame's launches into a HIP graph
+and replays it; the grain seed lives in a device-side block (the reference's uniform buffer, gpu_processor.py:585-597), so a new
+seed per render -- the reference's semantics and HipProcessor.prepare()'s default -- does not cost the graph.  Everything here
+goes through HipProcessor / HipContext.render, i.e. the C ABI."""
+
+import numpy as np
+import pytest
+
+from helpers import SEED, stocks, synthetic_frame
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _settings(H, W, fw):
+    neg, prt, _ = stocks()
+    return neg, dict(print_film=prt, frame_width=fw, frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000,
+                     color_masking=1.0)
+
+
+@pytest.mark.parametrize("shape,fw", [((192, 288), 36.0 * 288 / 6000.0),   # FFT halation + unrolled MTF, like a 24 MP frame
+                                       ((160, 256), 36.0 * 256 / 12288.0)])  # both stencils by FFT (100 MP pixel pitch)
+def test_four_frames_four_seeds_replay_and_equal_eager_launches(shape, fw):
+    from raw2film_amd import HipProcessor
+
+    H, W = shape
+    neg, kw = _settings(H, W, fw)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=5)).cuda()
+    seeds = [SEED, 1, 0xFFFFFFFF, 123456789]
+
+    eager = HipProcessor(device=0)
+    eager.ctx.set_option("render_graph", 0)
+    want = [eager.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=s, return_float=True, output="device", **kw).clone()
+            for s in seeds]
+    assert eager.ctx.render_stats()["replays"] == 0 and eager.ctx.render_stats()["eager"] == len(seeds)
+    eager.close()
+    assert not torch.equal(want[0], want[1])  # the seeds do reach the grain
+
+    proc = HipProcessor(device=0)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    got = []
+    for s in seeds:  # the same buffers every frame: eager, capture + replay, replay, replay
+        params = proc.prepare(neg, 6, 0.4, (W, H), seed=s, matrix=_rec709(), **kw)
+        proc.ctx.render(frame, params, out_f32=out)
+        got.append(out.clone())
+    stats = proc.ctx.render_stats()
+    assert stats["eager"] == 1 and stats["captures"] == 1 and stats["replays"] == 3, stats
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+    # the operator surface itself (fresh output tensors per call: the caching allocator hands the same block back)
+    before = proc.ctx.render_stats()["replays"]
+    for s, w in zip(seeds, want):
+        o = proc.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=s, return_float=True, output="device", **kw)
+        assert torch.equal(o, w)
+        del o
+    assert proc.ctx.render_stats()["replays"] > before
+    proc.close()
+
+
+def _rec709():
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+
+    return REC709_TO_XYZ
+
+
+def test_process_replays_with_a_random_seed_per_render_and_uint8_output():
+    """HipProcessor.process(): device-resident frame (load_image_texture), seed=None -> a new random seed per render like
+    upstream; from the third render on the frame is one graph launch."""
+    from raw2film_amd import HipProcessor
+
+    H, W = 128, 192
+    neg, kw = _settings(H, W, 0.8)
+    img = synthetic_frame(H, W, seed=9)
+    proc = HipProcessor(device=0)
+    outs = [proc.process(img, neg, 6, 0.4, **kw) for _ in range(6)]
+    stats = proc.ctx.render_stats()
+    assert stats["replays"] >= 3, stats
+    assert all(o.dtype == np.uint8 and o.shape == (H, W, 3) for o in outs)
+    assert any(not np.array_equal(outs[0], o) for o in outs[1:])  # different seeds, different grain
+    # a fixed seed reproduces the eager render bit for bit, replayed or not
+    a = proc.process(img, neg, 6, 0.4, seed=77, **kw)
+    proc.ctx.set_option("render_graph", 0)
+    b = proc.process(img, neg, 6, 0.4, seed=77, **kw)
+    np.testing.assert_array_equal(a, b)
+    proc.close()
+
+
+def test_table_changes_and_new_shapes_drop_the_graphs():
+    from raw2film_amd import HipProcessor
+
+    H, W = 160, 224
+    neg, kw = _settings(H, W, 0.7)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=11)).cuda()
+    proc = HipProcessor(device=0)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+
+    def render(**over):
+        params = proc.prepare(neg, 6, 0.4, (W, H), seed=3, matrix=_rec709(), **dict(kw, **over))
+        proc.ctx.render(frame, params, out_f32=out)
+        return out.clone()
+
+    base = [render() for _ in range(3)]
+    assert proc.ctx.render_stats()["replays"] == 2
+    assert torch.equal(base[0], base[1]) and torch.equal(base[0], base[2])
+    warm = render(exp_kelvin=5000)          # a new input LUT: generation moves, graphs dropped, this frame eager
+    s = proc.ctx.render_stats()
+    assert s["dropped"] >= 1 and s["eager"] == 2
+    assert not torch.equal(warm, base[0])
+    again = [render(exp_kelvin=5000) for _ in range(2)]
+    assert torch.equal(again[0], warm) and torch.equal(again[1], warm)
+    assert proc.ctx.render_stats()["replays"] == 4
+    # a different stage set is a different structure: never served by the other structure's graph
+    plain = render(exp_kelvin=5000, halation=False)
+    ref = HipProcessor(device=0)
+    ref.ctx.set_option("render_graph", 0)
+    p2 = ref.prepare(neg, 6, 0.4, (W, H), seed=3, matrix=_rec709(), **dict(kw, exp_kelvin=5000, halation=False))
+    want, _ = ref.ctx.render(frame, p2)
+    assert torch.equal(plain, want)
+    ref.close()
+    proc.close()
+
+
+def test_stage_calls_write_their_own_seed_unless_told_the_block_is_resident():
+    """r2f_stage_tail honours p->seed (it writes the frame block first); with F_FRAME_RESIDENT it reads what
+    r2f_write_frame_params wrote."""
+    from raw2film_amd import HipProcessor, _lib
+
+    H, W = 96, 128
+    neg, kw = _settings(H, W, 0.5)
+    proc = HipProcessor(device=0)
+    ctx = proc.ctx
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=5, **kw)
+    D = torch.rand((3, H, W), device="cuda") * 2.0
+    o1 = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    o2 = torch.empty_like(o1)
+    o3 = torch.empty_like(o1)
+    ctx.stage_tail(D, params, out_f32=o1, y0=0, y1=H, H_global=H)
+    p9 = _lib.Params.from_buffer_copy(params)
+    p9.seed = 9
+    ctx.stage_tail(D, p9, out_f32=o2, y0=0, y1=H, H_global=H)
+    assert not torch.equal(o1, o2)
+    resident = _lib.Params.from_buffer_copy(params)  # seed 5 in the struct, but the block says 9
+    resident.flags |= _lib.F_FRAME_RESIDENT
+    ctx.write_frame_params(p9)
+    ctx.stage_tail(D, resident, out_f32=o3, y0=0, y1=H, H_global=H)
+    assert torch.equal(o3, o2)
+    proc.close()
