@@ -92,11 +92,6 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
-    // 256-row windows in STRIP mode (r2f_fft.hip): pass 1 transforms every row of a strip of x-pairs once instead of once per
-    // window row (vertically adjacent windows share ny - vy of their 256 rows: 84 for the 85-tap halation box, a third of pass 1's
-    // work and bytes), the rows live in a ring per column that pass 2 updates in place.  0 = the windowed form everywhere (A/B).
-    int opt_fft_strip = 1;
-    int opt_fft_p2_lds_kb = 0;  // tuning aid: LDS per pass-2 workgroup in strip mode (caps the resident workgroups per CU)
     // Tap boxes up to this many taps a side take the on-chip form (r2f_fft2d.hip: 128 x 128 windows held in registers, no scratch
     // image) instead of the three passes; 0 = never (the default: it moves a third of the bytes but is the slower one, 2.65 against
     // 1.68 ms for the 35-tap MTF at 100 MP -- one workgroup per CU serialises its load, spectrum and store phases).
@@ -667,7 +662,7 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
 // the GLOBAL frame, so every row shard of a frame (and every call on it) uses the same shape and the kernel spectra are
 // built once.  stencil_fft_window / stencil_fft_window_rows force an axis (ignored for a box over 200 taps on that axis,
 // which needs the 512-point window).
-bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, bool strip, int* ny, int* nx) {
+bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int* ny, int* nx) {
     double best = -1.0;
     // a box wider than 200 columns needs 512 columns at least, whatever stencil_fft_window_max says (with the accepted
     // value 256 every candidate used to be rejected and the caller's 256 x 256 default went on to a division by zero)
@@ -684,9 +679,7 @@ bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, bool
             // two windows share one complex image.  The 512-row pass 2 moves its bytes ~1.3 x slower (r2f_fft.hip).
             const double p2 = y == 512 ? 1.3 : 1.0;
             const double e = s32 ? 4.0 : 8.0;  // scratch bytes per window element (half a complex64 / complex128)
-            // strip mode (256-row windows): pass 1 transforms and writes every row once, not once per window row
-            const double p1 = (strip && y == 256) ? (double)vy / y : 1.0;
-            const double bytes = p1 * (4.0 * n + e * n) + p2 * (e * n + e * part) + e * part + 4.0 * vy * vx;
+            const double bytes = 4.0 * n + e * n + p2 * (e * n + e * part) + e * part + 4.0 * vy * vx;
             const double cost = (double)((W + vx - 1) / vx) * ((H + vy - 1) / vy) * bytes;
             if (best < 0.0 || cost < best) best = cost, *ny = y, *nx = x;
         }
@@ -776,8 +769,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     if (std::max(bh, bw) <= ctx->opt_fft_onchip_max && !ctx->opt_fft_window && !ctx->opt_fft_window_rows)
         return run_stencil_fft_onchip(ctx, which, chans, nch, b, src, dst, y0, y1, W, H, epilogue, log_eps, s);
     int ny = 256, nx = 256;
-    const bool strip_able = ctx->opt_fft_strip && !((ctx->opt_fft_s96 >> which) & 1);
-    if (!fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, strip_able, &ny, &nx))
+    if (!fft_window(ctx, bh, bw, W, H, (ctx->opt_fft_s32 >> which) & 1, &ny, &nx))
         return fail(ctx, R2F_EINVAL, "stencil %d: no FFT window shape fits a %d x %d tap box under the current stencil_fft_window* options",
                     which, bh, bw);
     const size_t img = (size_t)ny * nx;
@@ -849,98 +841,6 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.s32 = ((ctx->opt_fft_s96 >> which) & 1) ? 2 : ((ctx->opt_fft_s32 >> which) & 1);
     const size_t img_bytes = img * (a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));
     const int pairs = a.ppc * nch;
-    const int gyw = (y1 - y0 + a.vy - 1) / a.vy, gxp = (a.gx + 1) / 2;  // window rows; x-pairs per window row
-    if (strip_able && ny == 256 && gyw >= 2) {
-        // ---- strip mode: the x-pairs are split into one strip per internal stream; a strip walks down its window rows in steps
-        // of n, keeping per column (channel, x-pair) a ring of n vy + (ny - vy) rows of row spectra: pass 1 adds the step's new rows,
-        // pass 2 turns each window row's 256 rows into its vy valid rows in place, pass 3 reads those.  Everything a strip touches
-        // stays on its own stream, in order, so the ring needs no fences; the rings of all strips together are sized to the
-        // Infinity Cache budget (opt_fft_batch MiB) like the windowed form's batches.
-        const size_t row_bytes = (size_t)nx * (a.s32 == 1 ? 8 : 16);
-        const size_t budget = (size_t)ctx->opt_fft_batch << 20;
-        const size_t all_pairs_bytes = (size_t)gxp * nch * gyw * a.vy * row_bytes;
-        int ns = (all_pairs_bytes > budget && gxp >= 2) ? std::min(ctx->opt_fft_streams, gxp) : 1;
-        struct Strip {
-            int xp0, nxp, n, steps, ring_rows;
-            size_t off;
-        } strips[4];
-        size_t total = 0;
-        for (int i = 0; i < ns; ++i) {
-            Strip& t = strips[i];
-            t.xp0 = (int)((long long)gxp * i / ns);
-            t.nxp = (int)((long long)gxp * (i + 1) / ns) - t.xp0;
-            const long long rows_fit = (long long)(budget / ns / ((size_t)t.nxp * nch * row_bytes));
-            int n = (int)std::max<long long>(1, (rows_fit - (ny - a.vy) - 16) / a.vy);
-            n = std::min(n, gyw);
-            t.steps = (gyw + n - 1) / n;
-            t.n = (gyw + t.steps - 1) / t.steps;  // equal steps
-            t.ring_rows = (t.n * a.vy + (ny - a.vy) + 15) / 16 * 16 + 16;  // + slack for pass 1's rounded-up grid
-            t.off = total;
-            total += (size_t)t.nxp * nch * t.ring_rows * row_bytes;
-        }
-        rc = ensure_bytes(ctx, ctx->fft_s1, total);
-        if (rc) return rc;
-        hipStream_t lanes[4] = {s, s, s, s};
-        if (ns > 1) {
-            for (int i = 0; i < ns; ++i) {
-                if (!ctx->fft_stream[i]) R2F_HIP(ctx, hipStreamCreateWithFlags(&ctx->fft_stream[i], hipStreamNonBlocking));
-                if (!ctx->fft_ev_out[i]) R2F_HIP(ctx, hipEventCreateWithFlags(&ctx->fft_ev_out[i], hipEventDisableTiming));
-                lanes[i] = ctx->fft_stream[i];
-            }
-            if (!ctx->fft_ev_in) R2F_HIP(ctx, hipEventCreateWithFlags(&ctx->fft_ev_in, hipEventDisableTiming));
-            R2F_HIP(ctx, hipEventRecord(ctx->fft_ev_in, s));  // everything queued on the caller's stream so far (src, spectra)
-            for (int i = 0; i < ns; ++i) R2F_HIP(ctx, hipStreamWaitEvent(lanes[i], ctx->fft_ev_in, 0));
-        }
-        auto timed_launch = [&](int cls, double bytes, hipStream_t st, auto&& launch) -> int {
-            if (!(ctx->opt_timing & (1 << cls))) {
-                R2F_HIP(ctx, launch());
-                return R2F_OK;
-            }
-            hipEvent_t e0, e1;
-            R2F_HIP(ctx, hipEventCreate(&e0));
-            R2F_HIP(ctx, hipEventCreate(&e1));
-            R2F_HIP(ctx, hipEventRecord(e0, st));
-            R2F_HIP(ctx, launch());
-            R2F_HIP(ctx, hipEventRecord(e1, st));
-            ctx->timing_ev[cls + 3 * (a.s32 == 1)].push_back({e0, e1});
-            ctx->timing_bytes[cls + 3 * (a.s32 == 1)] += bytes;
-            return R2F_OK;
-        };
-        a.strip = 1;
-        a.p2_lds_kb = ctx->opt_fft_p2_lds_kb;
-        int max_steps = 0;
-        for (int i = 0; i < ns; ++i) max_steps = std::max(max_steps, strips[i].steps);
-        for (int step = 0; step < max_steps; ++step)
-            for (int i = 0; i < ns; ++i) {
-                const Strip& t = strips[i];
-                if (step >= t.steps) continue;
-                hipStream_t st = lanes[i];
-                a.s1 = reinterpret_cast<double2*>(static_cast<char*>(ctx->fft_s1.p) + t.off);
-                a.ring_rows = t.ring_rows;
-                a.xp0 = t.xp0, a.nxp = t.nxp;
-                a.ty0 = step * t.n;
-                a.nty = std::min(t.n, gyw - a.ty0);
-                if (a.nty <= 0) continue;
-                a.rr0 = step == 0 ? 0 : a.ty0 * a.vy + (ny - a.vy);
-                a.rr1 = (a.ty0 + a.nty - 1) * a.vy + ny;
-                const double cols = (double)t.nxp * nch, rb = (double)row_bytes;
-                // algorithmic bytes: window floats in (2 windows per row) + row spectra out; 256 rows in + valid rows back per
-                // window row; valid rows in + valid outputs out
-                rc = timed_launch(0, cols * (a.rr1 - a.rr0) * (2.0 * nx * sizeof(float) + rb), st, [&] { return launch_fft_rows_fwd(a, st); });
-                if (rc) return rc;
-                rc = timed_launch(1, cols * a.nty * (double)(ny + a.vy) * rb, st, [&] { return launch_fft_cols(a, 0, st); });
-                if (rc) return rc;
-                rc = timed_launch(2, cols * a.nty * ((double)a.vy * rb + 2.0 * a.vy * a.vx * sizeof(float)), st,
-                                  [&] { return launch_fft_rows_inv(a, st); });
-                if (rc) return rc;
-            }
-        if (ns > 1)
-            for (int i = 0; i < ns; ++i) {
-                R2F_HIP(ctx, hipEventRecord(ctx->fft_ev_out[i], lanes[i]));
-                R2F_HIP(ctx, hipStreamWaitEvent(s, ctx->fft_ev_out[i], 0));
-            }
-        return R2F_OK;
-    }
     // batches alternate between two internal streams when there is enough work for that to matter
     // opt_fft_batch counts MiB of scratch in flight (a 256 x 256 complex128 pair is 1 MiB)
     const int fft_batch = std::max(1, (int)((size_t)ctx->opt_fft_batch * kFftN * kFftN * sizeof(double2) / img_bytes));
@@ -1271,15 +1171,6 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
-        return R2F_OK;
-    }
-    if (!strcmp(name, "stencil_fft_p2_lds_kb")) {
-        if (value < 0 || value > 64) return fail(ctx, R2F_EINVAL, "stencil_fft_p2_lds_kb must be in [0, 64]");
-        ctx->opt_fft_p2_lds_kb = value;
-        return R2F_OK;
-    }
-    if (!strcmp(name, "stencil_fft_strip")) {
-        ctx->opt_fft_strip = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_scratch96")) {

@@ -27,8 +27,6 @@
 // the row passes absorb in their addressing; the column pass of 512-row windows comes back through fft512_rev, the
 // transposed flow graph.  The host picks the window shape that moves the fewest scratch bytes for the stencil and the
 // frame (an 87-tap disc keeps 66 % of a 256-wide window's columns but 83 % of a 512-wide one's); cfg 4: 256 x 512.
-#include <algorithm>
-
 #include "r2f_launch.h"
 #include "r2f_fft_math.h"
 
@@ -390,66 +388,6 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
     fft_rows_fwd_body<XL, ST>(a, fsm);
 }
 
-// Strip mode (FftConvArgs::strip): each row of a strip is transformed ONCE -- vertically adjacent 256-row windows share
-// ny - vy of their rows (84 of 256 for the 85-tap halation box), which the windowed form above transforms and writes once per
-// window.  grid (rows of the launch / rows per workgroup, columns of the strip).
-template <int XL, int ST>
-__device__ __forceinline__ void fft_rows_fwd_strip_body(const FftConvArgs& a, double* fsm) {
-    typedef RowGeom<XL> G;
-    constexpr int NX = G::NX, LPL = G::LPL;
-    const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
-    const int col = blockIdx.y, ci = col / a.nxp, j = a.xp0 + (col - ci * a.nxp);
-    // (the grid is rounded up to whole workgroups: up to 15 rows past rr1 are transformed too and land in the ring's slack rows,
-    // where the next launch overwrites them before any window reads them)
-    const int local = blockIdx.x * G::ROWS + threadIdx.x / LPL, rr = a.rr0 + local;
-    const float* src = a.src.data + (long long)a.chan[ci] * a.src.plane_stride;
-    const int wxA = 2 * j * a.vx - a.ax, wxB = wxA + a.vx;
-    const bool hasB = 2 * j + 1 < a.gx;
-    const int sy = reflect101(a.y0 - a.ay + rr, a.H_global) - a.src.gy0;
-    const float* row = src + (long long)clampi(sy, 0, a.src.rows - 1) * a.W;  // rows outside the buffer only feed discarded outputs
-    const bool inA = wxA >= 0 && wxA + NX <= a.W, inB = wxB >= 0 && wxB + NX <= a.W;
-    const bool hasA = 2 * j < a.gx;  // always: kept as a run-time test so that the two windows' loads compile like the windowed
-                                     // form's (unconditional loads of window A had the allocator spill 6-8 registers per lane)
-    float fa[16], fb[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) fa[m] = fb[m] = 0.f;
-    if (hasA) {
-        if (inA) {
-            const float* pa = row + wxA + l;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) fa[m] = pa[LPL * m];
-        } else {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) fa[m] = row[reflect101(wxA + l + LPL * m, a.W)];
-        }
-    }
-    if (hasB) {
-        if (inB) {
-            const float* pb = row + wxB + l;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) fb[m] = pb[LPL * m];
-        } else {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) fb[m] = row[reflect101(wxB + l + LPL * m, a.W)];
-        }
-    }
-    cplx v[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2((double)fa[m], (double)fb[m]);
-    G::template fft<false>(v, a, l, wave_tbuf(fsm), lane);
-    char* s1 = simg<ST>(a.s1, col, (long long)a.ring_rows * NX);
-    int rq = a.rr0 % a.ring_rows + local;  // (wave-uniform modulo; a launch never covers more than ring_rows rows)
-    rq = rq >= a.ring_rows ? rq - a.ring_rows : rq;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) sst<ST>(s1, sidx(rq, G::out_col(l, q), G::NBX), v[q]);
-}
-
-template <int XL, int ST>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE1, 8))) void fft_rows_fwd_strip_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_fwd_strip_body<XL, ST>(a, fsm);
-}
-
 // ---------------------------------------------------------------------------------------------------- pass 2
 // grid (nx / 16, pairs): a workgroup transforms 16 neighbouring columns in place, a wave 4 of them.  NBX = nx / 16.
 // mode 0: forward along r, multiply by the kernel spectrum, inverse, store back
@@ -529,68 +467,48 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
         fft_cols_body<NBX, ST>(a, mode, fsm);
 }
 
-// Strip mode: grid (nx / 16, columns).  Window row ty of a column reads the ring rows [ty vy, ty vy + 256) and writes its vy
-// valid rows back over [ty vy, ty vy + vy).  The ny - vy rows behind those are window row ty + 1's first rows, so the window rows of
-// a step are NOT independent: ty + 1 may only overwrite rows once ty has loaded them.  A workgroup therefore walks down the step's
-// window rows itself, in order, for its 16 spectrum columns (every element it overwrites it has loaded before, in program order;
-// other workgroups own other columns).
-template <int NBX, int ST>
-__device__ __forceinline__ void fft_cols_strip_body(const FftConvArgs& a, double* fsm) {
-    const int lane = threadIdx.x & 63, l = lane & 15;
-    const int col = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
-    char* s1 = simg<ST>(a.s1, col, (long long)a.ring_rows * (NBX * 16));
-    const cplx w1 = a.tw[l];
-    double* tbuf = wave_tbuf(fsm);
-    const cplx* kf = a.kfs[col / a.nxp];
-    for (int w = 0; w < a.nty; ++w) {
-        const int rbase = ((a.ty0 + w) * a.vy) % a.ring_rows + l;  // ring_rows >= 256: one conditional subtraction per row below
-        cplx v[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            int r = rbase + 16 * m;
-            r = r >= a.ring_rows ? r - a.ring_rows : r;
-            v[m] = sld<ST>(s1, sidx(r, k, NBX));
-        }
-        fft256<false>(v, w1, tbuf, lane);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(l + 16 * q, k, NBX)));
-        fft256<true>(v, w1, tbuf, lane);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (l + 16 * q < a.vy) {
-                int r = rbase + 16 * q;
-                r = r >= a.ring_rows ? r - a.ring_rows : r;
-                sst<ST>(s1, sidx(r, k, NBX), v[q]);
-            }
-    }
-}
-
-template <int NBX, int ST>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_strip_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_strip_body<NBX, ST>(a, fsm);
-}
-
 // ---------------------------------------------------------------------------------------------------- pass 3
+// grid (ceil(vy / rows per workgroup), pairs); lanes and rows as in pass 1
+#ifndef R2F_FFT_EXP3
+#define R2F_FFT_EXP3 0  // development switch for pass 3: bit 0 no loads, bit 1 no stores, bit 2 no transform
+#endif
 #ifndef R2F_FFT_CURVE_BATCH
 // outputs of a lane whose curve cells are gathered together.  16 (all of them) keeps 64 VGPRs of cells live and holds the kernel
 // at 2 waves per SIMD; 4 fits 3 waves per SIMD without spills and is the faster one (halation 2.46 -> 2.43 ms at 100 MP)
 #define R2F_FFT_CURVE_BATCH 4
 #endif
-// The output half of pass 3 for one transformed line: scale, crop to the valid outputs inside the frame, [log + density curve],
-// store.  The line's real part belongs to window A (output row gyA, window origin column wxA), its imaginary part to window B.
-template <int XL, bool EPI>
-__device__ __forceinline__ void rows_inv_emit(const FftConvArgs& a, const cplx (&v)[16], const int ch, const bool hasA, const int gyA,
-                                              const int wxA, const bool hasB, const int gyB, const int wxB, double* fsm, const int lane,
-                                              const int l) {
+template <int XL, bool EPI, int ST>
+__device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
     typedef RowGeom<XL> G;
     constexpr int NX = G::NX, LPL = G::LPL;
+    const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
+    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
+    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
+    const char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
+    cplx v[16];
+    if (R2F_FFT_EXP3 & 1) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
+    }
+    if (!(R2F_FFT_EXP3 & 4)) {
+        G::template fft<true>(v, a, l, wave_tbuf(fsm), lane);
+    }
+    if (!live) return;
+    if (R2F_FFT_EXP3 & 2) {
+        if (v[3].x == 1.2345e300) a.dst.data[0] = (float)v[5].y;
+        return;
+    }
+    const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc, ch = a.chan[ci];
     float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
     const double scale = 1.0 / ((double)NX * a.ny);  // a power of two
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (!(half ? hasB : hasA)) continue;
-        const int gy = half ? gyB : gyA, wx = half ? wxB : wxA;
+        int wy, wx;
+        if (!window_of(a, 2 * pc + half, wy, wx)) continue;
+        const int gy = wy + a.ay + r;
         if (gy >= a.y1) continue;
         float* dbase = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax;
         // the 16 outputs of this lane first, then the curve on all of them at once (independent gathers), then the stores
@@ -632,41 +550,6 @@ __device__ __forceinline__ void rows_inv_emit(const FftConvArgs& a, const cplx (
     }
 }
 
-
-// grid (ceil(vy / rows per workgroup), pairs); lanes and rows as in pass 1
-#ifndef R2F_FFT_EXP3
-#define R2F_FFT_EXP3 0  // development switch for pass 3: bit 0 no loads, bit 1 no stores, bit 2 no transform
-#endif
-template <int XL, bool EPI, int ST>
-__device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
-    typedef RowGeom<XL> G;
-    constexpr int NX = G::NX, LPL = G::LPL;
-    const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
-    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
-    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
-    cplx v[16];
-    if (R2F_FFT_EXP3 & 1) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
-    } else {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
-    }
-    if (!(R2F_FFT_EXP3 & 4)) {
-        G::template fft<true>(v, a, l, wave_tbuf(fsm), lane);
-    }
-    if (!live) return;
-    if (R2F_FFT_EXP3 & 2) {
-        if (v[3].x == 1.2345e300) a.dst.data[0] = (float)v[5].y;
-        return;
-    }
-    const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc, ch = a.chan[ci];
-    int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
-    const bool hasA = window_of(a, 2 * pc, wyA, wxA), hasB = window_of(a, 2 * pc + 1, wyB, wxB);
-    rows_inv_emit<XL, EPI>(a, v, ch, hasA, wyA + a.ay + r, wxA, hasB, wyB + a.ay + r, wxB, fsm, lane, l);
-}
-
 #ifndef R2F_FFT_WPE3
 #define R2F_FFT_WPE3 3
 #endif
@@ -676,35 +559,6 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI
     fft_rows_inv_body<XL, EPI, ST>(a, fsm);
 }
 
-// Strip mode: grid (ceil(vy / rows per workgroup), nty x columns); the valid rows of window row ty sit in ring rows ty vy ...
-template <int XL, bool EPI, int ST>
-__device__ __forceinline__ void fft_rows_inv_strip_body(const FftConvArgs& a, double* fsm) {
-    typedef RowGeom<XL> G;
-    constexpr int NX = G::NX, LPL = G::LPL;
-    const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
-    const int ncols = a.nch * a.nxp;
-    const int w = blockIdx.y / ncols, col = blockIdx.y - w * ncols, ci = col / a.nxp, j = a.xp0 + (col - ci * a.nxp);
-    const int r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
-    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const char* s1 = simg<ST>(a.s1, col, (long long)a.ring_rows * NX);
-    const int ty = a.ty0 + w;
-    int rq = (ty * a.vy) % a.ring_rows + (live ? r : 0);  // (wave-uniform modulo; r < vy <= ring_rows)
-    rq = rq >= a.ring_rows ? rq - a.ring_rows : rq;
-    cplx v[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(rq, l + LPL * m, G::NBX));
-    G::template fft<true>(v, a, l, wave_tbuf(fsm), lane);
-    if (!live) return;
-    const int gy = a.y0 + ty * a.vy + r, wxA = 2 * j * a.vx - a.ax;
-    rows_inv_emit<XL, EPI>(a, v, a.chan[ci], true, gy, wxA, 2 * j + 1 < a.gx, gy, wxA + a.vx, fsm, lane, l);
-}
-
-template <int XL, bool EPI, int ST>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (XL ? 3 : 4), 8))) void fft_rows_inv_strip_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_inv_strip_body<XL, EPI, ST>(a, fsm);
-}
-
 // ---------------------------------------------------------------------------------------------------- launchers
 static size_t fft_lds_bytes() { return (size_t)(kFftThreads / 64) * 4 * kTLine * sizeof(double); }
 
@@ -712,15 +566,6 @@ hipError_t fft_init_attributes() { return hipSuccess; }
 
 template <int XL>
 static void launch_rows_fwd(const FftConvArgs& a, hipStream_t s) {
-    if (a.strip) {  // (complex128 or complex64 rings; the 12-byte element stays with the windowed form)
-        const int rows = RowGeom<XL>::ROWS;
-        const dim3 sgrid((a.rr1 - a.rr0 + rows - 1) / rows, a.nch * a.nxp);
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_rows_fwd_strip_kernel<XL, 1>), sgrid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((fft_rows_fwd_strip_kernel<XL, 0>), sgrid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        return;
-    }
     const dim3 block(kFftThreads), grid(a.ny / RowGeom<XL>::ROWS, a.npairs);
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 1>), grid, block, fft_lds_bytes(), s, a);
@@ -742,15 +587,6 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
 
 template <int NBX, bool Y512>
 static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    if (a.strip && !Y512) {
-        const dim3 sgrid(a.nx / 16, a.nch * a.nxp);
-        const size_t lds = std::max(fft_lds_bytes(), (size_t)a.p2_lds_kb * 1024);
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_cols_strip_kernel<NBX, 1>), sgrid, dim3(kFftThreads), lds, s, a);
-        else
-            hipLaunchKernelGGL((fft_cols_strip_kernel<NBX, 0>), sgrid, dim3(kFftThreads), lds, s, a);
-        return;
-    }
     const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1>), grid, block, fft_lds_bytes(), s, a, mode);
@@ -780,15 +616,6 @@ hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
 
 template <int XL, bool EPI>
 static void launch_rows_inv(const FftConvArgs& a, hipStream_t s) {
-    if (a.strip) {
-        const int srows = RowGeom<XL>::ROWS;
-        const dim3 sgrid((a.vy + srows - 1) / srows, a.nty * a.nch * a.nxp);
-        if (a.s32 == 1)
-            hipLaunchKernelGGL((fft_rows_inv_strip_kernel<XL, EPI, 1>), sgrid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((fft_rows_inv_strip_kernel<XL, EPI, 0>), sgrid, dim3(kFftThreads), fft_lds_bytes(), s, a);
-        return;
-    }
     const int rows = RowGeom<XL>::ROWS;
     const dim3 grid((a.vy + rows - 1) / rows, a.npairs);  // rows beyond the valid outputs are never stored
     if (a.s32 == 1)

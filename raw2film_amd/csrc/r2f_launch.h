@@ -191,20 +191,6 @@ struct FftConvArgs {
     DevCurve curve;
     float log_eps;
     int vec4;                 // 1: vx % 4 == 0, W % 4 == 0 and dst planes 16-byte aligned -> float4 stores in pass 3
-    // Strip mode (256-row windows): the row spectra are shared between the window rows of a strip.  A launch covers the
-    // `nch * nxp` COLUMNS of a strip -- column = ci * nxp + (j - xp0): channel chan[ci], x-pair j = windows 2 j and 2 j + 1 of every
-    // window row -- each with its own ring image of `ring_rows` rows x nx elements in s1 (scratch layout, rows taken modulo
-    // ring_rows).  Strip row rr holds the row transform of global input row y0 - ay + rr; window row ty reads rows
-    // [ty vy, ty vy + ny) and its vy valid rows are written back IN PLACE over [ty vy, ty vy + vy) (dead once loaded; the
-    // ny - vy rows behind them stay for window row ty + 1, so pass 2 walks a step's window rows in order inside a workgroup).
-    // Pass 1 transforms each strip row once: rows [rr0, rr1) per launch.
-    int strip;
-    int ring_rows;            // a multiple of 16, >= ny
-    int nxp, xp0;
-    int rr0, rr1;             // pass 1
-    int ty0, nty;             // passes 2 and 3: window rows [ty0, ty0 + nty) of this step
-    int p2_lds_kb;            // tuning aid: dynamic LDS requested per pass-2 workgroup (0 = what the transposes need); more LDS =
-                              // fewer resident workgroups per CU
 };
 hipError_t fft_init_attributes();
 // The same correlation with the whole window pair on chip (r2f_fft2d.hip): 128 x 128 windows, no scratch image; FftConvArgs with

@@ -218,8 +218,7 @@ def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
                 vy, vx = y - bh + 1, (x - bw + 1) & ~3
                 n = y * x
                 part, p2 = n * vy / y, (1.3 if y == 512 else 1.0)
-                p1 = vy / y if y == 256 else 1.0  # strip mode: 256-row windows transform every row once, not once per window row
-                cost = -(-W // vx) * -(-H // vy) * (p1 * (4.0 * n + 8.0 * n) + p2 * (8.0 * n + 8.0 * part) + 8.0 * part + 4.0 * vy * vx)
+                cost = -(-W // vx) * -(-H // vy) * (4.0 * n + 8.0 * n + p2 * (8.0 * n + 8.0 * part) + 8.0 * part + 4.0 * vy * vx)
                 if best is None or cost < best[0]:
                     best = (cost, (y, x))
         return best[1]
@@ -309,46 +308,3 @@ def test_twelve_byte_scratch_is_an_opt_in_for_the_halation(ctx):
         ctx.set_option("stencil_fft_scratch96", 0)
     assert_close(packed, ref, 2e-6, 1e-3, "12-byte scratch")
     assert not np.array_equal(packed, exact)
-
-
-@pytest.mark.parametrize("window", [(256, 256), (256, 512), (256, 1024)])
-@pytest.mark.parametrize("shape,batch", [((700, 900), 1), ((700, 900), 192), ((345, 1300), 2), ((1040, 300), 1), ((173, 344), 1)])
-def test_strip_mode_shares_row_spectra_between_window_rows(ctx, shape, window, batch):
-    """256-row windows in strip mode (pass 1 transforms every strip row once, rings per column, pass 2 in place walking down a
-    step's window rows): steps of one window row and two strips on two streams (a 1 MiB budget), everything in one step
-    (192 MiB), odd numbers of windows per row; against the oracle and against the windowed form (whose windows pair up
-    differently when a row holds an odd number: a few ulp of fp64, invisible after the rounding to fp32 except on rare ties)."""
-    force_window(ctx, window)
-    rng = np.random.default_rng(shape[0] + window[1])
-    img = rng.uniform(0.0, 2.0, shape + (3,)).astype(np.float32)
-    img[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = 500.0
-    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)  # 87 x 87 (85 x 85 non-zero), blue plane = identity
-    ref = st.convolve_2d(img, k)
-    a = run(ctx, 0, img, k, 1, stencil_fft_batch=batch, stencil_fft_strip=1)
-    assert [c["window"] for c in ctx.stencil_stats(0)] == [window, window, None]
-    assert_close(a, ref, 2e-6, 1e-3, "strip mode")
-    b = run(ctx, 0, img, k, 1, stencil_fft_batch=batch, stencil_fft_strip=0)
-    assert_close(b, ref, 2e-6, 1e-3, "windowed form")
-    assert np.max(np.abs(a - b) / np.maximum(np.abs(ref), 1e-3)) <= 5e-7
-    # a row range with halo rows (what a row shard calls), not aligned with the window rows of the whole frame
-    y0, y1 = shape[0] // 5, shape[0] - 3
-    part = run(ctx, 0, img, k, 1, rows=(y0, y1), stencil_fft_batch=batch, stencil_fft_strip=1)
-    assert np.max(np.abs(part - a[y0:y1]) / np.maximum(np.abs(ref[y0:y1]), 1e-3)) <= 1e-6
-    ctx.set_option("stencil_fft_batch", 192)
-
-
-def test_strip_mode_on_complex64_rings_with_arbitrary_taps(ctx):
-    """The MTF's scratch type (complex64 elements, fp64 butterflies) in strip mode, signed asymmetric taps, three channels."""
-    rng = np.random.default_rng(77)
-    H, W = 830, 1210
-    img = rng.uniform(0.0, 3.0, (H, W, 3)).astype(np.float32)
-    k = rng.uniform(-0.2, 1.0, (35, 31, 3)).astype(np.float32)
-    k /= k.sum(axis=(0, 1), keepdims=True)
-    ref = st.convolve_2d(img, k)
-    for batch in (1, 192):
-        a = run(ctx, 1, img, k, 1, stencil_fft_batch=batch, stencil_fft_strip=1)
-        assert uses_fft(ctx, 1) == [1, 1, 1] and all(c["window"][0] == 256 for c in ctx.stencil_stats(1))
-        assert_close(a, ref, 2e-6, 1e-3, f"strip mode, complex64 rings, {batch} MiB")
-    b = run(ctx, 1, img, k, 1, stencil_fft_strip=0)
-    assert np.max(np.abs(a - b) / np.maximum(np.abs(ref), 1e-3)) <= 1e-6
-    ctx.set_option("stencil_fft_batch", 192)
