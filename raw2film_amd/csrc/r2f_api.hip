@@ -92,10 +92,6 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
-    // 512-row windows: 1 = the column pass that moves full 128-byte lines (16 lanes per column, the 512 rows as two 256-point
-    // problems per lane group: fft_cols_y512s_kernel), 0 = the 32-lane fft512 form (half-used lines).  The two keep their kernel
-    // spectra in different row orders: switching rebuilds them.
-    int opt_fft_y512_split = 1;
     // Tap boxes up to this many taps a side take the on-chip form (r2f_fft2d.hip: 128 x 128 windows held in registers, no scratch
     // image) instead of the three passes; 0 = never (the default: it moves a third of the bytes but is the slower one, 2.65 against
     // 1.68 ms for the 35-tap MTF at 100 MP -- one workgroup per CU serialises its load, spectrum and store phases).
@@ -680,9 +676,8 @@ bool fft_window(const r2f_ctx* ctx, int bh, int bw, int W, int H, bool s32, int*
             if (vy < 1 || vx < 4) continue;  // the window has to keep outputs (and vx, vy divide below)
             const double n = (double)y * x, part = n * vy / y;
             // per window: pass 1 (floats in, image out), pass 2 (image in, valid rows out), pass 3 (valid rows in, floats out);
-            // two windows share one complex image.  The 32-lane form of the 512-row pass 2 moves its bytes ~1.3 x slower
-            // (half-used lines, r2f_fft.hip); the split form moves full lines like the 256-row pass.
-            const double p2 = (y == 512 && !ctx->opt_fft_y512_split) ? 1.3 : 1.0;
+            // two windows share one complex image.  The 512-row pass 2 moves its bytes ~1.3 x slower (r2f_fft.hip).
+            const double p2 = y == 512 ? 1.3 : 1.0;
             const double e = s32 ? 4.0 : 8.0;  // scratch bytes per window element (half a complex64 / complex128)
             const double bytes = 4.0 * n + e * n + p2 * (e * n + e * part) + e * part + 4.0 * vy * vx;
             const double cost = (double)((W + vx - 1) / vx) * ((H + vy - 1) / vy) * bytes;
@@ -797,7 +792,6 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.tw512 = a.tw + kFftN;
     a.tw1024 = a.tw + 2 * kFftN;
     a.ny = ny, a.nx = nx;
-    a.y512_split = ctx->opt_fft_y512_split;
     a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
     a.ax = set.kw / 2 - b[2];
     a.vy = ny - bh + 1;
@@ -1177,12 +1171,6 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
-        return R2F_OK;
-    }
-    if (!strcmp(name, "stencil_fft_y512_split")) {
-        ctx->opt_fft_y512_split = value ? 1 : 0;
-        for (auto& row : ctx->fft_kf_valid)
-            for (bool& v : row) v = false;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_scratch96")) {

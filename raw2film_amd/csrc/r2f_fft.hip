@@ -455,90 +455,6 @@ __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const i
         if (l + 32 * q < a.vy) sst<ST>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
 }
 
-// 512-row windows, the form that moves full lines: 16 lanes per column like the 256-row pass -- a wave =
-// 4 interleaved columns x 16 rows = 1 KB contiguous per access -- with the column's 512 rows as TWO 256-point problems per lane
-// group.  Decimation in frequency on the way in, decimation in time on the way out:
-//     a[n] = x[n] + x[n + 256],  b[n] = (x[n] - x[n + 256]) W_512^n          X[2 k] = FFT256(a)[k],  X[2 k + 1] = FFT256(b)[k]
-//     A = IFFT256(X[2 k] K^[2 k]),  B = IFFT256(X[2 k + 1] K^[2 k + 1])         y[n] = A[n] + W_512^-n B[n],  y[n + 256] = A[n] - W_512^-n B[n]
-// so between the two butterflies the halves are independent pipelines (forward transform, spectrum, inverse transform) that
-// run one after the other: the idle half rests in 64 registers while the other one uses the 256-point machinery of the
-// 256-row pass.  The spectrum image holds K^[2 k] in row k and K^[2 k + 1] in row 256 + k (built by MODE 1 of this kernel, so
-// the order is private to it).  Rows [0, 256) and [256, 512) are both read and written 16 consecutive rows per access.
-#ifndef R2F_FFT_WPE2S
-#define R2F_FFT_WPE2S 2
-#endif
-template <bool INV>
-__device__ __forceinline__ cplx w512_times(const cplx w1, const int m) {  // w1 W_32^m (w1 = W_512^l): W_512^(l + 16 m)
-    return cmul(w1, make_double2(kC32[m], -kS32[m]));
-}
-
-// The value unchanged, but opaque to the optimiser from here on: what was derived from it before (fifteen twiddle powers, 60
-// registers) is not kept alive for the next use -- it is recomputed there (a few dozen multiplications against 60 registers).
-__device__ __forceinline__ cplx launder(cplx w) {
-    asm volatile("" : "+v"(w.x), "+v"(w.y));
-    return w;
-}
-
-template <int NBX, int ST, int MODE>
-__device__ __forceinline__ void fft_cols_y512s_body(const FftConvArgs& a, double* fsm) {
-    const int lane = threadIdx.x & 63, l = lane & 15;
-    const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
-    char* s1 = simg<ST>(a.s1, pair, (long long)512 * (NBX * 16));
-    const cplx w1 = a.tw[l];       // W_256^l: the 256-point transforms
-    const cplx u1 = a.tw512[l];    // W_512^l: the radix-2 steps
-    double* tbuf = wave_tbuf(fsm);
-    cplx va[16], vb[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) va[m] = sld<ST>(s1, sidx(l + 16 * m, k, NBX));
-#pragma unroll
-    for (int m = 0; m < 16; ++m) vb[m] = sld<ST>(s1, sidx(256 + l + 16 * m, k, NBX));
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const cplx d = csub(va[m], vb[m]);
-        va[m] = cadd(va[m], vb[m]);
-        vb[m] = m == 0 ? cmul(d, u1) : cmul(d, w512_times<false>(u1, m));
-    }
-    if (MODE == 1) {  // the kernel spectrum: conj(X), even frequencies in rows [0, 256), odd ones in [256, 512)
-        fft256<false>(va, w1, tbuf, lane);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(va[q].x, -va[q].y);
-        fft256<false>(vb, w1, tbuf, lane);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(256 + l + 16 * q, k, NBX)) = make_double2(vb[q].x, -vb[q].y);
-        return;
-    }
-    const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
-    // one half at a time: the scheduling barriers keep the compiler from starting the second half's transform (or its spectrum
-    // loads) while the first is in flight -- both working sets at once do not fit the 256 registers of 2 waves per SIMD
-#ifndef R2F_Y512S_BAR
-#define R2F_Y512S_BAR 1
-#endif
-    fft256<false>(va, launder(w1), tbuf, lane);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) va[q] = cmul(va[q], at(kf, sidx(l + 16 * q, k, NBX)));
-    fft256<true>(va, launder(w1), tbuf, lane);
-    if (R2F_Y512S_BAR & 1) __builtin_amdgcn_sched_barrier(0);
-    fft256<false>(vb, launder(w1), tbuf, lane);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) vb[q] = cmul(vb[q], at(kf, sidx(256 + l + 16 * q, k, NBX)));
-    fft256<true>(vb, launder(w1), tbuf, lane);
-    if (R2F_Y512S_BAR & 2) __builtin_amdgcn_sched_barrier(0);
-    const cplx u2 = launder(u1);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const cplx t = m == 0 ? cmulc(vb[m], u2) : cmulc(vb[m], w512_times<false>(u2, m));  // W_512^-n B[n]
-        // (pass 3 never reads the rows past the valid outputs; boxes over 256 taps tall leave fewer than 256 of them)
-        if (l + 16 * m < a.vy) sst<ST>(s1, sidx(l + 16 * m, k, NBX), cadd(va[m], t));
-        if (256 + l + 16 * m < a.vy) sst<ST>(s1, sidx(256 + l + 16 * m, k, NBX), csub(va[m], t));
-    }
-}
-
-template <int NBX, int ST, int MODE>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2S, 8))) void fft_cols_y512s_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_y512s_body<NBX, ST, MODE>(a, fsm);
-}
-
 #ifndef R2F_FFT_WPE2
 #define R2F_FFT_WPE2 2
 #endif
@@ -669,26 +585,8 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int NBX, int ST>
-static void launch_cols_y512s(const FftConvArgs& a, int mode, hipStream_t s) {
-    const dim3 block(kFftThreads), grid(a.nx / 16, a.npairs);
-    if (mode == 1)
-        hipLaunchKernelGGL((fft_cols_y512s_kernel<NBX, ST, 1>), grid, block, fft_lds_bytes(), s, a);
-    else
-        hipLaunchKernelGGL((fft_cols_y512s_kernel<NBX, ST, 0>), grid, block, fft_lds_bytes(), s, a);
-}
-
 template <int NBX, bool Y512>
 static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    if (Y512 && a.y512_split) {
-        if (a.s32 == 1)
-            launch_cols_y512s<NBX, 1>(a, mode, s);
-        else if (a.s32 == 2)
-            launch_cols_y512s<NBX, 2>(a, mode, s);
-        else
-            launch_cols_y512s<NBX, 0>(a, mode, s);
-        return;
-    }
     const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1>), grid, block, fft_lds_bytes(), s, a, mode);

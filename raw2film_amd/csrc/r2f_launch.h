@@ -191,8 +191,6 @@ struct FftConvArgs {
     DevCurve curve;
     float log_eps;
     int vec4;                 // 1: vx % 4 == 0, W % 4 == 0 and dst planes 16-byte aligned -> float4 stores in pass 3
-    int y512_split;           // 512-row windows: 1 = the column pass that moves full lines (16 lanes x 2 x 16 rows per column,
-                              // fft_cols_y512s_kernel; its spectrum order is its own), 0 = the 32-lane fft512 form
 };
 hipError_t fft_init_attributes();
 // The same correlation with the whole window pair on chip (r2f_fft2d.hip): 128 x 128 windows, no scratch image; FftConvArgs with

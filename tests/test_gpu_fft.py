@@ -217,7 +217,7 @@ def test_window_shape_follows_the_frame_and_spectra_follow_the_window(ctx):
             for x in (256, 512):  # 1024 columns only when forced (stencil_fft_window / stencil_fft_window_max)
                 vy, vx = y - bh + 1, (x - bw + 1) & ~3
                 n = y * x
-                part, p2 = n * vy / y, 1.0  # (the split 512-row column pass moves full lines like the 256-row one)
+                part, p2 = n * vy / y, (1.3 if y == 512 else 1.0)
                 cost = -(-W // vx) * -(-H // vy) * (4.0 * n + 8.0 * n + p2 * (8.0 * n + 8.0 * part) + 8.0 * part + 4.0 * vy * vx)
                 if best is None or cost < best[0]:
                     best = (cost, (y, x))
