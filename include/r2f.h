@@ -309,6 +309,34 @@ uint64_t r2f_generation(const r2f_ctx* ctx);
 /* Tuning knob for A/B runs: stencil tile variant (0 = auto). */
 int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
 
+/* --- plan-only entry points: the host-side planners of this library (raw2film_amd/csrc/r2f_plan.cpp), callable without a GPU and
+ * without a context.  Nothing upstream corresponds to them (the reference leaves these decisions to OpenCV and wgpu:
+ * cv.filter2D picks its own DFT sizes, effects.py:151-153); they exist so that what the library decides on the CPU before it
+ * launches anything can be pinned and fuzzed -- also under AddressSanitizer / UBSan, tests/test_plan_sanitizers.py -- on a machine
+ * without a device. */
+typedef struct r2f_fft_plan {
+    int32_t ny, nx;          /* window rows, columns */
+    int32_t vy, vx;          /* valid outputs per window */
+    int32_t gx, ntiles;      /* windows per row of windows, windows per channel */
+    int32_t pairs_per_channel, pairs;
+    int32_t streams, batch, launches; /* internal streams, window pairs per launch triple, launch triples */
+    uint64_t scratch_bytes;  /* pass scratch the context allocates for it */
+} r2f_fft_plan;
+/* The FFT form's plan for a bh x bw tap box on a call that covers `rows` output rows of a W-column frame with nch channels:
+ * window shape (the cheapest under the stencil_fft_window / _rows / _max options, 0 = not forced), tiling and batches
+ * (batch_mib MiB of scratch in flight on `streams` internal streams).  scratch_elem_bytes: 16, 8 or 12.  R2F_EINVAL when no window
+ * shape fits. */
+int r2f_plan_fft(int bh, int bw, int W, int rows, int nch, int scratch_elem_bytes, int window, int window_rows, int window_max,
+                 int batch_mib, int streams, r2f_fft_plan* out);
+/* The direct form's device entry list for channel `channel` of a (kh, kw, kc) stencil on a TW x TH tile with Q rows per lane and
+ * an LDS budget (0 = one phase): out8 = {entries, row steps, LDS phases, mirrored taps paired, cropped rows, cropped (padded)
+ * columns, LDS row stride, rows of the largest phase}.  The list is checked against the taps it was built from (every tap exactly
+ * once, offsets inside the phase's LDS rows): R2F_EHIP would mean a planner bug.  R2F_ETOOLARGE: a row step does not fit. */
+int r2f_plan_stencil(const float* host_khwc, int kh, int kw, int kc, int channel, int Q, int TW, int TH, int lds_budget_bytes,
+                     int allow_sym, int* out8);
+/* Tile order of a gx x gy grid of stencil workgroups (a permutation of 0 .. gx gy - 1; band = 0: automatic band width). */
+int r2f_plan_tile_order(int gx, int gy, int band, int* order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,12 @@ class Planes(C.Structure):
     ]
 
 
+class FftPlan(C.Structure):  # r2f_fft_plan
+    _fields_ = [("ny", C.c_int32), ("nx", C.c_int32), ("vy", C.c_int32), ("vx", C.c_int32), ("gx", C.c_int32), ("ntiles", C.c_int32),
+                ("pairs_per_channel", C.c_int32), ("pairs", C.c_int32), ("streams", C.c_int32), ("batch", C.c_int32),
+                ("launches", C.c_int32), ("scratch_bytes", C.c_uint64)]
+
+
 class Blit(C.Structure):  # r2f_blit: the uniform block of shaders/copy_to_int.wgsl
     _fields_ = [
         ("scale_x", C.c_float), ("scale_y", C.c_float), ("offset_x", C.c_float), ("offset_y", C.c_float),
@@ -146,6 +152,9 @@ _SIGNATURES = {
     "r2f_resize_area_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "r2f_decode_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "r2f_blit_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _P(Blit), C.c_void_p]),
+    "r2f_plan_fft": (C.c_int, [C.c_int] * 11 + [_P(FftPlan)]),
+    "r2f_plan_stencil": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "r2f_plan_tile_order": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "r2f_generation": (C.c_uint64, [C.c_void_p]),
     "r2f_render_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "r2f_write_frame_params": (C.c_int, [C.c_void_p, _P(Params), C.c_void_p]),

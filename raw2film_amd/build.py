@@ -14,8 +14,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
-SOURCES = ["r2f_kernels.hip", "r2f_fft.hip", "r2f_fft2d.hip", "r2f_front.hip", "r2f_post.hip", "r2f_api.hip"]
-HEADERS = ["r2f_device.h", "r2f_launch.h", "r2f_fft_math.h", os.path.join("..", "..", "include", "r2f.h")]
+SOURCES = ["r2f_kernels.hip", "r2f_fft.hip", "r2f_front.hip", "r2f_post.hip", "r2f_api.hip", "r2f_plan.cpp"]
+HEADERS = ["r2f_device.h", "r2f_launch.h", "r2f_fft_math.h", "r2f_plan.h", os.path.join("..", "..", "include", "r2f.h")]
 ARCH = "gfx950"
 
 
@@ -35,8 +35,9 @@ def needs_build() -> bool:
 
 
 def _compile_one(hipcc: str, src: str, obj: str, defines: list[str]) -> tuple[str, int, str]:
-    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", "-c", "-o", obj,
-           os.path.join(CSRC, src)] + defines
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", "-o", obj, os.path.join(CSRC, src)] + defines
+    if src.endswith(".hip"):  # (r2f_plan.cpp is host-only C++: no device pass)
+        cmd.insert(3, f"--offload-arch={ARCH}")
     res = subprocess.run(cmd, capture_output=True, text=True)
     return " ".join(cmd), res.returncode, res.stdout + res.stderr
 
@@ -55,7 +56,7 @@ def build(force: bool = False, verbose: bool = False, defines: list[str] | None 
     import tempfile
 
     objdir = tempfile.mkdtemp(prefix="r2f_obj_")
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     with ThreadPoolExecutor(len(SOURCES)) as pool:
         results = list(pool.map(lambda so: _compile_one(hipcc, so[0], so[1], list(defines or [])), zip(SOURCES, objs)))
     for cmd, rc, log in results:

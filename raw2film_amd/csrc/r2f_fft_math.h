@@ -1,5 +1,5 @@
-// r2f_fft_math.h -- fp64 complex helpers and the register DFTs shared by the overlap-save FFT kernels (r2f_fft.hip: three passes over
-// a global scratch image; r2f_fft2d.hip: the whole 128 x 128 window in registers).
+// r2f_fft_math.h -- fp64 complex helpers and the register DFTs of the overlap-save FFT kernels (r2f_fft.hip: three passes over a
+// global scratch image).
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -193,11 +193,6 @@ struct FftConvArgs {
     int vec4;                 // 1: vx % 4 == 0, W % 4 == 0 and dst planes 16-byte aligned -> float4 stores in pass 3
 };
 hipError_t fft_init_attributes();
-// The same correlation with the whole window pair on chip (r2f_fft2d.hip): 128 x 128 windows, no scratch image; FftConvArgs with
-// ny = nx = 128 (s1, tw*, s32 unused; kfs / kf_out in the kernel's own register order, 16 x 1024 complex128 per channel).
-constexpr int kFft2dN = 128;
-hipError_t fft2d_init_attributes();
-hipError_t launch_fft2d(const FftConvArgs& a, int mode, hipStream_t s);
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s);
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s);
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s);

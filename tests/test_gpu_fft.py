@@ -69,59 +69,6 @@ def test_fft_form_matches_oracle_and_direct_form(ctx, shape, window):
     np.testing.assert_array_equal(a[..., 2], b[..., 2])  # the identity plane runs the direct kernel either way
 
 
-@pytest.mark.parametrize("shape", [(300, 417), (64, 64), (1, 7), (9, 1), (129, 128), (95, 93), (260, 1100), (401, 70)])
-@pytest.mark.parametrize("taps", [(21, 21), (35, 35), (48, 23), (27, 45)])
-def test_on_chip_form_matches_oracle_and_three_pass_form(ctx, shape, taps):
-    """r2f_fft2d.hip (opt-in, `stencil_fft_onchip_max`): a pair of 128 x 128 windows per workgroup, held in registers as complex128
-    from the load to the store -- no scratch image, no rounding between the passes.  Arbitrary signed, asymmetric taps; frames
-    smaller than a window, odd widths (scalar stores), several windows a side; a specular next to shadows."""
-    rng = np.random.default_rng(shape[0] + taps[0])
-    img = rng.uniform(0.0, 2.0, shape + (3,)).astype(np.float32)
-    img[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = 500.0
-    k = rng.uniform(-0.2, 1.0, taps + (3,)).astype(np.float32)
-    k /= k.sum(axis=(0, 1), keepdims=True)
-    ref = st.convolve_2d(img, k)
-    a = run(ctx, 1, img, k, 1, stencil_fft_onchip_max=48, stencil_fft_scratch32=0)
-    assert uses_fft(ctx, 1) == [1, 1, 1] and [c["window"] for c in ctx.stencil_stats(1)] == [(128, 128)] * 3
-    assert_close(a, ref, 2e-6, 1e-3, "on-chip form")
-    b = run(ctx, 1, img, k, 1, stencil_fft_onchip_max=0)
-    assert [c["window"] for c in ctx.stencil_stats(1)] != [(128, 128)] * 3
-    assert_close(b, ref, 2e-6, 1e-3, "three-pass form")
-    assert np.max(np.abs(a - b) / np.maximum(np.abs(ref), 1e-3)) <= 2e-6
-    # row ranges with halo rows (what a row shard calls) give the same rows
-    if shape[0] >= 64:
-        y0, y1 = shape[0] // 3, shape[0] - 5
-        part = run(ctx, 1, img, k, 1, rows=(y0, y1), stencil_fft_onchip_max=48)
-        assert np.max(np.abs(part - a[y0:y1]) / np.maximum(np.abs(ref[y0:y1]), 1e-3)) <= 1e-6
-    ctx.set_option("stencil_fft_onchip_max", 0)
-    ctx.set_option("stencil_fft_scratch32", 2)
-
-
-def test_on_chip_form_with_the_halation_epilogue(ctx):
-    """The same kernel with log + density curve fused into its stores (a halation stencil small enough for a 128-point window:
-    preview scales) against the oracle's S2 + S3 + S4."""
-    neg, prt, _ = stocks()
-    rng = np.random.default_rng(4)
-    H, W = 210, 330
-    expo = rng.uniform(0.001, 3.0, (H, W, 3)).astype(np.float32)
-    expo[50, 60] = 4000.0
-    k = ok.compute_halation_kernel(150.0, halation_green_factor=0.3)  # 39 x 39
-    ctx.set_curve1d(neg.get_density_curve(0.0, 1.0))
-    ctx.set_kernel(0, k)
-    params = ctx.make_params(halation=True)
-    ref = st.multi_channel_interp(st.log_clip(st.halation(expo, k)), neg.get_density_curve(0.0, 1.0))
-    outs = []
-    for onchip in (48, 0):
-        ctx.set_option("stencil_fft_onchip_max", onchip)
-        D = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
-        ctx.stage_halation(planes(expo), D, params, y0=0, y1=H, H_global=H)
-        outs.append(np.transpose(D.cpu().numpy(), (1, 2, 0)))
-        assert ctx.stencil_stats(0)[0]["window"] == ((128, 128) if onchip else ctx.stencil_stats(0)[0]["window"])
-        assert_close(outs[-1], ref, 1e-5, 1e-3, f"halation, on-chip max {onchip}")
-    assert ctx.stencil_stats(0)[0]["fft"] == 1
-    ctx.set_option("stencil_fft_onchip_max", 0)
-
-
 def test_eligibility_limits(ctx):
     img = np.random.default_rng(1).uniform(0, 1, (140, 150, 3)).astype(np.float32)
     rng = np.random.default_rng(2)
