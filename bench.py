@@ -176,9 +176,7 @@ def main():
     scale = max(H, W) / 36.0
     hal_k = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3) if effects else None
     mtf_k = stencils.mtf_stencil(neg, scale, 0.0, 1.0) if effects else None
-    backend = HipStageBackend(proc.ctx, params,
-                              halation_taps=stencils.vertical_reach(hal_k) if effects else (0, 0),
-                              mtf_taps=stencils.vertical_reach(mtf_k) if effects else (0, 0))
+    backend = HipStageBackend.for_stencils(proc.ctx, params, hal_k, mtf_k)
     use_graph = not args.no_graph and effects and not args.side_grain
     # N = 1 (and every rank of the frame-per-GPU batch): the product's own entry -- HipProcessor.process_array on device tensors,
     # i.e. prepare() + r2f_render, with a NEW grain seed every frame like the reference's renders (gpu_processor.py:585-597).

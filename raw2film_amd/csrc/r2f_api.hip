@@ -67,9 +67,13 @@ struct r2f_ctx {
     } tile_order[4];
     int tile_order_next = 0;
     // FFT form of large stencils (r2f_fft.hip): twiddles, per stencil and channel the kernel spectrum, pass scratch
-    DeviceBuf fft_tw, fft_kf[3][3], fft_s1, fft_kimg;
-    bool fft_kf_valid[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
-    int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 4096 + nx) each spectrum was built for
+    // (one spectrum per WINDOW SHAPE: the calls of one frame may differ in it -- a row shard's interior halation and its boundary
+    // bands cover different numbers of rows, and the window choice follows the rows of the call -- and must not evict each other)
+    static constexpr int kFftShapes = 6;  // {256, 512} rows x {256, 512, 1024} columns
+    static int fft_shape_index(int ny, int nx) { return (ny == 512 ? 3 : 0) + (nx == 256 ? 0 : (nx == 512 ? 1 : 2)); }
+    DeviceBuf fft_tw, fft_kf[3][3][kFftShapes], fft_s1, fft_kimg;
+    bool fft_kf_valid[3][3][kFftShapes] = {};
+    int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 4096 + nx) of the channel's last launch
     int opt_fft_window = 0;      // window columns: 0 = the cheapest of 256 / 512 / 1024 per stencil and frame, or one of them forced
     int opt_fft_window_max = 512;  // widest window the automatic choice may take (1024 columns: 9 % fewer window elements for the
                                    // 87-tap disc, but the passes run 10-25 % slower per element)
@@ -173,6 +177,7 @@ struct DeviceGuard {
     bool switched = false;
     hipError_t status = hipSuccess;
     explicit DeviceGuard(int device) {
+        (void)hipGetLastError();  // an entry point reports its own errors: a sticky one from earlier (a capture that was abandoned) is not ours
         status = hipGetDevice(&prev);
         if (status == hipSuccess && prev != device) {
             status = hipSetDevice(device);
@@ -440,6 +445,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         return fail(ctx, R2F_EINVAL, "stencil %d: no FFT window shape fits a %d x %d tap box under the current stencil_fft_window* options",
                     which, bh, bw);
     const size_t img = (size_t)ny * nx;
+    const int shape = r2f_ctx::fft_shape_index(ny, nx);
     if (!ctx->fft_tw.p) {
         // W_256^k, k < 256, then W_512^k, k < 256, then W_1024^k, k < 64
         std::vector<double> tw(4 * kFftN + 2 * 64);
@@ -467,7 +473,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     if (rc) return rc;
     for (int i = 0; i < nch; ++i) {
         const int c = chans[i];
-        if (ctx->fft_kf_valid[which][c] && ctx->fft_kf_dims[which][c] == ny * 4096 + nx) continue;
+        ctx->fft_kf_dims[which][c] = ny * 4096 + nx;
+        if (ctx->fft_kf_valid[which][c][shape]) continue;
         // the kernel's spectrum: the same two forward passes on its zero-padded image
         std::vector<float> kimg(img, 0.f);
         const int kc = set.kc == 1 ? 0 : c;
@@ -475,7 +482,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
             for (int x = 0; x < bw; ++x) kimg[(size_t)y * nx + x] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
         rc = upload(ctx, ctx->fft_kimg, kimg.data(), img * sizeof(float));
         if (rc) return rc;
-        rc = ensure_bytes(ctx, ctx->fft_kf[which][c], img * sizeof(double2));
+        rc = ensure_bytes(ctx, ctx->fft_kf[which][c][shape], img * sizeof(double2));
         if (rc) return rc;
         FftConvArgs k = a;
         k.src.data = static_cast<float*>(ctx->fft_kimg.p);
@@ -484,18 +491,17 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         k.nch = 1, k.chan[0] = 0, k.ppc = 1;
         k.ntiles = 1, k.gx = 1, k.npairs = 1, k.pair0 = 0;
         k.s1 = static_cast<double2*>(ctx->fft_s1.p);
-        k.kf_out = static_cast<double2*>(ctx->fft_kf[which][c].p);
+        k.kf_out = static_cast<double2*>(ctx->fft_kf[which][c][shape].p);
         R2F_HIP(ctx, launch_fft_rows_fwd(k, s));
         R2F_HIP(ctx, launch_fft_cols(k, 1, s));
-        ctx->fft_kf_valid[which][c] = true;
-        ctx->fft_kf_dims[which][c] = ny * 4096 + nx;
+        ctx->fft_kf_valid[which][c][shape] = true;
     }
     a.src = to_dev(src);
     a.dst = to_dev(dst);
     a.nch = nch;
     for (int i = 0; i < nch; ++i) {
         a.chan[i] = chans[i];
-        a.kfs[i] = static_cast<const double2*>(ctx->fft_kf[which][chans[i]].p);
+        a.kfs[i] = static_cast<const double2*>(ctx->fft_kf[which][chans[i]][shape].p);
     }
     a.y0 = y0, a.y1 = y1, a.W = W, a.H_global = H;
     a.s32 = ((ctx->opt_fft_s96 >> which) & 1) ? 2 : ((ctx->opt_fft_s32 >> which) & 1);
@@ -728,7 +734,8 @@ void r2f_destroy(r2f_ctx* ctx) {
     ctx->fft_s1.release();
     ctx->fft_kimg.release();
     for (auto& row : ctx->fft_kf)
-        for (auto& b : row) b.release();
+        for (auto& per_shape : row)
+            for (auto& b : per_shape) b.release();
     for (int i = 0; i < 4; ++i) {
         if (ctx->fft_stream[i]) (void)hipStreamDestroy(ctx->fft_stream[i]);
         if (ctx->fft_ev_out[i]) (void)hipEventDestroy(ctx->fft_ev_out[i]);
@@ -911,7 +918,10 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.host.assign(k, k + (size_t)kh * kw * kc);
     ++ctx->generation;
     s.built_q = 0;
-    for (int c = 0; c < 3; ++c) ctx->fft_kf_valid[which][c] = false;
+    for (int c = 0; c < 3; ++c) {
+        ctx->fft_kf_dims[which][c] = 0;
+        for (bool& v : ctx->fft_kf_valid[which][c]) v = false;
+    }
     if (which == R2F_KERNEL_GRAIN) ctx->grain_fixed_valid = false;
     ctx->stencil_fixed_valid[which] = false;
     return R2F_OK;
@@ -1075,7 +1085,7 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
         const int sep = which == R2F_KERNEL_GRAIN && fr && ctx->grain_fixed_valid && ctx->grain_sep && ctx->opt_grain_sep;
         o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym | (fr << 1) | (sep << 8);
         o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q;
-        o[7] = fft_eligible(ctx, set, c) ? 1 | ((ctx->fft_kf_valid[which][c] ? ctx->fft_kf_dims[which][c] : 0) << 1) : 0;
+        o[7] = fft_eligible(ctx, set, c) ? 1 | (ctx->fft_kf_dims[which][c] << 1) : 0;
     }
     return R2F_OK;
 }

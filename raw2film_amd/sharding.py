@@ -64,7 +64,9 @@ class ShardPlan:
 class HipStageBackend:
     """Stage calls of one GPU's HipContext on (3, rows, W) float32 CUDA tensors."""
 
-    def __init__(self, ctx, params, halation_taps=(0, 0), mtf_taps=(0, 0)):
+    def __init__(self, ctx, params, halation_taps=(0, 0), mtf_taps=(0, 0), halation_taps_per_channel=None, halation_box=None):
+        """halation_taps_per_channel: [(above, below)] x 3 (stencils.vertical_reach_per_channel): planes whose halation stencil is a
+        single tap need no halation halo.  halation_box: (rows, columns) of the halation's non-zero tap box, for `halation_band_rows`."""
         import torch
 
         self.torch = torch
@@ -72,7 +74,47 @@ class HipStageBackend:
         self.params = params
         self.halation_taps = halation_taps  # (rows above, rows below) the stencil reaches
         self.mtf_taps = mtf_taps
+        self.halation_taps_per_channel = halation_taps_per_channel
+        self.halation_box = halation_box
         self.device = ctx.device
+
+    @classmethod
+    def for_stencils(cls, ctx, params, halation_kernel=None, mtf_kernel=None):
+        """The backend for a context whose halation / MTF stencils are these (kh, kw, 1|3) arrays (None: stage off): their vertical
+        reach, the reach of each halation plane on its own and the halation's tap box are what the row tiler plans with."""
+        import numpy as np
+
+        from . import stencils
+
+        per, box = None, None
+        if halation_kernel is not None:
+            k = np.asarray(halation_kernel)
+            k = k[..., None] if k.ndim == 2 else k
+            per = stencils.vertical_reach_per_channel(k)
+            nz = np.nonzero(np.any(k != 0, axis=2))
+            if nz[0].size:
+                box = (int(nz[0].max() - nz[0].min() + 1), int(nz[1].max() - nz[1].min() + 1))
+        return cls(ctx, params,
+                   halation_taps=stencils.vertical_reach(halation_kernel) if halation_kernel is not None else (0, 0),
+                   mtf_taps=stencils.vertical_reach(mtf_kernel) if mtf_kernel is not None else (0, 0),
+                   halation_taps_per_channel=per, halation_box=box)
+
+    def halation_band_rows(self, W: int, rows: int) -> int:
+        """Rows one window row of the halation's FFT form yields on a call of `rows` rows (r2f_plan_fft, default options): a boundary
+        band of that height costs the frame no extra window row.  0 when unknown (direct form, no box given)."""
+        import ctypes as C
+
+        from . import _lib
+
+        if not self.halation_box:
+            return 0
+        bh, bw = self.halation_box
+        if bh * bw < 400 or max(bh, bw) > 400:
+            return 0
+        plan = _lib.FftPlan()
+        if _lib.load().r2f_plan_fft(int(bh), int(bw), int(W), int(rows), 2, 16, 0, 0, 512, 192, 2, C.byref(plan)) != 0:
+            return 0
+        return int(plan.vy)
 
     def empty(self, rows, W):
         return self.torch.empty((3, rows, W), dtype=self.torch.float32, device=self.device)
@@ -152,7 +194,7 @@ class RowShardedRenderer:
     """
 
     def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,
-                 group=None, rank=None, world=None, side_grain: bool = False, graph: bool = False):
+                 group=None, rank=None, world=None, side_grain: bool = False, graph: bool = False, split_halation="auto"):
         import torch
         import torch.distributed as dist
 
@@ -173,6 +215,13 @@ class RowShardedRenderer:
         self.single_exchange = halation and mtf
         ea, eb = (ha + ma, hb + mb) if self.single_exchange else (ha, hb)
         self.plan = ShardPlan(H, W, rank, world, r0, r1, (ea, eb), (ma, mb))
+        # Per plane: a channel whose halation stencil is a single tap (blue on a colour stock) needs exposure halo rows only for
+        # the MTF reach, not for the halation's -- 17 instead of 59 rows at 100 MP, 6.7 instead of 8.7 MB per direction.
+        per = getattr(backend, "halation_taps_per_channel", None) if halation else None
+        if per:
+            self.halo_e_ch = [((a + ma, b + mb) if self.single_exchange else (a, b)) for a, b in per]
+        else:
+            self.halo_e_ch = [(ea, eb)] * 3
         smallest = min(b - a for a, b in shard_rows(H, world))
         need = max(ea, eb, ma, mb)
         if world > 1 and smallest < need:
@@ -202,18 +251,45 @@ class RowShardedRenderer:
         self.graph = bool(graph and not burn and not self.side_grain and getattr(backend, "device", None) is not None
                           and torch.cuda.is_available() and (halation or mtf or grain)
                           and (world == 1 or self.single_exchange or not mtf))  # no exchange downstream of the front
+        # The halation in three calls: the interior rows -- whose stencil reads own exposure rows only -- are launched BEFORE the
+        # halo exchange is waited for (they run while the halos travel), a band at each inner boundary after it.  A band is one
+        # window row of the FFT form high (172 rows at 100 MP) where that is known, so the three calls together cover the same
+        # number of window rows as one call would.
+        # Worth it only where the exchange would otherwise be exposed: three calls cost ~0.05 ms more device time than one (the
+        # bands are small launches: measured on one GPU, tools/shard_model.py), the interior front kernel already covers
+        # 4.9 ns per kilopixel of own rows, and the exchange is MODELLED at 30 us + bytes / 55 GB/s (one xGMI link; no multi-GPU
+        # node was available to measure it).  split_halation = True / False overrides the estimate.
+        self.split = None
+        want_split = bool(split_halation)
+        if split_halation == "auto":
+            halo_bytes = sum(a for a, _ in self.halo_e_ch) * W * 4
+            exchange_ms = 0.03 + halo_bytes / 55e6
+            front_ms = 4.9e-6 * max(p.rows - (ea + eb), 0) * W / 1e3
+            want_split = exchange_ms - front_ms > 0.05
+        if halation and self.single_exchange and world > 1 and want_split:
+            need_t, need_b = (ha + ma, hb + mb)
+            band = getattr(backend, "halation_band_rows", lambda W, rows: 0)(W, self.d_hi - self.d_lo)
+            top = max(need_t, band) if rank > 0 else 0
+            bot = max(need_b, band) if rank < world - 1 else 0
+            lo, hi = self.d_lo + top, self.d_hi - bot
+            if hi - lo >= max(need_t, need_b, 1):
+                self.split = (lo, hi)
+        self.trace = None   # a list here collects (event name) in issue order: tests look at the overlap structure
         self._graphs = {}   # key -> [calls seen, CUDAGraph or None], most recently used last
         self._graphs_state = None  # _graph_state() the graphs were captured from
         self._identity_done = 0  # channel mask front_split finished (world == 1 only)
 
     # ------------------------------------------------------------------ neighbour exchange
-    def _exchange(self, buf, buf_gy0: int, above: int, below: int, wait: bool = True):
+    def _exchange(self, buf, buf_gy0: int, above, below, wait: bool = True):
         """Fill the halo rows of `buf` (global rows [buf_gy0, ...)) from the neighbours' own rows.
-        Rank k sends its first `below_of_prev` rows up and its last `above_of_next` rows down.
+        Rank k sends its first `below_of_prev` rows up and its last `above_of_next` rows down.  above / below: rows per plane
+        (an int for all three, or one per plane).
         wait=False: the transfers are only started (RCCL runs them on its own stream, ordered after what the current
         stream holds now); hand the return value to `_exchange_finish` before the halo rows are read."""
         p, dist, torch = self.plan, self.dist, self.torch
-        if p.world == 1 or (above == 0 and below == 0):
+        above = [above] * 3 if isinstance(above, int) else list(above)
+        below = [below] * 3 if isinstance(below, int) else list(below)
+        if p.world == 1 or (max(above) == 0 and max(below) == 0):
             return None
         ops, recvs = [], []
         own0 = p.r0 - buf_gy0  # buffer row of the first own row
@@ -223,14 +299,19 @@ class RowShardedRenderer:
 
         # A halo is `n` consecutive rows of each of the 3 planes: 3 contiguous blocks.  On RCCL they are sent
         # from / received into the plane buffer directly (no staging copies); on gloo through host tensors.
-        def add_send(row, n, peer):
+        def add_send(first_row, rows_of, peer):
             for c in range(3):
-                block = buf[c, row:row + n, :]
-                ops.append(dist.P2POp(dist.isend, block.cpu() if host_staging else block, peer, self.group))
+                n = rows_of[c]
+                if n:
+                    block = buf[c, first_row(n):first_row(n) + n, :]
+                    ops.append(dist.P2POp(dist.isend, block.cpu() if host_staging else block, peer, self.group))
 
-        def add_recv(row, n, peer):
+        def add_recv(first_row, rows_of, peer):
             for c in range(3):
-                block = buf[c, row:row + n, :]
+                n = rows_of[c]
+                if not n:
+                    continue
+                block = buf[c, first_row(n):first_row(n) + n, :]
                 if host_staging:
                     tmp = torch.empty((n, p.W), dtype=buf.dtype, device="cpu")
                     ops.append(dist.P2POp(dist.irecv, tmp, peer, self.group))
@@ -239,15 +320,11 @@ class RowShardedRenderer:
                     ops.append(dist.P2POp(dist.irecv, block, peer, self.group))
 
         if p.rank > 0:  # neighbour above: it needs my top `below` rows, I need its bottom `above` rows
-            if below:
-                add_send(own0, below, self._peer(p.rank - 1))
-            if above:
-                add_recv(own0 - above, above, self._peer(p.rank - 1))
+            add_send(lambda n: own0, below, self._peer(p.rank - 1))
+            add_recv(lambda n: own0 - n, above, self._peer(p.rank - 1))
         if p.rank < p.world - 1:  # neighbour below
-            if above:
-                add_send(own0 + p.rows - above, above, self._peer(p.rank + 1))
-            if below:
-                add_recv(own0 + p.rows, below, self._peer(p.rank + 1))
+            add_send(lambda n: own0 + p.rows - n, above, self._peer(p.rank + 1))
+            add_recv(lambda n: own0 + p.rows, below, self._peer(p.rank + 1))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         if not wait:
             return reqs, recvs
@@ -305,35 +382,60 @@ class RowShardedRenderer:
                 self._graphs = {key: slot}
             self._graphs_state = new_state
             return res
+        # world > 1: the front kernels and the exchange are issued every frame; what is captured is (1) the interior halation, which
+        # runs while the halos travel, and (2) everything downstream of the exchange.  world == 1: one graph, front included.
+        pending = None
         if not whole:
-            self._front_and_exchange(image_rows)
+            pending = self._front_and_start_exchange(image_rows)
         if slot[1] is None:
-            g = torch.cuda.CUDAGraph()
+            graphs = []
             try:
                 # thread_local: other threads (RCCL's watchdog polls events) may keep calling into HIP during the capture
+                if not whole and self.split:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                        self._halation_interior()
+                    graphs.append(g1)
+                g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     if whole:
-                        self._front_and_exchange(image_rows)
+                        self._exchange_finish(self._front_and_start_exchange(image_rows))
+                        self._halation_interior()
                     self._after_exchange(out_f32, out_u8, None)
+                graphs.append(g)
             except Exception:  # noqa: BLE001 -- a failed capture must not cost the frame: eager launches from here on
                 self.graph = False
                 self._graphs.clear()
                 torch.cuda.synchronize()
-                if whole:
-                    self._front_and_exchange(image_rows)
-                return self._after_exchange(out_f32, out_u8, None)
+                return self._finish_eager(image_rows, pending, out_f32, out_u8, whole)
             if self._graph_state() != state:
                 # the capture itself changed the context (a table built lazily on this frame: its upload synchronises and does
                 # not belong in a graph) -- keep this frame's eager result semantics simple: run it again eagerly, capture later
                 self._graphs.clear()
                 self._graphs_state = self._graph_state()
                 torch.cuda.synchronize()
-                if whole:
-                    self._front_and_exchange(image_rows)
-                return self._after_exchange(out_f32, out_u8, None)
-            slot[1] = g
-        slot[1].replay()
+                return self._finish_eager(image_rows, pending, out_f32, out_u8, whole)
+            slot[1] = graphs
+        if len(slot[1]) == 2:
+            self._note("replay:halation_interior")
+            slot[1][0].replay()
+        self._note("exchange_finish")
+        self._exchange_finish(pending)
+        self._note("replay:after_exchange")
+        slot[1][-1].replay()
         return out_f32, out_u8
+
+    def _finish_eager(self, image_rows, pending, out_f32, out_u8, whole):
+        """The rest of a frame whose capture did not work out, launched kernel by kernel (`pending`: its exchange in flight)."""
+        if whole:
+            pending = self._front_and_start_exchange(image_rows)
+        self._halation_interior()
+        self._exchange_finish(pending)
+        return self._after_exchange(out_f32, out_u8, None)
+
+    def _note(self, what):
+        if self.trace is not None:
+            self.trace.append(what)
 
     def _graph_state(self):
         """(context change counter, parameter block) of the backend -- what a captured graph of this renderer depends on besides
@@ -365,38 +467,55 @@ class RowShardedRenderer:
         if not (self.halation or self.mtf or self.grain or self.burn):  # LUTs only: one fused pointwise pass
             be.front_to_output(image_rows, p.r0, out_f32, out_u8, p.r0, p.r0, p.r1, H)
             return out_f32, out_u8
-        self._front_and_exchange(image_rows)
+        pending = self._front_and_start_exchange(image_rows)
+        self._halation_interior()
+        self._note("exchange_finish")
+        self._exchange_finish(pending)
         return self._after_exchange(out_f32, out_u8, field_ready)
 
-    def _front_and_exchange(self, image_rows):
-        """S0 + S1 (+ S3 + S4 without halation) on this rank's rows and the exposure halo exchange."""
+    def _front_and_start_exchange(self, image_rows):
+        """S0 + S1 (+ S3 + S4 without halation) on this rank's rows; the exposure halo exchange is STARTED (the rows the neighbours
+        wait for are made first, the interior rows while the halos travel).  Returns what `_exchange_finish` needs."""
         p, be = self.plan, self.backend
         H = p.H
+        pending = None
         if not (self.halation or self.mtf or self.grain or self.burn):
-            return
+            return pending
         if not (self.halation or self.mtf):
             be.front(image_rows, p.r0, 1, self.Dplain, p.r0, p.r0, p.r1, H)
         elif self.halation:
-            above, below = p.halo_e
-            if p.world > 1 and (above or below) and p.rows >= above + below:
+            above, below = [a for a, _ in self.halo_e_ch], [b for _, b in self.halo_e_ch]
+            if p.world > 1 and (max(above) or max(below)) and p.rows >= max(above) + max(below):
                 # the rows the neighbours wait for first, then the interior while the halos travel
-                lo_band = p.r0 + (below if p.rank > 0 else 0)
-                hi_band = p.r1 - (above if p.rank < p.world - 1 else 0)
+                lo_band = p.r0 + (max(below) if p.rank > 0 else 0)
+                hi_band = p.r1 - (max(above) if p.rank < p.world - 1 else 0)
                 if lo_band > p.r0:
                     be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, lo_band, H)
                 if hi_band < p.r1:
                     be.front(image_rows, p.r0, 0, self.E, self.e_lo, hi_band, p.r1, H)
+                self._note("exchange_start")
                 pending = self._exchange(self.E, self.e_lo, above, below, wait=False)
                 be.front(image_rows, p.r0, 0, self.E, self.e_lo, lo_band, hi_band, H)
-                self._exchange_finish(pending)
             elif p.world == 1 and hasattr(be, "front_split"):
                 # no neighbours to feed: the halation's identity channels (blue on a colour stock) skip their exposure plane
                 self._identity_done = be.front_split(image_rows, p.r0, self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H)
             else:
                 be.front(image_rows, p.r0, 0, self.E, self.e_lo, p.r0, p.r1, H)
-                self._exchange(self.E, self.e_lo, above, below)
+                self._note("exchange_start")
+                pending = self._exchange(self.E, self.e_lo, above, below, wait=False)
         else:
             be.front(image_rows, p.r0, 1, self.D, self.d_lo, p.r0, p.r1, H)
+        return pending
+
+    def _halation_interior(self):
+        """The halation of the rows whose stencil reads this rank's own exposure rows only: issued before the halo exchange is
+        waited for."""
+        if not self.split:
+            return
+        p, be = self.plan, self.backend
+        lo, hi = self.split
+        self._note("halation_interior")
+        be.halation(self.E, self.e_lo, self.D, self.d_lo, lo, hi, p.H)
 
     def _after_exchange(self, out_f32, out_u8, field_ready):
         """Everything downstream of the exposure planes: S2 .. S8 on this renderer's own buffers."""
@@ -407,7 +526,14 @@ class RowShardedRenderer:
         else:
             if self.halation:
                 kw = {"identity_done": self._identity_done} if self._identity_done else {}
-                if self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
+                if self.split:  # the interior rows are under way (or done): the bands next to the neighbours' rows
+                    lo, hi = self.split
+                    self._note("halation_bands")
+                    if lo > self.d_lo:
+                        be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, lo, H)
+                    if hi < self.d_hi:
+                        be.halation(self.E, self.e_lo, self.D, self.d_lo, hi, self.d_hi, H)
+                elif self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
                     be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H, **kw)
                 else:
                     be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H, **kw)

@@ -97,3 +97,13 @@ def vertical_reach(stencil: np.ndarray) -> tuple[int, int]:
         return 0, 0
     anchor = k.shape[0] // 2
     return max(anchor - int(rows[0]), 0), max(int(rows[-1]) - anchor, 0)
+
+
+def vertical_reach_per_channel(stencil: np.ndarray) -> list[tuple[int, int]]:
+    """`vertical_reach` of each of the three channels on its own: a channel whose stencil is a single tap at the anchor (the blue
+    layer of a colour stock's halation, effects.py:248-263) reaches no neighbouring row, so a row shard need not exchange halo
+    rows of that plane for this stencil."""
+    k = np.asarray(stencil)
+    if k.ndim == 2:
+        k = k[..., None]
+    return [vertical_reach(k[..., c if k.shape[2] > 1 else 0]) for c in range(3)]

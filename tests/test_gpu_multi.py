@@ -41,7 +41,7 @@ def _render_rows(rank, world, device, H, W, fw, direct):
     scale = max(H, W) / fw
     hal = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
     mtf = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
-    be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
+    be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
     rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=rank, world=world, graph=world > 1)
     frame = synthetic_frame(H, W, seed=31)
     frame[60:150, 40:200] *= 8.0

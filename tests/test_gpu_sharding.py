@@ -37,7 +37,7 @@ def _render(rank, world, H, W, fw, burn=0.0, direct=False):
     scale = max(H, W) / fw
     hal = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
     mtf = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
-    be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
+    be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
     rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, burn=bool(burn), rank=rank, world=world)
     frame = synthetic_frame(H, W, seed=31)
     frame[60:150, 40:200] *= 8.0
@@ -60,6 +60,78 @@ def _worker(rank, world, port, H, W, fw, path, burn=0.0, direct=False):
         np.save(f"{path}.{rank}.npy", out)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_graph(rank, world, port, H, W, fw, path):
+    """Four frames with four seeds through a graph-replaying renderer and through an eager one (same rank, same buffers)."""
+    import torch.distributed as dist
+
+    from raw2film_amd import HipProcessor, stencils
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        neg, prt, _ = stocks()
+        proc = HipProcessor(device=0)
+        params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
+                              frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
+        scale = max(H, W) / fw
+        hal, mtf = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3), stencils.mtf_stencil(neg, scale, 0.0, 1.0)
+        be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
+        eager = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=rank, world=world)
+        graphed = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=rank, world=world, graph=True, split_halation=True)
+        assert graphed.graph and graphed.split is not None
+        # per plane: the blue layer (a single halation tap) travels with the MTF's halo only
+        assert graphed.halo_e_ch[2] == (be.mtf_taps[0], be.mtf_taps[1]) and graphed.halo_e_ch[0][0] == be.halation_taps[0] + be.mtf_taps[0]
+        r0, r1 = graphed.plan.r0, graphed.plan.r1
+        img = torch.from_numpy(synthetic_frame(H, W, seed=31)).cuda()[r0:r1].contiguous()
+        out_e = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device="cuda")
+        out_g = torch.empty_like(out_e)
+        frames = []
+        for k, seed in enumerate((SEED, 7, 0xFFFFFFFF, 12345)):
+            eager.render(img, out_f32=out_e, seed=seed)
+            graphed.trace = []
+            graphed.render(img, out_f32=out_g, seed=seed)
+            assert torch.equal(out_g, out_e), (rank, k)
+            if k >= 1:  # captured on the second frame, replayed from then on -- a new seed costs no graph
+                assert graphed.trace == ["exchange_start", "replay:halation_interior", "exchange_finish", "replay:after_exchange"] or \
+                    graphed.trace[:1] == ["exchange_start"] and graphed.trace[-3:] == ["replay:halation_interior", "exchange_finish", "replay:after_exchange"], graphed.trace
+            frames.append(out_g.cpu().numpy().copy())
+        assert [len(v[1]) for v in graphed._graphs.values() if v[1] is not None] == [2]
+        assert not np.array_equal(frames[0], frames[1])  # the seed reaches the grain
+        np.save(f"{path}.{rank}.npy", frames[1])
+        proc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_graph_replay_with_a_new_seed_per_frame_and_the_interior_halation_ahead_of_the_exchange(tmp_path):
+    """world = 2 over gloo on one GPU, graph = True: the interior halation is one captured graph replayed BEFORE the exchange is
+    waited for (it overlaps the host-staged gloo transfer here, RCCL's own stream on a real node), everything downstream a
+    second one; the per-frame seed lives in the device-side frame block, so four seeds replay the same two graphs.  Each frame
+    equals the eager launches bit for bit, and the sharded frame the single-GPU one to an fp32 ulp (FFT windows are anchored
+    per call)."""
+    import torch.multiprocessing as mp
+
+    H, W, fw = 1400, 512, 1400 / 341.33  # 341 px/mm: 87-tap halation (85 non-zero) and 35-tap MTF by FFT; shards of 700 rows, one band each
+    path = str(tmp_path / "graph")
+    mp.spawn(_worker_graph, args=(2, _free_port(), H, W, fw, path), nprocs=2, join=True)
+    sharded = np.concatenate([np.load(f"{path}.{r}.npy") for r in range(2)])
+    from raw2film_amd import HipProcessor
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+
+    neg, prt, _ = stocks()
+    proc = HipProcessor(device=0)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=7, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
+                          frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
+    whole, _ = proc.ctx.render(torch.from_numpy(synthetic_frame(H, W, seed=31)).cuda(), params)
+    whole = whole.cpu().numpy()
+    assert np.max(np.abs(sharded - whole) / np.maximum(np.abs(whole), 1e-3)) <= 2e-6
+    proc.close()
 
 
 def test_two_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
@@ -181,7 +253,7 @@ def test_graph_replay_of_a_frame_is_bit_identical_to_eager_launches():
                           frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
     scale = max(H, W) / fw
     hal, mtf = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3), stencils.mtf_stencil(neg, scale, 0.0, 1.0)
-    be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
+    be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
     eager = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=0, world=1)
     graphed = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=0, world=1, graph=True)
     assert graphed.graph and not eager.graph
@@ -224,7 +296,7 @@ def test_graph_replay_follows_parameter_table_and_buffer_changes():
     params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, **kw)
     scale = max(H, W) / fw
     hal, mtf = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3), stencils.mtf_stencil(neg, scale, 0.0, 1.0)
-    be = HipStageBackend(proc.ctx, params, stencils.vertical_reach(hal), stencils.vertical_reach(mtf))
+    be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
     eager = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=0, world=1)
     graphed = RowShardedRenderer(be, H, W, halation=True, mtf=True, rank=0, world=1, graph=True)
     img = torch.from_numpy(synthetic_frame(H, W, seed=5)).cuda()

@@ -25,6 +25,8 @@ class OracleStageBackend:
         self.p = p
         self.halation_taps = stencils.vertical_reach(p.halation_kernel) if p.halation_kernel is not None else (0, 0)
         self.mtf_taps = stencils.vertical_reach(p.mtf_kernel) if p.mtf_kernel is not None else (0, 0)
+        self.halation_taps_per_channel = (stencils.vertical_reach_per_channel(p.halation_kernel)
+                                          if p.halation_kernel is not None else None)
 
     def empty(self, rows, W):
         return torch.full((3, rows, W), float("nan"), dtype=torch.float32)
@@ -53,13 +55,16 @@ class OracleStageBackend:
         period = max(2 * H - 2, 1)
         rows = np.abs(((rows % period) + period) % period)
         rows = np.where(rows >= H, period - rows, rows)  # reflect-101 on the global frame
-        used = kernel.any(axis=(1, 2))
-        lo, hi = np.nonzero(used)[0][[0, -1]]
-        need = rows[lo:len(rows) - (kernel.shape[0] - 1 - hi)]
-        assert need.min() >= src_gy0 and need.max() < src_gy0 + src.shape[1], "halo rows missing"
         idx = np.clip(rows - src_gy0, 0, src.shape[1] - 1)
         gathered = np.transpose(src.numpy()[:, idx, :], (1, 2, 0))
-        assert not np.isnan(gathered[lo:len(rows) - (kernel.shape[0] - 1 - hi)]).any(), "halo rows were never filled"
+        for c in range(3):  # per plane: a single-tap channel (the halation's blue layer) needs no halo rows of its own
+            used = kernel[..., c if kernel.shape[2] > 1 else 0].any(axis=1)
+            if not used.any():
+                continue
+            lo, hi = np.nonzero(used)[0][[0, -1]]
+            need = rows[lo:len(rows) - (kernel.shape[0] - 1 - hi)]
+            assert need.min() >= src_gy0 and need.max() < src_gy0 + src.shape[1], "halo rows missing"
+            assert not np.isnan(gathered[lo:len(rows) - (kernel.shape[0] - 1 - hi), :, c]).any(), "halo rows were never filled"
         gathered = np.nan_to_num(gathered)
         full = st.convolve_2d(gathered, kernel)
         return full[above:above + (y1 - y0)]
@@ -139,10 +144,22 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
         p, img = _inputs(H, W, scale, **flags)
         be = OracleStageBackend(p)
         rr = sharding.RowShardedRenderer(be, H, W, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None,
-                                         grain=p.grain_lut is not None, burn=bool(p.highlight_burn))
+                                         grain=p.grain_lut is not None, burn=bool(p.highlight_burn), split_halation=True)
+        rr.trace = []
         r0, r1 = rr.plan.r0, rr.plan.r1
         out = torch.zeros((r1 - r0, W, 3), dtype=torch.float32)
         rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
+        if world > 1 and rr.halation and rr.mtf:
+            # one exchange; the blue plane (a single halation tap) travels with the MTF's halo only; the interior halation is
+            # issued while the halos are in flight, the boundary bands after they arrived
+            ha, ma = be.halation_taps[0], be.mtf_taps[0]
+            assert rr.halo_e_ch[0] == (ha + ma, ha + ma) and rr.halo_e_ch[2] == (ma, ma), rr.halo_e_ch
+            if world == 2:
+                assert rr.split is not None
+            if rr.split is not None:
+                assert rr.trace == ["exchange_start", "halation_interior", "exchange_finish", "halation_bands"], rr.trace
+            else:  # (shards too short to have rows that need no halo: one halation call after the exchange)
+                assert rr.trace == ["exchange_start", "exchange_finish"], rr.trace
         gathered = [torch.zeros((b - a, W, 3), dtype=torch.float32) for a, b in sharding.shard_rows(H, world)]
         if world > 1:
             # shards may differ by one row: gather through a padded buffer

@@ -27,9 +27,8 @@ proc = HipProcessor(device=0)
 params = proc.prepare(neg, 6, 0.4, (W, H), seed=20260630, matrix=REC709_TO_XYZ, print_film=prt, halation_green_factor=0.3,
                       exp_kelvin=6000, color_masking=1.0)
 scale = max(H, W) / 36.0
-backend = HipStageBackend(proc.ctx, params,
-                          halation_taps=stencils.vertical_reach(stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)),
-                          mtf_taps=stencils.vertical_reach(stencils.mtf_stencil(neg, scale, 0.0, 1.0)))
+backend = HipStageBackend.for_stencils(proc.ctx, params, stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3),
+                                       stencils.mtf_stencil(neg, scale, 0.0, 1.0))
 frame = synthetic_frame_device(H, W, seed=1234)
 out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 

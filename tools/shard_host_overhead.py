@@ -14,7 +14,7 @@ fw = 36.0
 params = proc.prepare(neg, 6, 0.4, (W, 8192), seed=1, print_film=prt, matrix=REC709_TO_XYZ, halation_green_factor=0.3)
 scale = 12288 / 36
 hal_k = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3); mtf_k = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
-be = HipStageBackend(proc.ctx, params, halation_taps=stencils.vertical_reach(hal_k), mtf_taps=stencils.vertical_reach(mtf_k))
+be = HipStageBackend.for_stencils(proc.ctx, params, hal_k, mtf_k)
 r = RowShardedRenderer(be, H, W, halation=True, mtf=True, grain=True, rank=0, world=1)
 r.backend = TimedBackend(be)
 frame = synthetic_frame_device(H, W); out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")

@@ -1,5 +1,10 @@
-"""Device time of a 1/N row shard of the 100 MP frame on ONE GPU (what each of N GPUs would do between the exchanges),
-eager launches vs HIP graph replay: the measured inputs of DESIGN.md section 5's modelled 1 -> 8 GPU curve.
+"""Device time of a 1/N row shard of the 100 MP frame on ONE GPU (what each of N GPUs would do per frame), eager launches vs HIP
+graph replay: the measured inputs of DESIGN.md section 5's modelled 1 -> 8 GPU curve.
+
+Round 4: the shard measured is a MIDDLE rank's -- RowShardedRenderer(rank = N // 2, world = N) with the exchange itself stubbed out
+(nothing travels: the halo rows keep whatever the buffer held), so the launches are exactly a real rank's: front kernels on the
+own rows, the interior halation, the two boundary bands, the halation of the MTF's halo rows, MTF, tail.  Round 3 measured a
+(rows x W) frame of its own, i.e. left the halo work to the model.
 
     python tools/shard_model.py            # on the GPU box
 """
@@ -7,7 +12,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +21,14 @@ from raw2film_amd.hip_processor import REC709_TO_XYZ  # noqa: E402
 from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer  # noqa: E402
 from raw2film_amd.synthetic import synthetic_frame_device  # noqa: E402
 
+
+class NoTransport(RowShardedRenderer):
+    """A rank whose neighbours never answer: every launch of a real rank, no bytes on any wire."""
+
+    def _exchange(self, buf, buf_gy0, above, below, wait=True):
+        return None
+
+
 W, H = 12288, 8192
 stocks = filmstock.builtin_stocks()
 neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
@@ -24,32 +36,60 @@ proc = HipProcessor(device=0)
 scale = W / 36.0
 hal_k = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
 mtf_k = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
-ha, ma = stencils.vertical_reach(hal_k), stencils.vertical_reach(mtf_k)
-print(f"halo rows: halation {ha}, MTF {ma}; exchange per boundary and direction: {(ha[0] + ma[0]) * W * 3 * 4 / 1e6:.2f} MB")
+params = proc.prepare(neg, 6, 0.4, (W, H), seed=20260630, matrix=REC709_TO_XYZ, print_film=prt, frame_width=36, frame_height=24,
+                      exp_kelvin=6000, color_masking=1.0, halation_green_factor=0.3)
+be = HipStageBackend.for_stencils(proc.ctx, params, hal_k, mtf_k)
+ha, ma = be.halation_taps, be.mtf_taps
+per = be.halation_taps_per_channel
+mb_all = (ha[0] + ma[0]) * W * 3 * 4 / 1e6
+mb_per = sum(a + ma[0] for a, _ in per) * W * 4 / 1e6
+print(f"halo rows: halation {ha} (per plane {per}), MTF {ma}; exchange per boundary and direction: {mb_per:.2f} MB "
+      f"(all planes with the full halo: {mb_all:.2f} MB)")
+SPLIT = {"0": False, "1": True}.get(os.environ.get("R2F_SHARD_SPLIT", "auto"), "auto")  # A/B: 0 = one halation call after the exchange (round 3), 1 = always split
 for n in (1, 2, 4, 8):
-    rows = H // n
-    # a shard in the middle of the frame carries halo rows on both sides: the renderer computes halation for rows + 2 * r_m
-    ext = rows + (2 * (ha[0] + ma[0]) if n > 1 else 0)
-    fh = 36.0 * rows / W  # keep px/mm: frame of `rows` rows at 341.33 px/mm
-    params = proc.prepare(neg, 6, 0.4, (W, rows), seed=20260630, matrix=REC709_TO_XYZ, print_film=prt, frame_width=36, frame_height=fh,
-                          exp_kelvin=6000, color_masking=1.0, halation_green_factor=0.3)
-    be = HipStageBackend(proc.ctx, params, ha, ma)
-    frame = synthetic_frame_device(rows, W, seed=n)
-    out = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
-    res = {}
+    rank = n // 2 if n > 2 else 0
+    res, rr = {}, None
     for graph in (False, True):
-        rr = RowShardedRenderer(be, rows, W, halation=True, mtf=True, rank=0, world=1, graph=graph)
-        for _ in range(3):
-            rr.render(frame, out_f32=out)
+        rr = NoTransport(be, H, W, halation=True, mtf=True, rank=rank, world=n, graph=graph, split_halation=SPLIT)
+        rows = rr.plan.rows
+        frame = synthetic_frame_device(rows, W, seed=n)
+        out = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+        for i in range(3):
+            rr.render(frame, out_f32=out, seed=100 + i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         iters = 10
-        for _ in range(iters):
-            rr.render(frame, out_f32=out)
+        for i in range(iters):
+            rr.render(frame, out_f32=out, seed=200 + i)
         t_host = (time.perf_counter() - t0) / iters * 1e3
         torch.cuda.synchronize()
         t_all = (time.perf_counter() - t0) / iters * 1e3
         res[graph] = (t_all, t_host)
-        del rr
-    print(f"N = {n}: shard {W} x {rows}: eager {res[False][0]:.3f} ms/frame (host issue {res[False][1]:.3f}), "
-          f"graph replay {res[True][0]:.3f} ms/frame (host issue {res[True][1]:.3f})  -> ideal {5.6 / n:.2f}")
+        split, dl, dh = rr.split, rr.d_lo, rr.d_hi
+        del rr, frame, out
+    what = (f"halation rows [{dl}, {dh}) as interior [{split[0]}, {split[1]}) + bands" if split else f"halation rows [{dl}, {dh}) in one call")
+    print(f"N = {n}: rank {rank}, shard {W} x {rows} ({what}): eager {res[False][0]:.3f} ms/frame (host issue {res[False][1]:.3f}), "
+          f"graph replay {res[True][0]:.3f} ms/frame (host issue {res[True][1]:.3f})  -> 1/N of the N = 1 time would be {res[True][0] if n == 1 else base / n:.3f}")
+    if n == 1:
+        base = res[True][0]
+for which, name in ((0, "halation"), (1, "MTF")):
+    print(name, "windows of the last call:", [c["window"] for c in proc.ctx.stencil_stats(which)])
+
+# ... and round 3's measure for comparison: a (rows x W) frame of its own (no halo rows, one halation call)
+for n in (8,):
+    rows = H // n
+    fh = 36.0 * rows / W
+    params1 = proc.prepare(neg, 6, 0.4, (W, rows), seed=20260630, matrix=REC709_TO_XYZ, print_film=prt, frame_width=36, frame_height=fh,
+                           exp_kelvin=6000, color_masking=1.0, halation_green_factor=0.3)
+    be1 = HipStageBackend.for_stencils(proc.ctx, params1, hal_k, mtf_k)
+    rr = RowShardedRenderer(be1, rows, W, halation=True, mtf=True, rank=0, world=1, graph=True)
+    frame = synthetic_frame_device(rows, W, seed=n)
+    out = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+    for i in range(3):
+        rr.render(frame, out_f32=out, seed=i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        rr.render(frame, out_f32=out, seed=10 + i)
+    torch.cuda.synchronize()
+    print(f"a {W} x {rows} frame of its own (round 3's measure), graph replay: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms/frame")
