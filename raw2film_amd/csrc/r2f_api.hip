@@ -40,6 +40,7 @@ struct StencilSet {
     bool common_box = false;
     DevStencil dev[3];
     plan::StencilGeom geom[3];  // the host-side geometry dev[] was filled from
+    bool mixed_sign[3] = {false, false, false};  // the channel has taps of both signs (set by r2f_set_kernel)
     DeviceBuf wbuf[3], mbuf[3];
 };
 
@@ -409,7 +410,14 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     const int bh = b[1] - b[0] + 1, bw = b[3] - b[2] + 1;
     // up to 400 taps a side: a 512-point window then still yields 113 x 112 outputs (boxes over 200 taps on an axis take the
     // 512-point window there, see fft_window)
-    if (!(bh <= kFftMaxTaps && bw <= kFftMaxTaps && bh * bw >= ctx->opt_fft_min_taps)) return false;
+    if (!(bh <= kFftMaxTaps && bw <= kFftMaxTaps)) return false;
+    // A channel with taps of BOTH signs (the unsharp-masked MTF kernel, effects.py:179-183 with sharpening_strength > 0) cancels:
+    // a float32 sum is accurate relative to sum |w x|, not to the result -- 4-8 ulp of a density, which a stepped grain LUT or a
+    // steep output LUT then multiplies (found by the round-4 fuzz criterion against the float64 evaluation: one case of 1 100 at
+    // 1.46 x its bound).  Such a channel takes the float64 FFT form whatever its size, on complex128 scratch (run_stencil_fft):
+    // one rounding, like the oracle's.  Preview-scale unsharp masking is rare and its frames are small; the headline has none.
+    if (s.mixed_sign[c]) return true;
+    if (bh * bw < ctx->opt_fft_min_taps) return false;
     // square mirror-symmetric stencils up to 23 x 23 are faster in the unrolled direct form (needs the device form: callers
     // run ensure_stencil first)
     const int which = (int)(&s - ctx->stencil);
@@ -505,6 +513,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     }
     a.y0 = y0, a.y1 = y1, a.W = W, a.H_global = H;
     a.s32 = ((ctx->opt_fft_s96 >> which) & 1) ? 2 : ((ctx->opt_fft_s32 >> which) & 1);
+    for (int i = 0; i < nch; ++i)
+        if (set.mixed_sign[chans[i]]) a.s32 = 0;  // cancelling taps: no float32 rounding between the passes either
     const plan::FftBatches fb = plan::fft_batches(fo, ny, nx, bh, bw, W, y0, y1, nch, a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));
     a.gx = fb.gx;
     a.ntiles = fb.ntiles;
@@ -916,6 +926,14 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.kw = kw;
     s.kc = kc;
     s.host.assign(k, k + (size_t)kh * kw * kc);
+    for (int c = 0; c < 3; ++c) {
+        bool pos = false, neg = false;
+        for (size_t i = 0; i < (size_t)kh * kw; ++i) {
+            const float v = k[i * kc + (kc == 1 ? 0 : c)];
+            pos = pos || v > 0.f, neg = neg || v < 0.f;
+        }
+        s.mixed_sign[c] = pos && neg;
+    }
     ++ctx->generation;
     s.built_q = 0;
     for (int c = 0; c < 3; ++c) {

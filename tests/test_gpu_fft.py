@@ -73,11 +73,21 @@ def test_eligibility_limits(ctx):
     img = np.random.default_rng(1).uniform(0, 1, (140, 150, 3)).astype(np.float32)
     rng = np.random.default_rng(2)
     for n, expect in ((19, 0), (21, 1), (129, 1), (171, 1), (199, 1), (201, 1)):  # >= 400 taps (and at most 400 x 400, below)
-        k = rng.uniform(-0.2, 1.0, (n, n, 1)).astype(np.float32)
+        k = rng.uniform(0.01, 1.0, (n, n, 1)).astype(np.float32)
         k /= k.sum()
         out = run(ctx, 1, img, k, 1)
         assert uses_fft(ctx, 1) == [expect] * 3, n
         assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-5, 1e-3, f"{n} taps")
+    # taps of both signs cancel: such a channel takes the float64 form on complex128 scratch whatever its size (a
+    # float32 sum would be accurate relative to sum |w x| only), and meets the FFT form's own tolerance, five times under the contract's
+    for shape in ((1, 3), (3, 3), (5, 9), (17, 17), (19, 19)):
+        k = rng.uniform(-1.0, 1.0, shape + (1,)).astype(np.float32)
+        k[shape[0] // 2, shape[1] // 2, 0] += 3.0  # (an unsharp mask: a strong centre among cancelling neighbours)
+        k /= k.sum()
+        out = run(ctx, 1, img, k, 1)
+        assert uses_fft(ctx, 1) == [1, 1, 1], shape
+        assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 2e-6, 1e-3, f"mixed-sign {shape}")  # (as tight as the large kernels of the FFT form)
+
     # rectangular boxes count too
     k = np.zeros((87, 87, 1), np.float32)
     k[42:45, :, 0] = rng.uniform(0, 1, (3, 87))  # 3 x 87 = 261 taps: direct

@@ -87,11 +87,20 @@ def test_random_configuration(ctx, c):
     if c["nr"]:
         t, layout = ctx.chroma_nr(t, c["nr"], layout=layout), "chw"
     out, u8 = ctx.render(t, params, want_f32=True, want_u8=True, layout=layout)
-    # chroma NR divides by the (blurred) y chromaticity: a 2e-6 difference there is amplified in X and Z
-    # hostile tables: the contract's 1e-5 is met by the fixed battery (tests/test_gpu_hostile.py) and by 360 of 367 hostile cases
-    # of three soaks (R2F_FUZZ_CASES=600 R2F_FUZZ_SEED=11; 200 / R2F_FUZZ_BIG=4 / seed 5; 300 / seed 7); the other seven reach
-    # 1.06e-5 .. 1.24e-5 -- noisy texels next to the 3-D LUT's fall-off multiply one ulp of density by up to twice what a smooth
-    # print LUT does -- hence 1.5e-5 for those cases only (all 1 100 cases pass at that)
-    tol = 3e-5 if c["nr"] else (1.5e-5 if c["tables"] else 1e-5)
-    assert_close(out.cpu().numpy(), ref, tol, 1e-3, str(c))
+    got = out.cpu().numpy()
+    if c["nr"] or c["tables"]:
+        # No tolerance exceptions: hostile tables and the chroma NR (which divides by the blurred y
+        # chromaticity) amplify one ulp of an intermediate -- for the float32 oracle exactly as for the device.  The float64
+        # evaluation of the same formulas on the same inputs (oracle/truth.py) tells the two apart: the kernels may sit as far
+        # from it as the contract allows PLUS as far as the oracle itself does, and not a bit further.
+        from oracle import truth
+
+        exact = truth.render(src if c["nr"] else img, p, chroma_nr=c["nr"])  # (with chroma NR the matrix was applied up front)
+        slack = np.abs(ref.astype(np.float64) - exact)
+        bound = 1e-5 * np.maximum(np.abs(exact), 1e-3) + slack
+        worst = float(np.max(np.abs(got.astype(np.float64) - exact) / bound))
+        assert worst <= 1.0, f"|hip - truth| reaches {worst:.3f} x (1e-5 max(|truth|, 1e-3) + |oracle - truth|): {c}"
+    else:
+        assert_close(got, ref, 1e-5, 1e-3, str(c))
     assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1
+

@@ -256,7 +256,7 @@ def test_small_square_stencils_unrolled_direct_form(ctx, n, epilogue):
     per-channel taps, with and without the halation epilogue, on row ranges with halo rows of any origin."""
     rng = np.random.default_rng(100 + n)
     H, W = 150, 203
-    k = rng.uniform(-0.05, 1.0, (n, n, 3)).astype(np.float32)
+    k = rng.uniform(0.0, 1.0, (n, n, 3)).astype(np.float32)  # (one sign: taps of both signs take the float64 FFT form whatever their size)
     k = (k + k[:, ::-1]) / 2
     k /= k.sum(axis=(0, 1), keepdims=True)
     img = rng.uniform(0.01, 2.0, (H, W, 3)).astype(np.float32)

@@ -170,3 +170,37 @@ def test_burn_only_touches_highlights_and_uses_green():
     assert (out >= 0).all()
     cell, h_lo, w_lo = st.burn_geometry(60, 90, 10.0)
     assert (cell, h_lo, w_lo) == (6, 10, 15)
+
+
+def test_float64_truth_evaluation_agrees_with_the_float32_oracle_on_smooth_tables():
+    """oracle/truth.py (the fuzz criterion's third party: the same formulas in float64 throughout) against oracle.stages on the
+    stand-in stocks: the float32 oracle is within a few float32 roundings of it, stage by stage and end to end -- which is what
+    makes |oracle - truth| a measure of table roughness in tests/test_gpu_fuzz.py and nothing else."""
+    from oracle import truth
+
+    neg, prt, bw = stocks()
+    H, W = 72, 104
+    img = synthetic_frame(H, W, seed=3)
+    for stock, kw in ((neg, {}), (neg, dict(grain=1)), (bw, {}), (neg, dict(halation=False, mtf=False, grain=0))):
+        p = oracle_inputs(stock, prt, 200.0, **kw)
+        ref, exact = st.render(img, p), truth.render(img, p)
+        assert exact.dtype == np.float64
+        assert np.max(np.abs(ref - exact) / np.maximum(np.abs(exact), 1e-3)) <= 3e-6
+    p = oracle_inputs(neg, prt, 200.0)
+    p.highlight_burn, p.burn_scale, p.d_ref = 0.6, 20.0, float(neg.d_ref[1])
+    assert np.max(np.abs(st.render(img, p) - truth.render(img, p)) / np.maximum(np.abs(truth.render(img, p)), 1e-3)) <= 3e-6
+    # chroma NR ahead of the path (on XYZ): the division by the blurred chromaticity costs the float32 oracle more
+    p = oracle_inputs(neg, prt, 200.0, matrix=False)
+    xyz = st.apply_matrix3x3(img, st.REC709_TO_XYZ)
+    a, b = st.render(st.chroma_nr_filter(xyz, 2), p), truth.render(xyz, p, chroma_nr=2)
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= 3e-5
+    # per stage, float32 inputs on both sides
+    x = st.apply_2d_lut(xyz, p.lut_2d)
+    assert np.max(np.abs(x - truth.apply_2d_lut(xyz, p.lut_2d)) / np.maximum(np.abs(x), 1e-4)) <= 2e-6
+    d = st.multi_channel_interp(st.log_clip(x), p.lut_1d)
+    assert np.max(np.abs(d - truth.multi_channel_interp(truth.log_clip(x), p.lut_1d))) <= 2e-6
+    o = st.apply_lut_tetrahedral(d, p.lut_3d, 0.25)
+    assert np.max(np.abs(o - truth.apply_lut_tetrahedral(d, p.lut_3d, 0.25))) <= 2e-7
+    assert np.max(np.abs(st.apply_lut_trilinear(d, p.lut_3d) - truth.apply_lut_trilinear(d, p.lut_3d))) <= 2e-7
+    g = st.apply_grain(d, p.grain_lut, p.grain_kernel, 77)
+    assert np.max(np.abs(g - truth.apply_grain(d, p.grain_lut, p.grain_kernel, 77))) <= 2e-6
