@@ -6,9 +6,16 @@
 //   mode 3: random texels of a table held in LDS (ds_read_b128)
 //   mode 4: random 8-byte gathers (global)
 //   mode 5: mode 0 with nontemporal loads (global_load_dwordx4 ... nt)
+// Round 4: the tetrahedral 3-D LUT's access pattern itself, texel-major against a CELL-MAJOR copy:
+//   cell_kernel<false>: a pixel = 4 corners of one cell of an n^3 texel table (c000, c100, c110, c111: 4 different 128-byte lines)
+//   cell_kernel<true>:  a pixel = 4 of the 8 corners of one cell of a cell-major copy (8 x 16 B = ONE 128-byte line per cell;
+//                       (n - 1)^3 x 128 B: 4 MB for n = 33 against 575 KB)
+// each with cells drawn uniformly from the table and from a hot set of 300 cells (the benchmark frame's densities are strongly
+// correlated and cover a few hundred cells).
 // Prints wave-instructions per microsecond per CU and lanes per clock per CU (at the reported clock).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -52,6 +59,52 @@ __global__ __launch_bounds__(512) void gather_kernel(const float4* __restrict__ 
     if (acc == 1.2345e30f) out[0] = acc;
 }
 
+template <bool CELL_MAJOR>
+__global__ __launch_bounds__(512) void cell_kernel(const float4* __restrict__ table, int n, unsigned hot, int iters, float* out) {
+    const int tid = threadIdx.x;
+    unsigned s = (blockIdx.x * blockDim.x + tid) * 2654435761u + 12345u;
+    const unsigned cells = (unsigned)(n - 1) * (n - 1) * (n - 1);
+    float acc = 0.f;
+    for (int it = 0; it < iters; it += 2) {  // two pixels' gathers in flight together, like the tail kernel
+        float4 v[8];
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            unsigned cell = rnd(s) % (hot ? hot : cells);
+            if (hot) cell = (cell * 2654435761u) % cells;  // the hot cells are scattered over the table
+            const unsigned r = cell / ((n - 1) * (n - 1)), g = (cell / (n - 1)) % (n - 1), b = cell % (n - 1);
+            if (CELL_MAJOR) {
+                const float4* c = table + (size_t)cell * 8;
+                v[4 * px] = c[0], v[4 * px + 1] = c[4], v[4 * px + 2] = c[6], v[4 * px + 3] = c[7];
+            } else {
+                const float4* c = table + ((size_t)r * n + g) * n + b;
+                v[4 * px] = c[0], v[4 * px + 1] = c[(size_t)n * n], v[4 * px + 2] = c[(size_t)n * n + n], v[4 * px + 3] = c[(size_t)n * n + n + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    if (acc == 1.2345e30f) out[0] = acc;
+}
+
+template <bool CELL_MAJOR>
+void run_cells(const char* name, const float4* table, int n, unsigned hot, float* out) {
+    const int iters = 256, blocks = 256 * 4, threads = 512;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(cell_kernel<CELL_MAJOR>, dim3(blocks), dim3(threads), 0, 0, table, n, hot, iters, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double px = (double)blocks * threads * iters;
+    printf("%-58s %7.3f ms  %7.2f G pixels/s  = %5.2f lane-gathers/clk/CU at 2.1 GHz  (24 MP: %.3f ms)\n", name, ms, px / ms * 1e-6,
+           4.0 * px / (ms * 1e-3) / 256 / 2.1e9, 24e6 / (px / ms));
+}
+
 template <int MODE>
 void run(const char* name, const float4* table, unsigned texels, float* out) {
     const int iters = 512, blocks = 256 * 4, threads = 512;
@@ -89,6 +142,22 @@ int main() {
         run<5>("global 16 B, random, nontemporal (nt)", d, texels, out);
         if (texels * 16 <= 128 * 1024) run<3>("LDS 16 B (ds_read_b128), random texel per lane", d, texels, out);
         hipFree(d);
+    }
+    {   // the tetrahedral pattern: texel-major 33^3 against a cell-major copy of it
+        const int n = 33;
+        const size_t texels = (size_t)n * n * n, cell_floats4 = (size_t)(n - 1) * (n - 1) * (n - 1) * 8;
+        std::vector<float4> h(std::max(texels, cell_floats4), make_float4(1, 2, 3, 4));
+        float4 *dt, *dc;
+        hipMalloc(&dt, texels * sizeof(float4));
+        hipMalloc(&dc, cell_floats4 * sizeof(float4));
+        hipMemcpy(dt, h.data(), texels * sizeof(float4), hipMemcpyHostToDevice);
+        hipMemcpy(dc, h.data(), cell_floats4 * sizeof(float4), hipMemcpyHostToDevice);
+        run_cells<false>("texel-major 33^3 (575 KB), 4 corners, cells uniform", dt, n, 0, out);
+        run_cells<true>("cell-major 32^3 x 128 B (4 MB), 4 of 8 corners, uniform", dc, n, 0, out);
+        run_cells<false>("texel-major 33^3, 4 corners, 300 hot cells", dt, n, 300, out);
+        run_cells<true>("cell-major, 4 of 8 corners, 300 hot cells", dc, n, 300, out);
+        hipFree(dt);
+        hipFree(dc);
     }
     return 0;
 }
