@@ -99,6 +99,7 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
+    int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
     int lanczos_key[4] = {0, 0, 0, 0};
@@ -520,6 +521,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.ntiles = fb.ntiles;
     a.ppc = fb.ppc;
     a.epilogue = epilogue;
+    a.epi_lds = ctx->opt_fft_epi_lds;
     a.curve = ctx->curve;
     a.log_eps = log_eps;
     a.vec4 = planes_vec_ok(dst, W) ? 1 : 0;
@@ -838,6 +840,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_epilogue_lds")) {
+        ctx->opt_fft_epi_lds = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_scratch96")) {

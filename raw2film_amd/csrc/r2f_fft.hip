@@ -485,6 +485,17 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
     const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
     const char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
+    // The epilogue's curve cells: 32 divergent 16-byte gathers per lane.  From global memory they go through the texture path at
+    // 0.9 lanes per clock and CU (profiles/r02_gather_rate.txt) -- more of its cycles than all of the pass's coalesced scratch
+    // loads and stores; from LDS at 4.3.  The workgroup's channel has (m - 1) cells of 16 bytes: copied behind the transpose
+    // buffers when they fit (a.epi_lds_off, in doubles; 0 = gather from global memory).
+    float4* cells_lds = reinterpret_cast<float4*>(fsm + a.epi_lds_off);
+    if (EPI && a.epi_lds_off) {
+        const int gp0 = a.pair0 + pair, ch0 = a.chan[gp0 / a.ppc];
+        const float4* src_cells = a.curve.cells + (long long)ch0 * (a.curve.m - 1);
+        for (int i = threadIdx.x; i < a.curve.m - 1; i += kFftThreads) cells_lds[i] = src_cells[i];
+        __syncthreads();
+    }
     cplx v[16];
     if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
@@ -522,7 +533,10 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
                 float ob[CB];
 #pragma unroll
                 for (int q = 0; q < CB; ++q) ob[q] = log10_fast(o[CB * b + q], a.log_eps);
-                curve_eval_batch<CB, 1>(a.curve.cells, a.curve, ch, ob);
+                if (a.epi_lds_off)
+                    curve_eval_batch<CB, 1>((const float4*)cells_lds - (long long)ch * (a.curve.m - 1), a.curve, ch, ob);  // (ch-relative base)
+                else
+                    curve_eval_batch<CB, 1>(a.curve.cells, a.curve, ch, ob);
 #pragma unroll
                 for (int q = 0; q < CB; ++q) o[CB * b + q] = ob[q];
             }
@@ -615,15 +629,24 @@ hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
 }
 
 template <int XL, bool EPI>
-static void launch_rows_inv(const FftConvArgs& a, hipStream_t s) {
+static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
     const int rows = RowGeom<XL>::ROWS;
-    const dim3 grid((a.vy + rows - 1) / rows, a.npairs);  // rows beyond the valid outputs are never stored
+    const dim3 grid((a0.vy + rows - 1) / rows, a0.npairs);  // rows beyond the valid outputs are never stored
+    FftConvArgs a = a0;
+    size_t lds = fft_lds_bytes();
+    a.epi_lds_off = 0;
+    // the epilogue's curve cells behind the transpose buffers, while three workgroups still fit a CU (the kernel's registers allow
+    // three waves per SIMD): up to 1 152 cells (18 KB) -- a 1 024-point curve; longer curves gather from global memory
+    if (EPI && a0.epi_lds && (size_t)(a.curve.m - 1) * sizeof(float4) + lds <= 53 * 1024) {
+        a.epi_lds_off = (int)(lds / sizeof(double));
+        lds += (size_t)(a.curve.m - 1) * sizeof(float4);
+    }
     if (a.s32 == 1)
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 1>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 1>), grid, dim3(kFftThreads), lds, s, a);
     else if (a.s32 == 2)
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 2>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 2>), grid, dim3(kFftThreads), lds, s, a);
     else
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 0>), grid, dim3(kFftThreads), fft_lds_bytes(), s, a);
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 0>), grid, dim3(kFftThreads), lds, s, a);
 }
 
 template <int XL>

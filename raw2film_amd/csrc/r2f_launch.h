@@ -191,6 +191,8 @@ struct FftConvArgs {
     DevCurve curve;
     float log_eps;
     int vec4;                 // 1: vx % 4 == 0, W % 4 == 0 and dst planes 16-byte aligned -> float4 stores in pass 3
+    int epi_lds;              // pass 3 with the epilogue: 1 = the channel's curve cells may be copied to LDS (A/B knob)
+    int epi_lds_off;          // set by the launcher: offset (in doubles) of those cells in the dynamic LDS, 0 = gather from global memory
 };
 hipError_t fft_init_attributes();
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s);
