@@ -303,7 +303,7 @@ class HipProcessor:
                 canvas_ratio=1.0, halation_intensity=1.0, halation=True, halation_size=1.0, halation_green_factor=0.4,
                 sharpness=True, sharpening_strength=0.0, sharpening_sigma=1.0, chroma_nr=0, grain=2,
                 highlight_burn=0.0, burn_scale=50.0, half_size=True, cache=True, color_masking=None, max_scale=400.0,
-                seed=None, exposure=None, metadata=None, **_):
+                seed=None, exposure=None, metadata=None, src_version=None, **_):
         """Load (decoded) frame and render it: np.uint8 (H, W, 3), like cpu_processor.py:414 -- including the CPU processor's
         last step, resolution_scaling of the finished (canvas-framed) frame to the requested resolution (cpu_processor.py:411-412).
         With `dst_texture` (a uint8 (h, w, 4) CUDA tensor standing in for the preview widget's wgpu texture) the call behaves
@@ -311,7 +311,11 @@ class HipProcessor:
         device, `histogram_texture` (same kind of tensor) receives the histogram image, and None is returned.
         A uint16 `src` is LibRaw's 16-bit output before raw_to_linear's last two lines (raw_conversion.py:50-52): those run on
         the device with the auto exposure measured on the host (`metadata`: the EXIF dict calc_exposure reads) or given in stops
-        (`exposure`)."""
+        (`exposure`).
+        An array `src` that is the array of the previous call is taken for the same frame when a fingerprint of it agrees (shape,
+        dtype, address and a checksum of up to 32 evenly spaced rows -- an edit confined to other rows is NOT seen: pass
+        cache=False after a partial in-place edit, or `src_version`, any hashable token of the caller's that changes whenever
+        the buffer's content does and then replaces the checksum)."""
         if dst_texture is not None:
             self._check_texture(dst_texture, "dst_texture")
         if histogram_texture is not None:
@@ -321,6 +325,7 @@ class HipProcessor:
         self.load_image_texture(
             src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
             half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
+            src_version=src_version,
         )
         image, layout, payload = self._texture
         out_u8 = self._render_prepared(
@@ -340,14 +345,23 @@ class HipProcessor:
 
     def load_image_texture(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24, rotation=0.0,
                            zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True, cache=True, chroma_nr=0,
-                           max_scale=400.0, canvas_mode="No", canvas_scale=1.0, canvas_ratio=1.0, exposure=None, metadata=None):
+                           max_scale=400.0, canvas_mode="No", canvas_scale=1.0, canvas_ratio=1.0, exposure=None, metadata=None,
+                           src_version=None):
         """GpuProcessor.load_image_texture (gpu_processor.py:655-719): prepare and upload the frame unless the load parameters
         are those of the frame that is already on the device.  A path compares by value like upstream's `src`.  An array
         compares by identity AND by a fingerprint of its content (shape, dtype, address, a checksum of up to 32 evenly spaced
-        rows), so a decode buffer that was refilled or edited in place is uploaded again; the processor holds the array by weak
-        reference only (upstream's cache never sees arrays: this is this backend's own rule, kept conservative)."""
+        rows), so a decode buffer that was refilled is uploaded again -- a SAMPLE: an in-place edit that touches none of the sampled
+        rows is not seen.  `src_version` (any hashable token that the caller changes with the content) replaces the
+        checksum and saves its ~5 MB pass per call; `cache=False` always uploads.  The processor holds the array by weak reference
+        only (upstream's cache never sees arrays: this is this backend's own rule, kept conservative)."""
+        if isinstance(src, str):
+            src_key = src
+        elif src_version is not None:
+            src_key = (getattr(src, "shape", None), str(getattr(src, "dtype", "")), "version", src_version)
+        else:
+            src_key = self._array_fingerprint(src)
         new_param_dict = {
-            "src": src if isinstance(src, str) else self._array_fingerprint(src), "cam": cam, "lens": lens,
+            "src": src_key, "cam": cam, "lens": lens,
             "lens_correction": lens_correction,
             "frame_width": frame_width, "frame_height": frame_height, "rotation": rotation, "zoom": zoom,
             "rotate_times": rotate_times, "flip": flip, "resolution": resolution, "half_size": half_size, "chroma_nr": chroma_nr,

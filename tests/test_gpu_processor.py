@@ -424,6 +424,17 @@ def test_the_frame_stays_on_the_device_between_renders_with_the_same_load_parame
     e3 = proc.process(img2, neg, 6, 0.4, cache=False, **kw)  # cache=False always loads
     assert len(calls) == 6
     np.testing.assert_array_equal(e3, e2)
+    # a caller-supplied version token replaces the sampled checksum (an edit confined to unsampled rows is not seen by
+    # the checksum -- one row of a tall frame here): same token -> the cached frame, new token -> uploaded again
+    tall = rng.uniform(0.0, 1.0, (200, 64, 3)).astype(np.float32)
+    n0 = len(calls)
+    f1 = proc.process(tall, neg, 6, 0.4, src_version=1, **kw)
+    tall[3] *= 0.25  # row 3 is not among the 32 sampled rows (every 6th)
+    f2 = proc.process(tall, neg, 6, 0.4, src_version=1, **kw)
+    assert len(calls) == n0 + 1
+    np.testing.assert_array_equal(f1, f2)  # (the documented limit: the caller said "unchanged")
+    f3 = proc.process(tall, neg, 6, 0.4, src_version=2, **kw)
+    assert len(calls) == n0 + 2 and not np.array_equal(f3, f1)
     # the processor does not keep the host frame alive
     import gc
     import weakref
