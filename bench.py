@@ -54,7 +54,8 @@ def source_hash() -> str:
     """sha256 over the HIP sources and the C header: ties a committed PMC capture to the code that was profiled."""
     h = hashlib.sha256()
     for rel in ("raw2film_amd/csrc/r2f_device.h", "raw2film_amd/csrc/r2f_launch.h", "raw2film_amd/csrc/r2f_kernels.hip",
-                "raw2film_amd/csrc/r2f_fft.hip", "raw2film_amd/csrc/r2f_fft_math.h", "raw2film_amd/csrc/r2f_front.hip", "raw2film_amd/csrc/r2f_post.hip", "raw2film_amd/csrc/r2f_api.hip", "include/r2f.h"):
+                "raw2film_amd/csrc/r2f_fft.hip", "raw2film_amd/csrc/r2f_fft_math.h", "raw2film_amd/csrc/r2f_front.hip", "raw2film_amd/csrc/r2f_post.hip", "raw2film_amd/csrc/r2f_api.hip", "raw2film_amd/csrc/r2f_plan.cpp",
+                "raw2film_amd/csrc/r2f_plan.h", "include/r2f.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

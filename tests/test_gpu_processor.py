@@ -429,7 +429,7 @@ def test_the_frame_stays_on_the_device_between_renders_with_the_same_load_parame
     tall = rng.uniform(0.0, 1.0, (200, 64, 3)).astype(np.float32)
     n0 = len(calls)
     f1 = proc.process(tall, neg, 6, 0.4, src_version=1, **kw)
-    tall[3] *= 0.25  # row 3 is not among the 32 sampled rows (every 6th)
+    tall[99] *= 0.25  # row 99 is not among the 32 sampled rows (every 6th) and lies inside the 3:2 crop
     f2 = proc.process(tall, neg, 6, 0.4, src_version=1, **kw)
     assert len(calls) == n0 + 1
     np.testing.assert_array_equal(f1, f2)  # (the documented limit: the caller said "unchanged")
