@@ -531,9 +531,13 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #pragma unroll
             for (int b = 0; b < 16 / CB; ++b) {
                 float ob[CB];
+#ifndef R2F_FFT_EPI_ABLATE
+#define R2F_FFT_EPI_ABLATE 0  // development switch: 1 no curve (log only), 2 no log (curve only), 4 one-instruction stand-in for both
+#endif
 #pragma unroll
-                for (int q = 0; q < CB; ++q) ob[q] = log10_fast(o[CB * b + q], a.log_eps);
-                if (a.epi_lds_off)
+                for (int q = 0; q < CB; ++q) ob[q] = (R2F_FFT_EPI_ABLATE & 6) ? o[CB * b + q] * 0.5f : log10_fast(o[CB * b + q], a.log_eps);
+                if (R2F_FFT_EPI_ABLATE & 5) {
+                } else if (a.epi_lds_off)
                     curve_eval_batch<CB, 1>((const float4*)cells_lds - (long long)ch * (a.curve.m - 1), a.curve, ch, ob);  // (ch-relative base)
                 else
                     curve_eval_batch<CB, 1>(a.curve.cells, a.curve, ch, ob);

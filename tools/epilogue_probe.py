@@ -13,6 +13,10 @@ sys.path.insert(0, ROOT)
 from raw2film_amd import HipProcessor, filmstock, stencils  # noqa: E402
 from raw2film_amd.hip_processor import REC709_TO_XYZ  # noqa: E402
 
+if "--lib" in sys.argv:  # a development build of the library (tools/_var/...), e.g. with -DR2F_FFT_EPI_ABLATE=n
+    from raw2film_amd import _lib
+
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 W, H = 12288, 8192
 stocks = filmstock.builtin_stocks()
 neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
