@@ -146,3 +146,55 @@ def test_stage_calls_write_their_own_seed_unless_told_the_block_is_resident():
     ctx.stage_tail(D, resident, out_f32=o3, y0=0, y1=H, H_global=H)
     assert torch.equal(o3, o2)
     proc.close()
+
+
+def test_replay_on_a_side_stream_with_burn_uint8_output_and_planar_input():
+    """The graph is captured on a stream of the context's own and launched on whatever stream the caller is on (here a torch side
+    stream); the highlight burn's extra stages (grain to planes, cell sums, map, tail with the map) are part of it; uint8-only
+    output and a planar (3, H, W) input are keys like any other."""
+    from raw2film_amd import HipProcessor
+
+    H, W = 180, 240
+    neg, kw = _settings(H, W, 0.9)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=21)).cuda().permute(2, 0, 1).contiguous()  # (3, H, W)
+    ref = HipProcessor(device=0)
+    ref.ctx.set_option("render_graph", 0)
+    proc = HipProcessor(device=0)
+    side = torch.cuda.Stream()
+    seeds = [3, 4, 5, 6]
+    out_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    for s in seeds:
+        p_ref = ref.prepare(neg, 6, 0.4, (W, H), seed=s, highlight_burn=0.6, burn_scale=20.0, **kw)
+        assert p_ref.flags & 32
+        _, want = ref.ctx.render(frame, p_ref, want_f32=False, want_u8=True, layout="chw")
+        with torch.cuda.stream(side):
+            params = proc.prepare(neg, 6, 0.4, (W, H), seed=s, highlight_burn=0.6, burn_scale=20.0, **kw)
+            proc.ctx.render(frame, params, out_u8=out_u8, want_f32=False, layout="chw")
+        side.synchronize()
+        assert torch.equal(out_u8, want), s
+    stats = proc.ctx.render_stats()
+    assert stats["replays"] == 3 and stats["captures"] == 1 and stats["eager"] == 1, stats
+    ref.close()
+    proc.close()
+
+
+def test_more_than_eight_buffer_sets_evict_the_least_recently_used_graph():
+    from raw2film_amd import HipProcessor
+
+    H, W = 96, 160
+    neg, kw = _settings(H, W, 0.5)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=2)).cuda()
+    proc = HipProcessor(device=0)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=1, matrix=_rec709(), **kw)
+    outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(10)]
+    proc.ctx.render(frame, params, out_f32=outs[0])  # eager: the structure is warm from here on
+    for o in outs:  # ten distinct buffer sets: ten captures, the two oldest evicted on the way
+        proc.ctx.render(frame, params, out_f32=o)
+    s = proc.ctx.render_stats()
+    assert s["captures"] == 10 and s["dropped"] == 2 and s["replays"] == 10, s
+    proc.ctx.render(frame, params, out_f32=outs[9])  # still cached
+    proc.ctx.render(frame, params, out_f32=outs[0])  # evicted: captured again
+    s = proc.ctx.render_stats()
+    assert s["captures"] == 11 and s["replays"] == 12, s
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    proc.close()
