@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 // at 2 waves per SIMD; 4 fits 3 waves per SIMD without spills and is the faster one (halation 2.46 -> 2.43 ms at 100 MP)
 #define R2F_FFT_CURVE_BATCH 4
 #endif
-template <int XL, bool EPI, int ST>
+template <int XL, int EPI, int ST>
 __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* fsm) {
     typedef RowGeom<XL> G;
     constexpr int NX = G::NX, LPL = G::LPL;
@@ -490,7 +490,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     // loads and stores; from LDS at 4.3.  The workgroup's channel has (m - 1) cells of 16 bytes: copied behind the transpose
     // buffers when they fit (a.epi_lds_off, in doubles; 0 = gather from global memory).
     float4* cells_lds = reinterpret_cast<float4*>(fsm + a.epi_lds_off);
-    if (EPI && a.epi_lds_off) {
+    if (EPI == 2) {
         const int gp0 = a.pair0 + pair, ch0 = a.chan[gp0 / a.ppc];
         const float4* src_cells = a.curve.cells + (long long)ch0 * (a.curve.m - 1);
         for (int i = threadIdx.x; i < a.curve.m - 1; i += kFftThreads) cells_lds[i] = src_cells[i];
@@ -537,8 +537,8 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #pragma unroll
                 for (int q = 0; q < CB; ++q) ob[q] = (R2F_FFT_EPI_ABLATE & 6) ? o[CB * b + q] * 0.5f : log10_fast(o[CB * b + q], a.log_eps);
                 if (R2F_FFT_EPI_ABLATE & 5) {
-                } else if (a.epi_lds_off)
-                    curve_eval_batch<CB, 1>((const float4*)cells_lds - (long long)ch * (a.curve.m - 1), a.curve, ch, ob);  // (ch-relative base)
+                } else if (EPI == 2)
+                    curve_eval_near_lds<CB>((const float4*)cells_lds, a.curve, a.curve.f_first[ch], a.curve.f_last[ch], ob);
                 else
                     curve_eval_batch<CB, 1>(a.curve.cells, a.curve, ch, ob);
 #pragma unroll
@@ -571,7 +571,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #ifndef R2F_FFT_WPE3
 #define R2F_FFT_WPE3 3
 #endif
-template <int XL, bool EPI, int ST>
+template <int XL, int EPI, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (XL ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     fft_rows_inv_body<XL, EPI, ST>(a, fsm);
@@ -632,7 +632,7 @@ hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int XL, bool EPI>
+template <int XL, int EPI>
 static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
     const int rows = RowGeom<XL>::ROWS;
     const dim3 grid((a0.vy + rows - 1) / rows, a0.npairs);  // rows beyond the valid outputs are never stored
@@ -641,7 +641,7 @@ static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
     a.epi_lds_off = 0;
     // the epilogue's curve cells behind the transpose buffers, while three workgroups still fit a CU (the kernel's registers allow
     // three waves per SIMD): up to 1 152 cells (18 KB) -- a 1 024-point curve; longer curves gather from global memory
-    if (EPI && a0.epi_lds && (size_t)(a.curve.m - 1) * sizeof(float4) + lds <= 53 * 1024) {
+    if (EPI == 2) {
         a.epi_lds_off = (int)(lds / sizeof(double));
         lds += (size_t)(a.curve.m - 1) * sizeof(float4);
     }
@@ -655,10 +655,15 @@ static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
 
 template <int XL>
 static void launch_rows_inv_epi(const FftConvArgs& a, hipStream_t s) {
-    if (a.epilogue == 1)
-        launch_rows_inv<XL, true>(a, s);
+    // the epilogue's curve cells behind the transpose buffers while three workgroups still fit a CU (the kernel's registers allow
+    // three waves per SIMD): up to 1 152 cells (18 KB) -- a 1 024-point curve -- of a curve whose first guess is never more than
+    // a cell off (DevCurve::near: any near-uniform axis); anything else gathers from global memory through the generic walk
+    if (a.epilogue == 1 && a.epi_lds && a.curve.near && (size_t)(a.curve.m - 1) * sizeof(float4) + fft_lds_bytes() <= 53 * 1024)
+        launch_rows_inv<XL, 2>(a, s);
+    else if (a.epilogue == 1)
+        launch_rows_inv<XL, 1>(a, s);
     else
-        launch_rows_inv<XL, false>(a, s);
+        launch_rows_inv<XL, 0>(a, s);
 }
 
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s) {
