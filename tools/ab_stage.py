@@ -68,4 +68,6 @@ if effects:
     line.append(f"tail {timeit(lambda: ctx.stage_tail(D2, params, out_f32=out, y0=0, y1=H, H_global=H)):.3f}")
 t = timeit(lambda: ctx.render(img, params, out_f32=out))
 line.append(f"render {t:.3f} ms -> {H * W / 1e6 / t * 1e3:.0f} MP/s")
+torch.cuda.synchronize()
+line.append(f"sum {out.double().sum().item():.6f} crc {int(out.view(torch.int32).long().sum().item()) & 0xffffffff:08x}")
 print("  ".join(line), flush=True)
