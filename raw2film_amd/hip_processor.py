@@ -71,6 +71,8 @@ class HipProcessor:
         self.mtf_param_dict = None
         self.grain_kernel_param_dict = None
         self.grain_lut_param_dict = None
+        self.highlight_burn_param_dict = None
+        self.pipeline_resolution = None  # (w, h) of the frame prepared last
         self.matrix_key = None
         self.uploads = 0  # number of table uploads, for the caching tests
         self.last_output = None  # device uint8 (H, W, 3) of the last process()/process_preloaded(): histogram source
@@ -177,6 +179,32 @@ class HipProcessor:
         self.grain_kernel_param_dict = new
 
     # ------------------------------------------------------------------ phase 1 (host)
+    def load_highlight_burn(self, negative_film, highlight_burn, burn_scale, pipeline_resolution=None):
+        """Parameters of the highlight burn for the frame size at hand -- the counterpart of GpuProcessor.load_highlight_burn
+        (gpu_processor.py:856-878): reference density, strength, the low-resolution grid.  Nothing is uploaded here: the device
+        side takes them by value in r2f_params (the reference keeps them in a uniform buffer).  `pipeline_resolution` = (w, h);
+        default: the frame prepared last (the reference reads self.pipeline_resolution).  Returns the dict it keeps in
+        `highlight_burn_param_dict`; "cell" is the size in pixels of a low-resolution cell (effects.py:365)."""
+        if pipeline_resolution is None:
+            pipeline_resolution = self.pipeline_resolution
+        if pipeline_resolution is None:
+            raise ValueError("load_highlight_burn: no pipeline_resolution (prepare a frame first or pass (w, h))")
+        w, h = int(pipeline_resolution[0]), int(pipeline_resolution[1])
+        d_ref = negative_film.d_ref[1 if len(negative_film.d_ref) > 1 else 0]  # effects.py:406
+        cell = math.ceil(min(w, h) / burn_scale)
+        self.highlight_burn_param_dict = {"d_ref": d_ref, "highlight_burn": highlight_burn, "lowres_w": max(1, w // cell),
+                                          "lowres_h": max(1, h // cell), "cell": cell}
+        return self.highlight_burn_param_dict
+
+    def read_texture(self, texture):
+        """A device "texture" (an (h, w, 4) or (h, w, 3) uint8 tensor, e.g. `dst_texture` after process()) as an (h, w, 3) uint8
+        array on the host -- GpuProcessor.read_texture (gpu_processor.py:1311-1356)."""
+        torch = self._torch
+        if not (isinstance(texture, torch.Tensor) and texture.is_cuda and texture.dtype == torch.uint8 and texture.dim() == 3
+                and texture.shape[2] in (3, 4)):
+            raise NotImplementedError("read_texture: wgpu textures are not supported; pass a uint8 (h, w, 3 or 4) CUDA tensor")
+        return self._download(texture[:, :, :3].contiguous())
+
     def extract_image_data_cpu(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24,
                                rotation=0.0, zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True,
                                cache=True, chroma_nr=0, max_scale=400.0, canvas_mode="No", canvas_scale=1.0,
@@ -622,6 +650,7 @@ class HipProcessor:
                 highlight_burn=0.0, burn_scale=50.0, color_masking=None, matrix=None, seed=None, lut3d_mode=0, **_):
         """Upload whatever changed and return the r2f_params for this render: the table half of
         `_execute_gpu_pipeline` (gpu_processor.py:1735-1756, 1772-1825)."""
+        self.pipeline_resolution = (int(pipeline_resolution[0]), int(pipeline_resolution[1]))
         self.load_input_lut(negative_film, exp_kelvin, tint, exp_comp)
         self.load_density_curve(negative_film, push_pull, color_masking)
         self.load_output_lut(negative_film, print_film, red_light, green_light, blue_light, projector_kelvin,
@@ -648,9 +677,8 @@ class HipProcessor:
         do_burn = bool(highlight_burn) and (print_film is not None or negative_film.density_measure in ["status_m", "bw"])
         burn_kw = {}
         if do_burn:
-            d_ref = negative_film.d_ref[1 if len(negative_film.d_ref) > 1 else 0]  # effects.py:406
-            burn_kw = dict(burn_strength=float(highlight_burn), burn_d_ref=float(d_ref),
-                           burn_cell=math.ceil(min(pipeline_resolution) / burn_scale))  # effects.py:365
+            burn = self.load_highlight_burn(negative_film, highlight_burn, burn_scale, pipeline_resolution)
+            burn_kw = dict(burn_strength=float(burn["highlight_burn"]), burn_d_ref=float(burn["d_ref"]), burn_cell=burn["cell"])
         return self.ctx.make_params(matrix=matrix is not None, halation=do_hal, mtf=do_mtf, grain=do_grain,
                                     grain_mono=grain == 1, seed=seed, lut3d_mode=lut3d_mode,
                                     log_eps=LOG_EPS, lut3d_scale=LUT3D_SCALE, **burn_kw)

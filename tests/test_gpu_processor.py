@@ -350,6 +350,10 @@ def test_process_with_destination_textures_like_the_gpu_processor(proc):
     plain = proc.process(img, neg, 6, 0.4, **kw)
     # no scaling here would be needed at equal size: compare the centre pixel through the blit's own mapping instead
     assert plain.shape == (H, W, 3)
+    # GpuProcessor.read_texture (gpu_processor.py:1311-1356): the texture's colour channels on the host
+    np.testing.assert_array_equal(proc.read_texture(dst), d[..., :3])
+    with pytest.raises(NotImplementedError):
+        proc.read_texture(object())
     with pytest.raises(NotImplementedError):
         proc.process(img, neg, 6, 0.4, dst_texture=object(), **kw)
 

@@ -110,6 +110,11 @@ def test_highlight_burn_gate_and_parameters(proc):
     odd = filmstock.SyntheticStock("odd", density_measure="status_a")
     assert "burn_strength" not in proc.prepare(odd, 6, 0.4, (600, 400), print_film=None, highlight_burn=0.5)
     assert "burn_strength" in proc.prepare(neg, 6, 0.4, (600, 400), print_film=None, highlight_burn=0.5)
+    # GpuProcessor.load_highlight_burn (gpu_processor.py:856-878): the low-resolution grid of the frame prepared last
+    d = proc.load_highlight_burn(neg, 0.5, 50)
+    assert d["lowres_w"] == 600 // 8 and d["lowres_h"] == 400 // 8 and d["d_ref"] == neg.d_ref[1] and d is proc.highlight_burn_param_dict
+    big = proc.load_highlight_burn(neg, 0.25, 50.0, (6000, 4000))
+    assert (big["cell"], big["lowres_w"], big["lowres_h"]) == (80, 75, 50)
 
 
 def test_random_seed_when_not_given(proc):
