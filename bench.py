@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="A/B: launch every kernel from the host instead of replaying the frame's HIP graph (the default: everything "
                          "downstream of the halo exchange is captured once and replayed, raw2film_amd/sharding.py)")
+    ap.add_argument("--output", default="f32", choices=["f32", "u8"],
+                    help="f32 (default, the contract's fp32 HWC frame: 24 algorithmic B/px) or u8: the reference's own output stage "
+                         "S9 as the only output (SURVEY.md 8d: 12 + 3 = 15 B/px) -- single GPU, frame configurations")
     ap.add_argument("--checksum", action="store_true",
                     help="validation: every rank takes its rows of ONE full frame (seed 1234) and the JSON line carries a checksum of "
                          "the whole output, comparable across --gpus values")
@@ -205,7 +208,10 @@ def main():
         del whole_frame
     else:
         frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}", kind=args.frame)
-    out = torch.empty((r1 - r0, W, 3), dtype=torch.float32, device=frame.device)
+    out_u8 = args.output == "u8"
+    if out_u8 and not use_processor:
+        raise SystemExit("--output u8 is measured through HipProcessor.process_array: one GPU, a frame configuration")
+    out = torch.empty((r1 - r0, W, 3), dtype=torch.uint8 if out_u8 else torch.float32, device=frame.device)
 
     # per-stage device times come from eager steps bracketed with events (a replayed graph has no stage boundaries to time)
     from raw2film_amd.tracing import TimedBackend
@@ -228,7 +234,7 @@ def main():
     def step():
         for _ in range(frames_here):
             if use_processor:
-                proc.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=next_seed(), return_float=True,
+                proc.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=next_seed(), return_float=not out_u8,
                                    output="device", out=out, **settings)
             else:
                 renderer.render(frame, out_f32=out, seed=next_seed())
@@ -290,7 +296,7 @@ def main():
             "workload": f"{args.config}: " + (f"{args.frames} x " if batch else "") + f"{W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 "
                         "frame, 36x24 mm, " + (f"full pipeline S0-S8: {full}" if effects else "LUTs only (S0+S1+S3+S4+S8), effects off")
                         + (f", stencils {hal_k.shape[0]}x{hal_k.shape[1]} / {mtf_k.shape[0]}x{mtf_k.shape[1]}" if effects else "")
-                        + ", fp32 HWC in -> fp32 HWC out",
+                        + (", fp32 HWC in -> uint8 HWC out (S9, the only output)" if args.output == "u8" else ", fp32 HWC in -> fp32 HWC out"),
             "stocks": "synthetic stand-ins portra400_like + k2383_like (spectral_film_lut data unavailable offline)",
             "sharding": (f"batch of {args.frames} frames, frame i -> rank i mod {world}, no collectives" if batch else
                          "single GPU" if world == 1 else
@@ -333,7 +339,7 @@ def main():
 
         def step():  # noqa: F811 -- from here on the eager renderer
             for _ in range(frames_here):
-                eager.render(frame, out_f32=out, seed=next_seed())
+                eager.render(frame, **{"out_u8" if out_u8 else "out_f32": out}, seed=next_seed())
 
         proc.ctx.set_option("kernel_timing", 2)
         drain_timing()
@@ -369,15 +375,17 @@ def main():
     proc.ctx.set_option("kernel_timing", 0)
 
     # ---- roofline, SURVEY.md 8(d): 24 algorithmic bytes per pixel over the whole step
-    alg_bytes = 24.0 * H * W * n_frames
+    bpp = 15 if out_u8 else 24
+    alg_bytes = float(bpp) * H * W * n_frames
     gbps = alg_bytes / (ms_per_step * 1e-3) / 1e9
     peak = HBM_PEAK_GBPS * world
     roof = {
         "bound": "hbm", "achieved": gbps, "peak": peak, "unit": "GB/s", "frac": gbps / peak,
-        "definition": "SURVEY.md 8(d): 12 B/px read + 12 B/px written (fp32 HWC in and out) x the frame, over ms_per_step"
+        "definition": ("SURVEY.md 8(d): 12 B/px read + 3 B/px written (fp32 HWC in, uint8 HWC out: the only output) x the frame, over ms_per_step"
+                       if out_u8 else "SURVEY.md 8(d): 12 B/px read + 12 B/px written (fp32 HWC in and out) x the frame, over ms_per_step")
                       + (f"; peak = {world} x 8 TB/s" if world > 1 else ""),
-        "bytes_per_px": 24,
-        "read_only": {"bytes_per_px": 12, "achieved": gbps / 2, "frac": gbps / 2 / peak,
+        "bytes_per_px": bpp,
+        "read_only": {"bytes_per_px": 12, "achieved": gbps * 12 / bpp, "frac": gbps * 12 / bpp / peak,
                       "note": "the north_star's 'HBM-read roofline' variant: input bytes only"},
         "traffic": None,
     }
@@ -385,7 +393,7 @@ def main():
     # the practical ceiling beside the spec peak: a float4 streaming copy of the frame's own 12 B/px in and
     # 12 B/px out (r2f_stream_copy: input frame -> output frame buffer, the algorithmic bytes of one step and nothing else),
     # timed with events on the launch stream, best of 5 after a warm-up
-    if not batch and frame.numel() == out.numel():
+    if not batch and frame.numel() == out.numel() and not out_u8:
         proc.ctx.stream_copy(frame, out)
         best = float("inf")
         for _ in range(5):
@@ -415,7 +423,7 @@ def main():
     traffic_rec = None
     captures = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{args.config}_hbm_traffic.json")))  # latest round last
     tfile = captures[-1] if captures else ""
-    if tfile and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain:
+    if tfile and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain and not out_u8:
         rec = json.load(open(tfile))
         meta = rec.get("_meta", {})
         match = meta.get("source_hash") == source_hash() and meta.get("config") == args.config and meta.get("frame") == args.frame

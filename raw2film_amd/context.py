@@ -85,6 +85,22 @@ class HipContext:
             raise ValueError("planes: need a contiguous float32 CUDA tensor of shape (3, rows, W)")
         return _lib.Planes(t.data_ptr(), int(t.shape[1]) * int(t.shape[2]), int(gy0), int(t.shape[1]))
 
+    def _check_out(self, t, dtype, W, what, *, rows=None, gy0=0, y0=None, y1=None):
+        """A caller's output tensor before its pointer crosses the C ABI (which cannot check it): (rows, W, 3) of `dtype`,
+        contiguous, on this context's device, holding the global rows [gy0, gy0 + rows) and covering [y0, y1)."""
+        if t is None:
+            return
+        torch = self._torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.dim() == 3 and t.shape[2] == 3
+                and int(t.shape[1]) == int(W) and t.is_contiguous()):
+            raise ValueError(f"{what} must be a contiguous {dtype} CUDA tensor of shape (rows, {int(W)}, 3)")
+        if t.device.index is not None and self.device.index is not None and t.device.index != self.device.index:
+            raise ValueError(f"{what} lives on {t.device}, this context on {self.device}")
+        if rows is not None and int(t.shape[0]) != int(rows):
+            raise ValueError(f"{what} has {int(t.shape[0])} rows, the frame {int(rows)}")
+        if y0 is not None and (y0 < gy0 or y1 > gy0 + int(t.shape[0])):
+            raise ValueError(f"{what} holds rows [{gy0}, {gy0 + int(t.shape[0])}), asked to write [{y0}, {y1})")
+
     def generation(self) -> int:
         """Change counter of the context's tables, options and internal buffers (r2f_generation): a captured HIP graph of this
         context's launches is stale once it moves."""
@@ -197,6 +213,8 @@ class HipContext:
             out_f32 = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
         if out_u8 is None and want_u8:
             out_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        self._check_out(out_f32, torch.float32, W, "out_f32", rows=H)
+        self._check_out(out_u8, torch.uint8, W, "out_u8", rows=H)
         nbytes = self.workspace_bytes(params, H, W)
         ws = self._get_workspace(nbytes)
         rc = self._lib.r2f_render(
@@ -217,6 +235,8 @@ class HipContext:
         y1 = in_gy0 + rows if y1 is None else y1
         H_global = in_gy0 + rows if H_global is None else H_global
         pl = self.planes(dst, dst_gy0) if dst is not None else None
+        self._check_out(out_f32, self._torch.float32, W, "out_f32", gy0=out_gy0, y0=y0, y1=y1)
+        self._check_out(out_u8, self._torch.uint8, W, "out_u8", gy0=out_gy0, y0=y0, y1=y1)
         rc = self._lib.r2f_stage_front(
             self._h, C.byref(params), image.data_ptr(), layout, in_gy0, rows, int(upto),
             C.byref(pl) if pl is not None else None,
@@ -265,6 +285,8 @@ class HipContext:
                    burn_map=None):
         pd = self.planes(density, src_gy0)
         W = int(density.shape[2])
+        self._check_out(out_f32, self._torch.float32, W, "out_f32", gy0=out_gy0, y0=y0, y1=y1)
+        self._check_out(out_u8, self._torch.uint8, W, "out_u8", gy0=out_gy0, y0=y0, y1=y1)
         rc = self._lib.r2f_stage_tail(
             self._h, C.byref(params), C.byref(pd), burn_map.data_ptr() if burn_map is not None else None,
             out_f32.data_ptr() if out_f32 is not None else None,
@@ -283,6 +305,8 @@ class HipContext:
                          H_global):
         """stage_tail with a grain field made by stage_grain_field instead of generating it in the same kernel."""
         pd, pf = self.planes(density, src_gy0), self.planes(field, field_gy0)
+        self._check_out(out_f32, self._torch.float32, int(density.shape[2]), "out_f32", gy0=out_gy0, y0=y0, y1=y1)
+        self._check_out(out_u8, self._torch.uint8, int(density.shape[2]), "out_u8", gy0=out_gy0, y0=y0, y1=y1)
         self._check(self._lib.r2f_stage_tail_field(
             self._h, C.byref(params), C.byref(pd), C.byref(pf),
             out_f32.data_ptr() if out_f32 is not None else None, out_u8.data_ptr() if out_u8 is not None else None,

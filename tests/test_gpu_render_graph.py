@@ -198,3 +198,31 @@ def test_more_than_eight_buffer_sets_evict_the_least_recently_used_graph():
     assert s["captures"] == 11 and s["replays"] == 12, s
     assert all(torch.equal(o, outs[0]) for o in outs)
     proc.close()
+
+
+def test_wrong_output_tensors_raise_before_anything_is_launched():
+    """The C ABI takes raw pointers; the binding checks a caller's output tensors (dtype, shape, rows covered) so that a mistake
+    is a ValueError, not a GPU memory fault."""
+    from raw2film_amd import HipProcessor
+
+    H, W = 64, 96
+    neg, kw = _settings(H, W, 0.5)
+    proc = HipProcessor(device=0)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=4)).cuda()
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=1, matrix=_rec709(), **kw)
+    for bad in (dict(out_f32=torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")),        # a quarter of the bytes
+                dict(out_f32=torch.empty((H - 1, W, 3), dtype=torch.float32, device="cuda")),
+                dict(out_u8=torch.empty((H, W, 3), dtype=torch.float32, device="cuda"), want_f32=False),
+                dict(out_f32=torch.empty((H, W, 4), dtype=torch.float32, device="cuda")),
+                dict(out_f32=torch.empty((H, W, 3), dtype=torch.float32))):                        # host memory
+        with pytest.raises(ValueError):
+            proc.ctx.render(frame, params, **bad)
+    D = torch.rand((3, H, W), device="cuda")
+    with pytest.raises(ValueError):  # rows [0, H) asked of a buffer that holds [0, H / 2)
+        proc.ctx.stage_tail(D, params, out_f32=torch.empty((H // 2, W, 3), dtype=torch.float32, device="cuda"), y0=0, y1=H, H_global=H)
+    with pytest.raises(ValueError):
+        proc.ctx.stage_tail(D, params, out_u8=torch.empty((H, W, 3), dtype=torch.float32, device="cuda"), y0=0, y1=H, H_global=H)
+    ok = torch.empty((H // 2, W, 3), dtype=torch.float32, device="cuda")
+    proc.ctx.stage_tail(D, params, out_f32=ok, out_gy0=H // 2, y0=H // 2, y1=H, H_global=H)  # a shard's own rows: fine
+    torch.cuda.synchronize()
+    proc.close()
