@@ -287,6 +287,8 @@ class HipContext:
         W = int(density.shape[2])
         self._check_out(out_f32, self._torch.float32, W, "out_f32", gy0=out_gy0, y0=y0, y1=y1)
         self._check_out(out_u8, self._torch.uint8, W, "out_u8", gy0=out_gy0, y0=y0, y1=y1)
+        if burn_map is not None:
+            self._check_lowres(burn_map, params, H_global, W, "burn_map")
         rc = self._lib.r2f_stage_tail(
             self._h, C.byref(params), C.byref(pd), burn_map.data_ptr() if burn_map is not None else None,
             out_f32.data_ptr() if out_f32 is not None else None,
@@ -319,6 +321,12 @@ class HipContext:
     def burn_shape(self, params, H_global, W):
         return H_global // params.burn_cell, W // params.burn_cell
 
+    def _check_lowres(self, t, params, H_global, W, what):
+        torch = self._torch
+        shape = self.burn_shape(params, H_global, W)
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
+            raise ValueError(f"{what} must be a contiguous float32 CUDA tensor of shape {shape} (the highlight burn's low-resolution grid)")
+
     def stage_burn_sums(self, density, params, *, src_gy0=0, y0, y1, H_global):
         """S7 part 1: area-weighted partial sums of the green density over rows [y0, y1) -> (h_lo, w_lo) tensor."""
         torch = self._torch
@@ -333,6 +341,7 @@ class HipContext:
     def stage_burn_map(self, sums, params, *, W, H_global):
         """S7 part 2: clip(x - d_ref, 0) + Gaussian(sigma 3) on the low-res map."""
         torch = self._torch
+        self._check_lowres(sums, params, H_global, W, "sums")
         out = torch.empty_like(sums)
         scratch = torch.empty((2,) + tuple(sums.shape), dtype=torch.float32, device=self.device)
         self._check(self._lib.r2f_stage_burn_map(self._h, C.byref(params), sums.data_ptr(), out.data_ptr(), scratch.data_ptr(), W,
@@ -463,6 +472,9 @@ class HipContext:
         torch = self._torch
         mix = np.ascontiguousarray(np.asarray(mix_table, dtype=np.uint8).reshape(8, 4))
         image = torch.empty((int(height), 256, 4), dtype=torch.uint8, device=self.device)
+        if not (isinstance(counts, torch.Tensor) and counts.is_cuda and counts.dtype in (torch.int32, torch.uint32)
+                and tuple(counts.shape) == (3, 256)):
+            raise ValueError("histogram_render needs the (3, 256) int32 CUDA counts of histogram_counts")
         counts = counts.contiguous()
         if target is not None and not (target.is_cuda and target.dtype == torch.uint8 and target.is_contiguous() and target.dim() == 3
                                        and target.shape[2] == 4):

@@ -224,5 +224,13 @@ def test_wrong_output_tensors_raise_before_anything_is_launched():
         proc.ctx.stage_tail(D, params, out_u8=torch.empty((H, W, 3), dtype=torch.float32, device="cuda"), y0=0, y1=H, H_global=H)
     ok = torch.empty((H // 2, W, 3), dtype=torch.float32, device="cuda")
     proc.ctx.stage_tail(D, params, out_f32=ok, out_gy0=H // 2, y0=H // 2, y1=H, H_global=H)  # a shard's own rows: fine
+    burn = proc.prepare(neg, 6, 0.4, (W, H), seed=1, matrix=_rec709(), highlight_burn=0.5, burn_scale=8.0, **kw)
+    with pytest.raises(ValueError):  # a burn map that is not the low-resolution grid of this frame
+        proc.ctx.stage_tail(D, burn, out_f32=torch.empty((H, W, 3), dtype=torch.float32, device="cuda"), y0=0, y1=H, H_global=H,
+                            burn_map=torch.zeros((3, 3), device="cuda"))
+    with pytest.raises(ValueError):
+        proc.ctx.stage_burn_map(torch.zeros((2, 2), device="cuda"), burn, W=W, H_global=H)
+    with pytest.raises(ValueError):
+        proc.ctx.histogram_render(torch.zeros((3, 255), dtype=torch.int32, device="cuda"), [0] * 32, 40)
     torch.cuda.synchronize()
     proc.close()
