@@ -3,6 +3,9 @@ one stream, then concurrently on two (the tail reads an older density buffer: ti
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raw2film_amd import _lib
+if os.environ.get('R2F_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['R2F_LIB'])
 from raw2film_amd import HipProcessor, filmstock
 from raw2film_amd.hip_processor import REC709_TO_XYZ
 from raw2film_amd.synthetic import synthetic_frame_device
