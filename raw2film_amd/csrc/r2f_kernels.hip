@@ -78,15 +78,18 @@ __device__ __forceinline__ void emit_hwc(float* out_f32, uint8_t* out_u8, long l
     }
 }
 
+// NT: non-temporal loads (ld4_stream) -- for planes that are read exactly once and written by another kernel (the tail's densities:
+// 0.95 against 0.99 ms at 100 MP, profiles/r04_tail_overlap_probe.txt; the pointwise kernels' own plane reads lose with them)
+template <bool NT = false>
 __device__ __forceinline__ void load_planes4(const DevPlanes& pl, int gy, int x, int W, int nv, bool vec, float (&r)[4],
                                              float (&g)[4], float (&b)[4]) {
     const float* p0 = pl.data + (long long)(gy - pl.gy0) * W + x;
     const float* p1 = p0 + pl.plane_stride;
     const float* p2 = p1 + pl.plane_stride;
     if (vec && nv == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(p0);
-        const float4 c = *reinterpret_cast<const float4*>(p1);
-        const float4 d = *reinterpret_cast<const float4*>(p2);
+        const float4 a = NT ? ld4_stream(p0) : *reinterpret_cast<const float4*>(p0);
+        const float4 c = NT ? ld4_stream(p1) : *reinterpret_cast<const float4*>(p1);
+        const float4 d = NT ? ld4_stream(p2) : *reinterpret_cast<const float4*>(p2);
         r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
         g[0] = c.x; g[1] = c.y; g[2] = c.z; g[3] = c.w;
         b[0] = d.x; b[1] = d.y; b[2] = d.z; b[3] = d.w;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(kTailBX* kTailBY) void tail_kernel(const TailArgs a
         const int gy = tile_y0 + pty * Q + q;
 #pragma unroll
         for (int p = 0; p < 4; ++p) pre_r[q][p] = pre_g[q][p] = pre_b[q][p] = 0.f;
-        if (a.to_planes != 2 && pgx < a.W && gy < a.y1) load_planes4(a.src, gy, pgx, a.W, min(4, a.W - pgx), a.vec != 0, pre_r[q], pre_g[q], pre_b[q]);
+        if (a.to_planes != 2 && pgx < a.W && gy < a.y1) load_planes4<true>(a.src, gy, pgx, a.W, min(4, a.W - pgx), a.vec != 0, pre_r[q], pre_g[q], pre_b[q]);
     }
 #ifndef R2F_TAIL_LUT_BATCH
 #define R2F_TAIL_LUT_BATCH 2  // pixels of a lane whose 3-D LUT gathers are in flight together (1, 2 or 4)
