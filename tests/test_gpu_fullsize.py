@@ -280,3 +280,44 @@ def test_cfg4_100mp_uint8_windows_match_the_oracle(full):
     _, u8 = ctx.render(frame, params, want_f32=False, want_u8=True)
     halo = 42 + 17 + 4
     _check_windows(out, u8, frame, p, H_FULL, W_FULL, [(0, 0), (4000, 6000), (H_FULL - 96, W_FULL - 96)], 96, halo)
+
+
+def test_a_frame_with_more_than_2_31_elements_per_buffer():
+    """Maximum sizes: 32768 x 21888 x 3 = 2.15e9 floats (8.6 GB) per interleaved buffer -- element indices beyond int32, byte offsets
+    beyond 2^33 -- through r2f_render with the headline's stencils; windows at the far end of the buffers against the oracle."""
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame_device
+    from test_gpu_parity import setup_ctx
+
+    if torch.cuda.get_device_properties(0).total_memory < 48 * 2**30:
+        pytest.skip("needs ~33 GiB of device memory")
+    W, H = 32768, 21888
+    assert W * H * 3 > 2**31
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, SCALE, seed=SEED)
+    ctx = HipContext(0)
+    try:
+        params = setup_ctx(ctx, p)
+        frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        for y in range(0, H, 2048):  # (the generator's temporaries are several times its output)
+            frame[y:y + 2048] = synthetic_frame_device(min(2048, H - y), W, seed=7 + y)
+        out, _ = ctx.render(frame, params)
+        torch.cuda.synchronize()
+        n, halo = 96, 42 + 17 + 4
+        for y0, x0 in [(H - 96, W - 96), (21846, 100), (0, 0)]:  # (21846, 100): the first rows past element 2^31
+            ya, yb = max(y0 - halo, 0), min(y0 + n + halo, H)
+            xa, xb = max(x0 - halo, 0), min(x0 + n + halo, W)
+            crop = frame[ya:yb, xa:xb].cpu().numpy()
+            x = st.apply_2d_lut(st.apply_matrix3x3(crop, p.matrix), p.lut_2d)
+            x = st.halation(x, p.halation_kernel)
+            x = st.multi_channel_interp(st.log_clip(x), p.lut_1d)
+            x = st.film_sharpness(x, p.mtf_kernel)
+            x = st.apply_grain(x, p.grain_lut, p.grain_kernel, p.seed, False, row0=ya, H_global=H, col0=xa, W_global=W)
+            ref = st.apply_lut_tetrahedral(x, p.lut_3d, 0.25)[y0 - ya:y0 - ya + n, x0 - xa:x0 - xa + n]
+            got = out[y0:y0 + n, x0:x0 + n].cpu().numpy()
+            err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3))
+            assert err <= 1e-5, (y0, x0, err)
+        del frame, out
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
