@@ -321,3 +321,60 @@ def test_a_frame_with_more_than_2_31_elements_per_buffer():
     finally:
         ctx.close()
         torch.cuda.empty_cache()
+
+
+def test_operations_either_side_of_the_path_beyond_2_31_elements():
+    """The same maximum size for the steps around the path (histogram, both uint8 scalings, the uint16 hand-off, INTER_AREA, the
+    affine warp, chroma NR): a far corner of the 717 MP result equals the same operation on a crop."""
+    from raw2film_amd.context import HipContext
+
+    if torch.cuda.get_device_properties(0).total_memory < 48 * 2**30:
+        pytest.skip("needs ~24 GiB of device memory")
+    W, H = 32768, 21888
+    ctx = HipContext(0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    try:
+        u8 = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda", generator=g)  # > 2^31 bytes
+        counts = ctx.histogram_counts(u8)
+        want = torch.stack([torch.bincount(u8[..., c].reshape(-1).to(torch.int64), minlength=256) for c in range(3)])
+        assert torch.equal(counts.to(torch.int64) & 0xFFFFFFFF, want & 0xFFFFFFFF)
+        del want
+        small = u8[: H // 2, : W // 2].contiguous()
+        up = ctx.resize_lanczos4_u8(small, H, W)  # factor 2: a crop at even offsets, away from the borders, scales to the same pixels
+        y0, x0, n = H // 2 - 600, W // 2 - 700, 256
+        cu = ctx.resize_lanczos4_u8(small[y0 - 16:y0 + n + 16, x0 - 16:x0 + n + 16].contiguous(), 2 * (n + 32), 2 * (n + 32))
+        assert torch.equal(up[2 * y0:2 * (y0 + n), 2 * x0:2 * (x0 + n)], cu[32:32 + 2 * n, 32:32 + 2 * n])
+        del up, cu, small
+        dn = ctx.resize_area_u8(u8, H // 4, W // 4)
+        y0, x0, n = H // 4 - 300, W // 4 - 300, 200
+        cd = ctx.resize_area_u8(u8[4 * y0:4 * (y0 + n), 4 * x0:4 * (x0 + n)].contiguous(), n, n)
+        assert torch.equal(dn[y0:y0 + n, x0:x0 + n], cd)
+        del dn, cd, u8
+
+        u16 = torch.randint(0, 65536, (H, W, 3), dtype=torch.int32, device="cuda", generator=g).to(torch.uint16)
+        f = ctx.decode_u16(u16, 1.7)  # > 2^31 elements
+        for ya, xa in ((H - 64, W - 64), (21845, 0)):
+            src = u16[ya:ya + 64, xa:xa + 64].cpu().numpy().astype(np.float32)
+            ref = np.minimum(src / np.float32(65535.0) * np.float32(1.7), np.float32(65504.0))
+            assert np.array_equal(f[ya:ya + 64, xa:xa + 64].cpu().numpy(), ref)
+        del u16
+        a = ctx.resize_area(f, H // 4, W // 4)
+        y0, x0, n = H // 4 - 300, W // 4 - 300, 200
+        ca = ctx.resize_area(f[4 * y0:4 * (y0 + n), 4 * x0:4 * (x0 + n)].contiguous(), n, n)
+        assert torch.allclose(a[:, y0:y0 + n, x0:x0 + n], ca, rtol=1e-6, atol=1e-7)
+        del a, ca
+        m = [1.0, 0.0, 3.25, 0.0, 1.0, 2.5]  # dst -> src: a sub-pixel shift
+        wy, wx, n = H - 400, W - 500, 256
+        wa = ctx.warp_affine(f, m, window=(wy, wx, n, n))
+        wb = ctx.warp_affine(f[wy - 8:wy + n + 8, wx - 8:wx + n + 8].contiguous(), m, window=(8, 8, n, n))
+        assert torch.allclose(wa, wb, rtol=1e-6, atol=1e-7)
+        del wa, wb
+        nr = ctx.chroma_nr(f, 2)
+        y0, x0, n = H - 700, W - 800, 256
+        nc = ctx.chroma_nr(f[y0 - 64:y0 + n + 64, x0 - 64:x0 + n + 64].contiguous(), 2)
+        assert torch.allclose(nr[:, y0:y0 + n, x0:x0 + n], nc[:, 64:64 + n, 64:64 + n], rtol=2e-6, atol=1e-7)
+        del nr, nc, f
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
