@@ -71,7 +71,11 @@ class HipStageBackend:
 
         self.torch = torch
         self.ctx = ctx
-        self.params = params
+        # a copy: begin_frame() writes the seed and F_FRAME_RESIDENT into it, which must not leak into a parameter block the caller
+        # goes on to hand to ctx.render() (whose own seed write that flag would switch off)
+        from . import _lib
+
+        self.params = _lib.Params.from_buffer_copy(params) if isinstance(params, _lib.Params) else params
         self.halation_taps = halation_taps  # (rows above, rows below) the stencil reaches
         self.mtf_taps = mtf_taps
         self.halation_taps_per_channel = halation_taps_per_channel

@@ -53,4 +53,37 @@ for graph in (False, True):
           f"{'== first' if ok else '!= first: ' + str(sorted(sums)[:4])}", flush=True)
     eager_sum = first if not graph else eager_sum  # noqa: F821
 print("graph == eager:", first == eager_sum)
-sys.exit(1 if bad or first != eager_sum else 0)
+
+# The product surface: r2f_render's own graph replay with a NEW seed every frame and no synchronisation between frames -- the seed
+# block is rewritten in stream order between two replays; frame k must never see frame k + 1's seed (or the other way round).
+import copy  # noqa: E402
+from raw2film_amd import _lib  # noqa: E402
+
+seeds = [20260630, 7, 0xFFFFFFFF, 123456]
+outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+want = {}
+proc.ctx.set_option("render_graph", 0)
+for sd in seeds:
+    q = _lib.Params.from_buffer_copy(params)
+    q.seed = sd
+    assert not q.flags & _lib.F_FRAME_RESIDENT  # (the stage backend above works on its own copy)
+    proc.ctx.render(frame, q, out_f32=out)
+    want[sd] = checksum()
+proc.ctx.set_option("render_graph", 1)
+assert len(set(want.values())) == len(seeds)
+wrong = 0
+pending = []
+for i in range(args.iters):
+    sd = seeds[(i * 7 + i // 5) % len(seeds)]
+    q = _lib.Params.from_buffer_copy(params)
+    q.seed = sd
+    o = outs[i % 2]
+    proc.ctx.render(frame, q, out_f32=o)
+    pending.append((sd, o.view(torch.int32).to(torch.int64).sum()))  # (the reduction is queued behind the frame, no host sync)
+    if len(pending) >= 16:
+        wrong += sum(int(v.item()) != want[sd0] for sd0, v in pending)
+        pending = []
+wrong += sum(int(v.item()) != want[sd0] for sd0, v in pending)
+stats = proc.ctx.render_stats()
+print(f"{args.config} r2f_render, a new seed per frame, {args.iters} frames back to back: {wrong} wrong frame(s); {stats}", flush=True)
+sys.exit(1 if bad or first != eager_sum or wrong or stats["replays"] < args.iters - 4 else 0)
