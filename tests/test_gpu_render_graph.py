@@ -187,8 +187,11 @@ def test_more_than_eight_buffer_sets_evict_the_least_recently_used_graph():
     proc = HipProcessor(device=0)
     params = proc.prepare(neg, 6, 0.4, (W, H), seed=1, matrix=_rec709(), **kw)
     outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(10)]
-    proc.ctx.render(frame, params, out_f32=outs[0])  # eager: the structure is warm from here on
-    for o in outs:  # ten distinct buffer sets: ten captures, the two oldest evicted on the way
+    for o in outs:  # first sight of every buffer set: kernel by kernel (a set is captured the SECOND time it comes by)
+        proc.ctx.render(frame, params, out_f32=o)
+    s = proc.ctx.render_stats()
+    assert s["captures"] == 0 and s["eager"] == 10 and s["replays"] == 0, s
+    for o in outs:  # ten distinct buffer sets seen before: ten captures, the two oldest evicted on the way
         proc.ctx.render(frame, params, out_f32=o)
     s = proc.ctx.render_stats()
     assert s["captures"] == 10 and s["dropped"] == 2 and s["replays"] == 10, s
@@ -197,6 +200,30 @@ def test_more_than_eight_buffer_sets_evict_the_least_recently_used_graph():
     s = proc.ctx.render_stats()
     assert s["captures"] == 11 and s["replays"] == 12, s
     assert all(torch.equal(o, outs[0]) for o in outs)
+    proc.close()
+
+
+def test_fresh_buffers_every_frame_are_never_captured_and_two_alternating_sets_are():
+    """Results a caller keeps alive arrive in new buffers every frame: capturing those would cost a graph per frame that is never
+    replayed.  Double buffering (A, B, A, B, ...) is captured from the second round on."""
+    from raw2film_amd import HipProcessor
+
+    H, W = 96, 160
+    neg, kw = _settings(H, W, 0.5)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=2)).cuda()
+    proc = HipProcessor(device=0)
+    kept = [proc.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=s, return_float=True, output="device", **kw)
+            for s in range(12)]  # all alive: twelve different allocations
+    s = proc.ctx.render_stats()
+    assert s["captures"] == 0 and s["replays"] == 0 and s["eager"] == 12, s
+    assert len({int(k.data_ptr()) for k in kept}) == 12
+    a, b = torch.empty_like(kept[0]), torch.empty_like(kept[0])
+    for i in range(8):
+        proc.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=i % 12, return_float=True, output="device",
+                           out=a if i % 2 == 0 else b, **kw)
+        assert torch.equal(a if i % 2 == 0 else b, kept[i % 12])
+    s = proc.ctx.render_stats()
+    assert s["captures"] == 2 and s["replays"] == 6 and s["eager"] == 14, s
     proc.close()
 
 
