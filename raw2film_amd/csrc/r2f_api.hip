@@ -374,6 +374,11 @@ int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s) {
 }
 
 void drop_render_graphs(r2f_ctx* ctx) {
+    // a replay of one of them may still be running (an option changed between two asynchronous frames; table uploads and buffer
+    // growth have synchronised already): an executable graph must outlive its last launch
+    bool any = false;
+    for (const auto& g : ctx->graphs) any = any || g.exec;
+    if (any) (void)hipDeviceSynchronize();
     for (auto& g : ctx->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec), ++ctx->stat_dropped;
         if (g.graph) (void)hipGraphDestroy(g.graph);
