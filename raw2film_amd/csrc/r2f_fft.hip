@@ -364,8 +364,10 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
                 for (int m = 0; m < 16; ++m) fb[m] = rowB[reflect101(wxB + l + LPL * m, a.W)];
             }
         }
+        // A NaN or an infinity in ONE sample would come back from the transforms in every output of its window (the direct form
+        // keeps it inside the stencil's reach, like the reference's): such a sample enters the correlation as 0.
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = make_double2((double)fa[m], (double)fb[m]);
+        for (int m = 0; m < 16; ++m) v[m] = make_double2(__builtin_isfinite(fa[m]) ? (double)fa[m] : 0.0, __builtin_isfinite(fb[m]) ? (double)fb[m] : 0.0);
     }
     if (!(R2F_FFT_EXP & 4)) {
         G::template fft<false>(v, a, l, wave_tbuf(fsm), lane);

@@ -260,3 +260,42 @@ def test_full_render_through_a_round_tripped_bundle(tmp_path):
         proc.close()
     ref = st.render(img, p)
     assert rel_err(out, ref, 1e-3) <= 1e-5
+
+
+@pytest.mark.parametrize("scale,shape", [(341.33, (700, 900)), (60.0, (300, 400))])  # FFT stencils / direct stencils
+def test_non_finite_and_absurd_samples_stay_inside_the_stencils_reach(scale, shape):
+    """NaN, infinities, negative and 3e38 samples in the frame: no fault, a finite output, and pixels further away than the
+    stencils reach are the clean render's (bit for bit in the direct form; to the rounding class of a window that holds a 65 504
+    specular in the FFT form, whose pass 1 takes a non-finite sample as 0 instead of handing it to every output of its window)."""
+    from raw2film_amd.context import HipContext
+
+    H, W = shape
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, scale, seed=SEED)
+    c = HipContext(0)
+    try:
+        params = setup_ctx(c, p)
+        img = synthetic_frame(H, W, seed=3)
+        clean, _ = c.render(torch.from_numpy(img).cuda(), params)
+        clean = clean.cpu().numpy()
+        bad = img.copy()
+        cy, cx = H // 2, W // 2
+        vals = [np.nan, np.inf, -np.inf, -5.0, 3e38, -3e38, 0.0, -0.0, 1e-45]
+        for i, v in enumerate(vals):
+            bad[cy + 3 * i, cx, i % 3] = v
+            bad[5, 5 + 7 * i, :] = v
+        out, u8 = c.render(torch.from_numpy(bad).cuda(), params, want_u8=True)
+        o = out.cpu().numpy()
+        assert np.isfinite(o).all() and u8.shape == (H, W, 3)
+        reach = sum(k.shape[0] // 2 for k in (p.halation_kernel, p.mtf_kernel, p.grain_kernel) if k is not None) + 1
+        far = np.ones((H, W), bool)
+        far[max(cy - reach, 0):cy + 3 * len(vals) + reach, max(cx - reach, 0):cx + reach] = False
+        far[:5 + reach + 1, :5 + 7 * len(vals) + reach] = False
+        assert far.mean() > 0.5
+        fft = any(s["fft"] for s in c.stencil_stats(0)) or any(s["fft"] for s in c.stencil_stats(1))
+        if fft:
+            assert np.max(np.abs(o[far] - clean[far]) / np.maximum(np.abs(clean[far]), 1e-3)) <= 5e-6
+        else:
+            assert np.array_equal(o[far], clean[far])
+    finally:
+        c.close()
