@@ -299,3 +299,38 @@ def test_non_finite_and_absurd_samples_stay_inside_the_stencils_reach(scale, sha
             assert np.array_equal(o[far], clean[far])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("scale,shape", [(341.33, (300, 600)), (60.0, (200, 300))])
+def test_non_finite_values_inside_tables_and_stencils_neither_fault_nor_hang(scale, shape):
+    """NaN / infinities sprinkled over each table and stencil in turn: the result may be garbage (so is the reference's), the
+    call may refuse the table (ValueError: a curve axis must be non-decreasing) -- but every index stays inside its table and every
+    loop ends."""
+    import copy
+
+    from raw2film_amd.context import HipContext
+
+    H, W = shape
+    neg, prt, _ = stocks()
+    base = oracle_inputs(neg, prt, scale, seed=SEED)
+    rng = np.random.default_rng(0)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=3)).cuda()
+    for name in ("lut_2d", "lut_1d", "lut_3d", "grain_lut", "halation_kernel", "mtf_kernel", "grain_kernel"):
+        if getattr(base, name) is None or np.ndim(getattr(base, name)) < 2:
+            continue
+        for v in (np.nan, np.inf, -np.inf):
+            p = copy.copy(base)
+            t = np.array(getattr(base, name), copy=True)
+            flat = t.reshape(-1)
+            flat[rng.integers(0, flat.size, size=max(1, flat.size // 50))] = v
+            setattr(p, name, t)
+            c = HipContext(0)
+            try:
+                params = setup_ctx(c, p)
+                out, u8 = c.render(frame, params, want_u8=True)
+                torch.cuda.synchronize()
+                assert out.shape == (H, W, 3) and u8.shape == (H, W, 3)
+            except ValueError:
+                pass
+            finally:
+                c.close()
