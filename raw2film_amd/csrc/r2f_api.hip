@@ -99,10 +99,6 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
-    // 512-row windows: 1 = the column pass that moves full lines with the idle half of its two 256-point problems parked in LDS
-    // (fft_cols_y512p_kernel), 0 = the 32-lane fft512 form (default: the faster one, profiles/r04_y512_split_ab.txt).  The two keep
-    // their kernel spectra in different row orders: switching rebuilds them.
-    int opt_fft_y512_park = 0;
     int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
@@ -486,7 +482,6 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.tw512 = a.tw + kFftN;
     a.tw1024 = a.tw + 2 * kFftN;
     a.ny = ny, a.nx = nx;
-    a.y512_park = ctx->opt_fft_y512_park;
     a.ay = set.kh / 2 - b[0];  // anchor (kh/2, kw/2): cv.filter2D's default
     a.ax = set.kw / 2 - b[2];
     a.vy = ny - bh + 1;
@@ -853,13 +848,6 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
-        return R2F_OK;
-    }
-    if (!strcmp(name, "stencil_fft_y512_park")) {
-        ctx->opt_fft_y512_park = value ? 1 : 0;
-        for (auto& per_stencil : ctx->fft_kf_valid)
-            for (auto& per_channel : per_stencil)
-                for (bool& v : per_channel) v = false;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_epilogue_lds")) {

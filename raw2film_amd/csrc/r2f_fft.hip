@@ -457,86 +457,6 @@ __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const i
         if (l + 32 * q < a.vy) sst<ST>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
 }
 
-// 512-row windows, the form VERDICT r3 sketched (next 2b): 16 lanes per column like the 256-row pass -- a wave = 4 interleaved columns
-// x 16 rows = 1 KB contiguous per access, rows [0, 256) and [256, 512) each read and written in full lines -- with the column's 512
-// rows as TWO 256-point problems and the idle half PARKED IN LDS (16 elements x 16 B per lane, lane-private slots: 16 KB per wave):
-//     a[n] = x[n] + x[n + 256],  b[n] = (x[n] - x[n + 256]) W_512^n          X[2 k] = FFT256(a)[k],  X[2 k + 1] = FFT256(b)[k]
-//     A = IFFT256(X[2 k] K^[2 k]),  B = IFFT256(X[2 k + 1] K^[2 k + 1])         y[n] = A[n] + W_512^-n B[n],  y[n + 256] = A[n] - W_512^-n B[n]
-// The spectrum image holds K^[2 k] in row k and K^[2 k + 1] in row 256 + k (built by MODE 1 of this kernel: the order is private
-// to it).  Workgroups of 2 waves (8 columns): 2 x (8.5 KB of transposes + 16 KB of parking) = 49 KB, three of them per CU.
-// (The same decomposition with the idle half in REGISTERS was measured in profiles/r04_y512_split_ab.txt: 1 wave per SIMD, 1.5 x slower.)
-constexpr int kY512pThreads = 128;
-constexpr int kY512pWaveDoubles = 4 * kTLine + 16 * 64 * 2;  // per wave: transpose buffers, then 16 x 64 parked complex values
-__device__ __forceinline__ cplx w512_lane(const cplx u1, const int m) {  // u1 W_32^m (u1 = W_512^l): W_512^(l + 16 m)
-    return m == 0 ? u1 : cmul(u1, make_double2(kC32[m], -kS32[m]));
-}
-template <int NBX, int ST, int MODE>
-__device__ __forceinline__ void fft_cols_y512p_body(const FftConvArgs& a, double* fsm) {
-    const int lane = threadIdx.x & 63, l = lane & 15, wave = threadIdx.x >> 6;
-    const int pair = blockIdx.y, k = blockIdx.x * 8 + (threadIdx.x >> 4);
-    char* s1 = simg<ST>(a.s1, pair, (long long)512 * (NBX * 16));
-    const cplx w1 = a.tw[l];     // W_256^l: the 256-point transforms
-    const cplx u1 = a.tw512[l];  // W_512^l: the radix-2 steps
-    double* tbuf = fsm + wave * kY512pWaveDoubles;
-    cplx* park = reinterpret_cast<cplx*>(tbuf + 4 * kTLine) + lane;  // element m of this lane: park[64 * m]
-    cplx v[16];
-    {
-        cplx hi[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(l + 16 * m, k, NBX));
-#pragma unroll
-        for (int m = 0; m < 16; ++m) hi[m] = sld<ST>(s1, sidx(256 + l + 16 * m, k, NBX));
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const cplx d = csub(v[m], hi[m]);
-            v[m] = cadd(v[m], hi[m]);
-            park[64 * m] = cmul(d, w512_lane(u1, m));
-        }
-    }
-    const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
-    // ---- even frequencies
-    fft256<false>(v, w1, tbuf, lane);
-    if (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(l + 16 * q, k, NBX)));
-        fft256<true>(v, w1, tbuf, lane);
-    }
-    // ---- swap: A goes to the parking slots, b comes back
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const cplx b = park[64 * m];
-        if (MODE == 0) park[64 * m] = v[m];
-        v[m] = b;
-    }
-    // ---- odd frequencies
-    fft256<false>(v, w1, tbuf, lane);
-    if (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(256 + l + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(256 + l + 16 * q, k, NBX)));
-    fft256<true>(v, w1, tbuf, lane);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const cplx A = park[64 * m];
-        const cplx t = cmulc(v[m], w512_lane(u1, m));  // W_512^-n B[n]
-        // (pass 3 never reads the rows past the valid outputs; boxes over 256 taps tall leave fewer than 256 of them)
-        if (l + 16 * m < a.vy) sst<ST>(s1, sidx(l + 16 * m, k, NBX), cadd(A, t));
-        if (256 + l + 16 * m < a.vy) sst<ST>(s1, sidx(256 + l + 16 * m, k, NBX), csub(A, t));
-    }
-}
-
-template <int NBX, int ST, int MODE>
-__global__ __launch_bounds__(kY512pThreads) __attribute__((amdgpu_waves_per_eu(2, 8))) void fft_cols_y512p_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_cols_y512p_body<NBX, ST, MODE>(a, fsm);
-}
-
 #ifndef R2F_FFT_WPE2
 #define R2F_FFT_WPE2 2
 #endif
@@ -685,27 +605,8 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int NBX, int ST>
-static void launch_cols_y512p(const FftConvArgs& a, int mode, hipStream_t s) {
-    const dim3 block(kY512pThreads), grid(a.nx / 8, a.npairs);
-    const size_t lds = (size_t)(kY512pThreads / 64) * kY512pWaveDoubles * sizeof(double);
-    if (mode == 1)
-        hipLaunchKernelGGL((fft_cols_y512p_kernel<NBX, ST, 1>), grid, block, lds, s, a);
-    else
-        hipLaunchKernelGGL((fft_cols_y512p_kernel<NBX, ST, 0>), grid, block, lds, s, a);
-}
-
 template <int NBX, bool Y512>
 static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
-    if (Y512 && a.y512_park) {
-        if (a.s32 == 1)
-            launch_cols_y512p<NBX, 1>(a, mode, s);
-        else if (a.s32 == 2)
-            launch_cols_y512p<NBX, 2>(a, mode, s);
-        else
-            launch_cols_y512p<NBX, 0>(a, mode, s);
-        return;
-    }
     const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1>), grid, block, fft_lds_bytes(), s, a, mode);

@@ -191,8 +191,6 @@ struct FftConvArgs {
     DevCurve curve;
     float log_eps;
     int vec4;                 // 1: vx % 4 == 0, W % 4 == 0 and dst planes 16-byte aligned -> float4 stores in pass 3
-    int y512_park;            // 512-row windows: 1 = the column pass with 16 lanes per column and the idle half parked in LDS
-                              // (fft_cols_y512p_kernel; its spectrum order is its own), 0 = the 32-lane fft512 form
     int epi_lds;              // pass 3 with the epilogue: 1 = the channel's curve cells may be copied to LDS (A/B knob)
     int epi_lds_off;          // set by the launcher: offset (in doubles) of those cells in the dynamic LDS, 0 = gather from global memory
 };
