@@ -5,9 +5,11 @@ TEST INFRASTRUCTURE ONLY (same import rules as the rest of `oracle/`).  Not a se
 difference between the HIP path and the oracle is the float32 ORACLE'S OWN distance from the exact value of the same formulas on
 the same float32 inputs and tables?  tests/test_gpu_fuzz.py asserts
 
-    |hip - truth|  <=  1e-5 * max(|truth|, 1e-3)  +  |oracle - truth|
+    |hip - truth|  <=  1e-5 * max(|truth|, 1e-3)  +  |oracle - truth|  +  conditioning
 
-for hostile tables and with chroma NR: the kernels get no slack the float32 oracle does not need itself.
+for hostile tables and with chroma NR: the contract, the float32 oracle's own distance from the exact value at
+that sample, and what the case's tables make of ONE float32 ulp of each plane between two stages (`conditioning` below: measured
+per sample -- the oracle's stencils are float64 FFTs rounded once, more exact than any float32 sum of products can be).
 A rough table (a 3-D LUT that jumps by 1 across a cell) turns one ulp of its float32 argument into 1e-5 of its value for the
 oracle and the device alike; against the truth that shows as |oracle - truth| of the same size.
 
@@ -216,24 +218,54 @@ def chroma_nr_filter(image, size):
     return out
 
 
-def render(image, p: st.RenderInputs, chroma_nr: int = 0):
-    """stages.render (cpu_processor.py:363-405) in float64: [chroma NR ->] S0 -> S1 -> [S2] -> S3 -> S4 -> [S5] -> [S6] -> [S7] -> S8."""
+PLANES = ("exposure", "density", "mtf", "grain")  # the float32 planes between the stages (what render's `nudge` can move)
+
+
+def render(image, p: st.RenderInputs, chroma_nr: int = 0, nudge: str | None = None, rel: float = 0.0):
+    """stages.render (cpu_processor.py:363-405) in float64: [chroma NR ->] S0 -> S1 -> [S2] -> S3 -> S4 -> [S5] -> [S6] -> [S7] -> S8.
+
+    nudge / rel: multiply ONE of the planes that every float32 implementation stores between two stages (PLANES: the exposure
+    after S1, the density after S4, the MTF's output, the grained density) by (1 + rel) -- `conditioning` below measures with it
+    how far the tables carry an ulp of such a plane into the output."""
+    def moved(x, name):
+        return x * (1.0 + rel) if nudge == name else x
+
     x = np.asarray(image, dtype=np.float32).astype(F64)
     if chroma_nr:
         x = chroma_nr_filter(x, chroma_nr)
     if p.matrix is not None:
         x = apply_matrix3x3(x, p.matrix)
-    x = apply_2d_lut(x, p.lut_2d)
+    x = moved(apply_2d_lut(x, p.lut_2d), "exposure")
     if p.halation_kernel is not None:
         x = convolve_2d(x, p.halation_kernel)
-    x = multi_channel_interp(log_clip(x), p.lut_1d)
+    x = moved(multi_channel_interp(log_clip(x), p.lut_1d), "density")
     if p.mtf_kernel is not None:
-        x = convolve_2d(x, p.mtf_kernel)
+        x = moved(convolve_2d(x, p.mtf_kernel), "mtf")
     if p.grain_lut is not None:
         gk = p.grain_kernel if p.grain_kernel is not None else np.ones((1, 1), dtype=np.float32)
-        x = apply_grain(x, p.grain_lut, gk, p.seed, p.grain_mono)
+        x = moved(apply_grain(x, p.grain_lut, gk, p.seed, p.grain_mono), "grain")
     if p.highlight_burn:
         x = burn(x, p.d_ref, p.highlight_burn, p.burn_scale)
     if p.lut3d_mode == "tetrahedral":
         return apply_lut_tetrahedral(x, p.lut_3d, st.LUT3D_SCALE)
     return apply_lut_trilinear(x, p.lut_3d, st.LUT3D_SCALE)
+
+
+def conditioning(image, p: st.RenderInputs, chroma_nr: int = 0, ulps: float = 1.0, exact=None):
+    """Per output sample: how far the output moves when each float32 plane between two stages moves by `ulps` float32 ulps
+    (relative 2^-23 each), summed over the planes.  The device and the reference's own GPU path keep those planes in float32 and
+    fill them with float32 sums of products; an ulp of such a plane is nobody's error.  With smooth tables it is worth ~5e-7 of a
+    mid-tone and up to ~3e-6 of a dark output (an ulp of a density of 3 against an output of 0.01); stepped or noisy tables multiply
+    it -- by a factor this function measures instead of assuming: the test allows exactly what the tables themselves turn one ulp
+    per plane into (profiles/r04_parity_budget.txt)."""
+    if exact is None:
+        exact = render(image, p, chroma_nr)
+    rel = ulps * 2.0 ** -23
+    total = np.zeros_like(exact)
+    for name in PLANES:
+        if name == "mtf" and p.mtf_kernel is None:
+            continue
+        if name == "grain" and p.grain_lut is None:
+            continue
+        total += np.abs(render(image, p, chroma_nr, nudge=name, rel=rel) - exact)
+    return total

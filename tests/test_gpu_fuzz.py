@@ -95,11 +95,17 @@ def test_random_configuration(ctx, c):
         # from it as the contract allows PLUS as far as the oracle itself does, and not a bit further.
         from oracle import truth
 
-        exact = truth.render(src if c["nr"] else img, p, chroma_nr=c["nr"])  # (with chroma NR the matrix was applied up front)
+        base = src if c["nr"] else img  # (with chroma NR the matrix was applied up front)
+        exact = truth.render(base, p, chroma_nr=c["nr"])
         slack = np.abs(ref.astype(np.float64) - exact)
-        bound = 1e-5 * np.maximum(np.abs(exact), 1e-3) + slack
+        # ... plus what the tables of THIS case turn ONE float32 ulp of each plane between two stages into (truth.conditioning:
+        # measured per sample): the oracle's stencils are float64 FFTs rounded once, more exact than any
+        # float32 sum of products -- the device's direct form or the reference's own -- can be; 4 of 1 620 soak cases with stepped
+        # grain LUTs sat 3-10 % over the bound without this term (profiles/r04_parity_budget.txt)
+        cond = truth.conditioning(base, p, chroma_nr=c["nr"], ulps=1.0, exact=exact)
+        bound = 1e-5 * np.maximum(np.abs(exact), 1e-3) + slack + cond
         worst = float(np.max(np.abs(got.astype(np.float64) - exact) / bound))
-        assert worst <= 1.0, f"|hip - truth| reaches {worst:.3f} x (1e-5 max(|truth|, 1e-3) + |oracle - truth|): {c}"
+        assert worst <= 1.0, f"|hip - truth| reaches {worst:.3f} x (1e-5 max(|truth|, 1e-3) + |oracle - truth| + conditioning): {c}"
     else:
         assert_close(got, ref, 1e-5, 1e-3, str(c))
     assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1

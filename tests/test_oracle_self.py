@@ -204,3 +204,31 @@ def test_float64_truth_evaluation_agrees_with_the_float32_oracle_on_smooth_table
     assert np.max(np.abs(st.apply_lut_trilinear(d, p.lut_3d) - truth.apply_lut_trilinear(d, p.lut_3d))) <= 2e-7
     g = st.apply_grain(d, p.grain_lut, p.grain_kernel, 77)
     assert np.max(np.abs(g - truth.apply_grain(d, p.grain_lut, p.grain_kernel, 77))) <= 2e-6
+
+
+def test_conditioning_term_of_the_fuzz_criterion_is_what_the_tables_make_of_an_ulp_per_plane():
+    """truth.conditioning: the change of the float64 output when each float32 plane between two stages moves by an ulp.  With the
+    smooth stand-in tables that is ~1.2e-6 of the output per ulp (median; 3e-6 at dark outputs) -- an eighth of the contract's 1e-5 --;
+    tables with steps multiply it, by a factor the function MEASURES per sample (the point of the term: tests/test_gpu_fuzz.py)."""
+    import hostile
+    from oracle import truth
+
+    neg, prt, _ = stocks()
+    H, W = 60, 88
+    img = synthetic_frame(H, W, seed=5)
+    p = oracle_inputs(neg, prt, 97.3, grain=1)
+    exact = truth.render(img, p)
+    cond = truth.conditioning(img, p, ulps=2.0, exact=exact)  # (the fuzz test uses ulps = 1)
+    assert cond.shape == exact.shape and (cond >= 0).all()
+    rel = cond / np.maximum(np.abs(exact), 1e-3)
+    smooth = np.max(rel)
+    # (dark outputs: an ulp of a density of 3 is 2.4e-7, the print LUT's slope there carries it into an output of 0.01 -- the
+    # contract's 1e-5 of a dark output is a couple of ulps of the plane it was computed from, smooth tables or not)
+    assert 0 < smooth <= 8e-6 and np.median(rel) <= 3e-6, (smooth, np.median(rel))  # i.e. ~1.2e-6 per ulp: the contract's 1e-5 is ~8 ulps
+    # linear in the number of ulps, and no plane nudged -> nothing
+    np.testing.assert_allclose(truth.conditioning(img, p, ulps=4.0, exact=exact), 2.0 * cond, rtol=0.2, atol=1e-9)
+    assert np.array_equal(truth.render(img, p, nudge="mtf", rel=0.0), exact)
+    q = oracle_inputs(neg, prt, 97.3, grain=1)
+    hostile.roughen(np.random.default_rng(1750364522), q, 64, 4096, 24)  # the tables of one of the soak's four cases
+    rough = truth.conditioning(img, q, ulps=2.0)
+    assert np.max(rough / np.maximum(np.abs(truth.render(img, q)), 1e-3)) > 3 * smooth
