@@ -6,7 +6,7 @@ library that can run under one: the same translation unit the library links is c
 1 x 1 ... 16384^2, tap boxes 1 ... 400 (odd, even, non-square, sparse, disc-like, mirrored), shard row ranges and every value
 of the FFT options, and checks each plan against its own contract (windows cover the rows and columns, batches cover the pairs,
 an entry list reproduces the taps it was built from -- every tap once per output row -- inside the LDS rows of its phase, a
-tile order is a permutation ...).  Round 4: 129 000 cases over 9 seeds, nothing found (the round-2 division by zero in the
+tile order is a permutation ...).  Round 4: 229 000 cases over 13 seeds, nothing found (the round-2 division by zero in the
 window choice is the kind of bug this is for)."""
 
 import ctypes
