@@ -81,8 +81,9 @@ class HipContext:
     def planes(self, t, gy0: int = 0) -> _lib.Planes:
         """Describe a contiguous float32 (3, rows, W) device tensor holding global rows gy0.."""
         torch = self._torch
-        if t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous() or not t.is_cuda:
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous() or not t.is_cuda:
             raise ValueError("planes: need a contiguous float32 CUDA tensor of shape (3, rows, W)")
+        self._same_device(t, "planes")
         return _lib.Planes(t.data_ptr(), int(t.shape[1]) * int(t.shape[2]), int(gy0), int(t.shape[1]))
 
     def _check_out(self, t, dtype, W, what, *, rows=None, gy0=0, y0=None, y1=None):
@@ -94,8 +95,7 @@ class HipContext:
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.dim() == 3 and t.shape[2] == 3
                 and int(t.shape[1]) == int(W) and t.is_contiguous()):
             raise ValueError(f"{what} must be a contiguous {dtype} CUDA tensor of shape (rows, {int(W)}, 3)")
-        if t.device.index is not None and self.device.index is not None and t.device.index != self.device.index:
-            raise ValueError(f"{what} lives on {t.device}, this context on {self.device}")
+        self._same_device(t, what)
         if rows is not None and int(t.shape[0]) != int(rows):
             raise ValueError(f"{what} has {int(t.shape[0])} rows, the frame {int(rows)}")
         if y0 is not None and (y0 < gy0 or y1 > gy0 + int(t.shape[0])):
@@ -187,10 +187,15 @@ class HipContext:
             return _lib.LAYOUT_CHW, int(t.shape[1]), int(t.shape[2])
         raise ValueError(f"cannot interpret image shape {tuple(t.shape)}")
 
+    def _same_device(self, t, what):
+        if t.device.index is not None and self.device.index is not None and t.device.index != self.device.index:
+            raise ValueError(f"{what} lives on {t.device}, this context on {self.device}")
+
     def _check_image(self, t):
         torch = self._torch
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise ValueError("image must be a contiguous float32 CUDA tensor")
+        self._same_device(t, "image")
 
     def workspace_bytes(self, params, H, W) -> int:
         return int(self._lib.r2f_workspace_bytes(C.byref(params), H, W))
