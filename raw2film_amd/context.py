@@ -331,6 +331,7 @@ class HipContext:
         shape = self.burn_shape(params, H_global, W)
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
             raise ValueError(f"{what} must be a contiguous float32 CUDA tensor of shape {shape} (the highlight burn's low-resolution grid)")
+        self._same_device(t, what)
 
     def stage_burn_sums(self, density, params, *, src_gy0=0, y0, y1, H_global):
         """S7 part 1: area-weighted partial sums of the green density over rows [y0, y1) -> (h_lo, w_lo) tensor."""
@@ -423,6 +424,7 @@ class HipContext:
         if not (image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.is_contiguous() and image_u8.dim() == 3
                 and image_u8.shape[2] == 3):
             raise ValueError("resize_lanczos4_u8 needs a contiguous uint8 (H, W, 3) CUDA tensor")
+        self._same_device(image_u8, "image")
         out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=self.device)
         self._check(self._lib.r2f_resize_lanczos4_u8(self._h, image_u8.data_ptr(), int(image_u8.shape[0]), int(image_u8.shape[1]),
                                                      out.data_ptr(), int(out_h), int(out_w), self._stream()))
@@ -435,6 +437,7 @@ class HipContext:
         if not (image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.is_contiguous() and image_u8.dim() == 3
                 and image_u8.shape[2] == 3):
             raise ValueError("resize_area_u8 needs a contiguous uint8 (H, W, 3) CUDA tensor")
+        self._same_device(image_u8, "image")
         out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=self.device)
         self._check(self._lib.r2f_resize_area_u8(self._h, image_u8.data_ptr(), int(image_u8.shape[0]), int(image_u8.shape[1]),
                                                  out.data_ptr(), int(out_h), int(out_w), self._stream()))
@@ -447,6 +450,7 @@ class HipContext:
         if not (image_u16.is_cuda and image_u16.dtype in (torch.uint16, torch.int16) and image_u16.is_contiguous()
                 and image_u16.dim() == 3 and image_u16.shape[2] in (3, 4)):
             raise ValueError("decode_u16 needs a contiguous uint16 (H, W, 3 or 4) CUDA tensor")
+        self._same_device(image_u16, "image")
         out = torch.empty((int(image_u16.shape[0]), int(image_u16.shape[1]), 3), dtype=torch.float32, device=self.device)
         self._check(self._lib.r2f_decode_u16(self._h, image_u16.data_ptr(), int(image_u16.shape[0]), int(image_u16.shape[1]),
                                              int(image_u16.shape[2]), float(np.float32(divisor)), float(np.float32(factor)),
@@ -463,6 +467,8 @@ class HipContext:
         if not (dst_rgba.is_cuda and dst_rgba.dtype == torch.uint8 and dst_rgba.is_contiguous() and dst_rgba.dim() == 3
                 and dst_rgba.shape[2] == 4):
             raise ValueError("blit_rgba8 needs a contiguous uint8 (h, w, 4) CUDA destination")
+        self._same_device(image_f32, "image")
+        self._same_device(dst_rgba, "destination")
         t = _lib.Blit(transform["scale_x"], transform["scale_y"], transform["offset_x"], transform["offset_y"],
                       transform["canvas_min_x"], transform["canvas_min_y"], transform["canvas_max_x"], transform["canvas_max_y"],
                       (C.c_float * 3)(*transform["canvas_color"]))
@@ -480,10 +486,13 @@ class HipContext:
         if not (isinstance(counts, torch.Tensor) and counts.is_cuda and counts.dtype in (torch.int32, torch.uint32)
                 and tuple(counts.shape) == (3, 256)):
             raise ValueError("histogram_render needs the (3, 256) int32 CUDA counts of histogram_counts")
+        self._same_device(counts, "counts")
         counts = counts.contiguous()
         if target is not None and not (target.is_cuda and target.dtype == torch.uint8 and target.is_contiguous() and target.dim() == 3
                                        and target.shape[2] == 4):
             raise ValueError("histogram_render needs a contiguous uint8 (h, w, 4) CUDA target")
+        if target is not None:
+            self._same_device(target, "target")
         self._check(self._lib.r2f_histogram_render(
             self._h, counts.data_ptr(), mix.ctypes.data, int(height), image.data_ptr(),
             target.data_ptr() if target is not None else None, int(target.shape[0]) if target is not None else 0,
@@ -513,6 +522,8 @@ class HipContext:
         nbytes = src.numel() * src.element_size()
         if dst.numel() * dst.element_size() != nbytes or not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()):
             raise ValueError("stream_copy needs two contiguous CUDA tensors of the same size in bytes")
+        self._same_device(src, "source")
+        self._same_device(dst, "destination")
         self._check(self._lib.r2f_stream_copy(self._h, src.data_ptr(), dst.data_ptr(), nbytes, self._stream()))
 
     def kernel_timing(self, cls: int):
@@ -527,6 +538,7 @@ class HipContext:
         if not (image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.is_contiguous() and image_u8.dim() == 3
                 and image_u8.shape[2] == 3):
             raise ValueError("histogram_counts needs a contiguous uint8 (H, W, 3) CUDA tensor")
+        self._same_device(image_u8, "image")
         counts = torch.empty((3, 256), dtype=torch.int32, device=self.device)
         self._check(self._lib.r2f_histogram_u8(self._h, image_u8.data_ptr(), int(image_u8.shape[0]), int(image_u8.shape[1]),
                                                counts.data_ptr(), self._stream()))
