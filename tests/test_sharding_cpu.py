@@ -203,6 +203,7 @@ def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
 @pytest.mark.parametrize("world,H,W,scale,flags", [
     (4, 131, 48, 100.0, dict()),            # interior ranks talk to BOTH neighbours (a 2-rank world never does); shards of 33 / 33 / 33 / 32
     (3, 100, 40, 80.0, dict(burn=0.7)),     # odd world, S7's all-reduce over three ranks
+    (8, 163, 40, 100.0, dict()),            # the node's full width: eight ranks, six of them interior, shards of 21 / 21 / 21 / 20 x 5 rows
 ])
 def test_interior_ranks_exchange_with_both_neighbours(tmp_path, world, H, W, scale, flags):
     path = str(tmp_path / "out.npy")
