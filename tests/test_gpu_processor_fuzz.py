@@ -127,3 +127,62 @@ def test_process_under_random_settings(proc, c):
     scaled = ref.shape[:2] != (pipeline_hw if c["canvas"] == "No" else None)
     lim, frac = (3, 5e-3) if (scaled or c["rotation"] or c["nr"]) else (1, 1e-4)
     assert d.max() <= lim and (d > 0).mean() <= frac, (int(d.max()), float((d > 0).mean()), c)
+
+
+@pytest.mark.parametrize("c", _cases(int(os.environ.get("R2F_PROC_FUZZ_CASES", "12"))), ids=lambda c: f"{c['H']}x{c['W']}-f{c['frame'][0]:g}-z{c['zoom']:g}-t{c['turns']}-ms{c['max_scale']}-{c['canvas'].split()[0]}")
+def test_two_phase_api_into_a_destination_texture_under_random_settings(proc, c):
+    """The GPU processor's preview branch (gui.py:2472-2514; gpu_processor.py:715-783, 1865-1890): extract_image_data_cpu ->
+    process_preloaded(dst_texture=...).  The payload's three resolutions are the product's (pinned against the reference by
+    tests/golden/payload_geometry.npz); the frame is the oracle's float render of the oracle-prepared frame at the payload's
+    pipeline resolution, letterboxed by the oracle's copy_to_int.wgsl restatement with the transform those resolutions give."""
+    from raw2film_amd import geometry
+
+    neg, prt, bw = stocks()
+    stock = bw if c["bw"] else neg
+    img = st.apply_matrix3x3(synthetic_frame(c["H"], c["W"], seed=c["seed"] % 997), st.REC709_TO_XYZ)
+    fw, fh = c["frame"]
+    load = dict(frame_width=fw, frame_height=fh, rotation=c["rotation"], zoom=c["zoom"], rotate_times=c["turns"], flip=c["flip"],
+                chroma_nr=c["nr"], resolution=c["resolution"], max_scale=c["max_scale"], canvas_mode=c["canvas"],
+                canvas_scale=c["canvas_scale"], canvas_ratio=c["canvas_ratio"])
+    payload = proc.extract_image_data_cpu(img, **load)
+    pw, ph = payload["pipeline_resolution"]
+    # the frame the pipeline reads, from the oracle's pieces
+    aspect = fw / fh
+    r0, c0, nr, nc = geometry.crop_box(img.shape[0], img.shape[1], 1, aspect, c["flip"])
+    x = np.ascontiguousarray(img[r0:r0 + nr, c0:c0 + nc])
+    if c["rotation"]:
+        x = st.rotate(x, c["rotation"])
+    z = geometry.crop_box(x.shape[0], x.shape[1], c["zoom"], aspect, False)
+    x = np.ascontiguousarray(np.rot90(x[z[0]:z[0] + z[2], z[1]:z[1] + z[3]], c["turns"]))
+    if c["nr"]:
+        x = st.chroma_nr_filter(x, c["nr"])
+    resolution = c["resolution"]  # gpu_processor.py:753-762
+    if resolution is None and c["max_scale"] is not None:
+        resolution = x.shape[:2]
+    if resolution is not None:
+        scale = max(resolution) / max(fw, fh)
+        if c["max_scale"] is not None and scale > c["max_scale"]:
+            resolution = [round(v * c["max_scale"] / scale) for v in resolution]
+        x = _scale_float(x, resolution)
+    assert x.shape[:2] == (ph, pw), (x.shape, (ph, pw))
+    p = oracle_inputs(stock, prt, max(x.shape) / max(fw, fh), halation=c["halation"], mtf=c["mtf"], grain=c["grain"], seed=c["seed"],
+                      matrix=False, halation_green_factor=c["green"], grain_size=c["grain_size"])
+    rendered = st.render(np.ascontiguousarray(x), p)
+    dh, dw = 150 + c["seed"] % 200, 180 + (c["seed"] // 7) % 260
+    dst = torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda")
+    out = proc.process_preloaded(payload, stock, c["grain_size"], 0.4, dst_texture=dst, print_film=prt, exp_kelvin=6000,
+                                 color_masking=1.0, seed=c["seed"], frame_width=fw, frame_height=fh, halation=c["halation"],
+                                 sharpness=c["mtf"], grain=c["grain"], halation_green_factor=c["green"], canvas_mode=c["canvas"],
+                                 canvas_scale=c["canvas_scale"], canvas_ratio=c["canvas_ratio"])
+    assert out is None
+    has_canvas = c["canvas"] != "No"
+    color = geometry.canvas_layout((payload["output_resolution"][1], payload["output_resolution"][0]), c["canvas"], c["canvas_scale"],
+                                   c["canvas_ratio"])[1] if has_canvas else (255, 255, 255)
+    t = geometry.blit_transform((pw, ph), (dw, dh), pipeline_resolution=payload["pipeline_resolution"],
+                                output_resolution=payload["output_resolution"],
+                                canvas_resolution=payload.get("canvas_resolution") if has_canvas else None, canvas_color=color)
+    want = post.blit_rgba8(rendered, dh, dw, t)
+    got = dst.cpu().numpy()
+    np.testing.assert_array_equal(got[..., 3], want[..., 3])
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 2 and (d > 0).mean() <= 5e-3, (int(d.max()), float((d > 0).mean()), c)
