@@ -284,7 +284,8 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
  * Form word: bit 0 = mirrored taps are paired in the entry list; the bits above = R when the channel takes the fully unrolled
  * (2 R + 1)^2 direct form instead of the entry list (bits 1-7); bit 8 = the grain stencil is u v^T to fp32 rounding and runs as two
  * 1-D passes (known after the first tail launch).  FFT word: bit 0 = the channel takes the FFT form (then the direct form's numbers before it are not what runs); the bits
- * above it = window rows * 4096 + window columns of its last launch (0 before the first).  One entry =
+ * above it = window rows * 4096 + window columns of its last launch (0 before the first); bit 30 = that launch multiplied by a REAL
+ * kernel spectrum (taps centrally symmetric around an anchor at the centre of their box: option stencil_fft_real_spectrum).  One entry =
  * 32 packed FMAs per lane for 16 pixels (x2 taps when mirror-paired). */
 int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
 

@@ -500,8 +500,8 @@ class HipContext:
         return image
 
     def stencil_stats(self, which: int):
-        """Per channel: dict(entries, rowsteps, phases, sym, unrolled, kh, kw, q, fft, window) of the device form of stencil `which`
-        (bench.py); fft = 1: the channel takes the FFT form, window = (rows, columns) of its last launch or None."""
+        """Per channel: dict(entries, rowsteps, phases, sym, unrolled, kh, kw, q, fft, window, real_spectrum) of the device form of
+        stencil `which` (bench.py); fft = 1: the channel takes the FFT form, window = (rows, columns) of its last launch or None."""
         out = (C.c_int * 24)()
         self._check(self._lib.r2f_stencil_stats(self._h, int(which), out))
         keys = ("entries", "rowsteps", "phases", "sym", "kh", "kw", "q")
@@ -513,7 +513,9 @@ class HipContext:
             d["separable"] = (d["sym"] >> 8) & 1  # grain stencil only: two 1-D passes of 2 R + 1 taps
             d["sym"] &= 1
             d["fft"] = word & 1
-            d["window"] = ((word >> 1) // 4096, (word >> 1) % 4096) if word >> 1 else None
+            dims = (word >> 1) & 0x1FFFFFFF
+            d["window"] = (dims // 4096, dims % 4096) if dims else None
+            d["real_spectrum"] = (word >> 30) & 1  # its last FFT launch multiplied by a real kernel spectrum (centred symmetric taps)
             stats.append(d)
         return stats
 

@@ -75,6 +75,7 @@ struct r2f_ctx {
     DeviceBuf fft_tw, fft_kf[3][3][kFftShapes], fft_s1, fft_kimg;
     bool fft_kf_valid[3][3][kFftShapes] = {};
     int fft_kf_dims[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // window shape (ny * 4096 + nx) of the channel's last launch
+    int fft_last_real[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // ... and whether that launch multiplied by a real spectrum
     int opt_fft_window = 0;      // window columns: 0 = the cheapest of 256 / 512 / 1024 per stencil and frame, or one of them forced
     int opt_fft_window_max = 512;  // widest window the automatic choice may take (1024 columns: 9 % fewer window elements for the
                                    // 87-tap disc, but the passes run 10-25 % slower per element)
@@ -100,6 +101,11 @@ struct r2f_ctx {
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
     int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
+    // 1: a centrally symmetric tap box (k[i][j] == k[bh-1-i][bw-1-j] bit for bit, anchor at its centre -- every halation disc and
+    // |ifft2| MTF kernel the reference builds, effects.py:200-217, :123-143) is laid out with its anchor on the window origin, so its
+    // spectrum is real: pass 2 reads 8 instead of 16 bytes of it per element (FftConvArgs::kreal).  0: complex spectra for all (A/B).
+    int opt_fft_real = 1;
+    bool fft_kf_real[3][3][kFftShapes] = {};  // what the cached spectrum of (stencil, channel, shape) holds
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
     int lanczos_key[4] = {0, 0, 0, 0};
@@ -486,21 +492,44 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.ax = set.kw / 2 - b[2];
     a.vy = ny - bh + 1;
     a.vx = (nx - bw + 1) & ~3;  // a multiple of 4: window origins stay 16-byte aligned for the float4 stores of pass 3
+    // Real spectra: every channel of the group centrally symmetric around an anchor at the centre of its (odd x odd) box
+    bool kreal = ctx->opt_fft_real && (bh & 1) && (bw & 1) && a.ay == bh / 2 && a.ax == bw / 2;
+    for (int i = 0; i < nch && kreal; ++i) {
+        const int kc = set.kc == 1 ? 0 : chans[i];
+        for (int y = 0; y < bh && kreal; ++y)
+            for (int x = 0; x < bw; ++x) {
+                const float u = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
+                const float v = set.host[((size_t)(b[1] - y) * set.kw + b[3] - x) * set.kc + kc];
+                if (memcmp(&u, &v, sizeof u)) {
+                    kreal = false;
+                    break;
+                }
+            }
+    }
+    a.kreal = kreal ? 1 : 0;
+    a.oy = kreal ? a.ay : 0;
+    a.ox = kreal ? a.ax : 0;
     int rc = ensure_bytes(ctx, ctx->fft_s1, img * sizeof(double2));
     if (rc) return rc;
     for (int i = 0; i < nch; ++i) {
         const int c = chans[i];
         ctx->fft_kf_dims[which][c] = ny * 4096 + nx;
-        if (ctx->fft_kf_valid[which][c][shape]) continue;
-        // the kernel's spectrum: the same two forward passes on its zero-padded image
+        ctx->fft_last_real[which][c] = kreal ? 1 : 0;
+        if (ctx->fft_kf_valid[which][c][shape] && ctx->fft_kf_real[which][c][shape] == kreal) continue;
+        // the kernel's spectrum: the same two forward passes on its zero-padded image -- the box in the window's top left corner
+        // (outputs from row / column 0 on), or, for a real spectrum, wrapped around the window with its anchor on the origin
         std::vector<float> kimg(img, 0.f);
         const int kc = set.kc == 1 ? 0 : c;
         for (int y = 0; y < bh; ++y)
-            for (int x = 0; x < bw; ++x) kimg[(size_t)y * nx + x] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
+            for (int x = 0; x < bw; ++x) {
+                const int py = kreal ? (y - a.ay + ny) % ny : y, px = kreal ? (x - a.ax + nx) % nx : x;
+                kimg[(size_t)py * nx + px] = set.host[((size_t)(b[0] + y) * set.kw + b[2] + x) * set.kc + kc];
+            }
         rc = upload(ctx, ctx->fft_kimg, kimg.data(), img * sizeof(float));
         if (rc) return rc;
         rc = ensure_bytes(ctx, ctx->fft_kf[which][c][shape], img * sizeof(double2));
         if (rc) return rc;
+        ctx->fft_kf_real[which][c][shape] = kreal;
         FftConvArgs k = a;
         k.src.data = static_cast<float*>(ctx->fft_kimg.p);
         k.raw = 1;
@@ -850,6 +879,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         ctx->opt_fft_streams = value;
         return R2F_OK;
     }
+    if (!strcmp(name, "stencil_fft_real_spectrum")) {
+        ctx->opt_fft_real = value ? 1 : 0;
+        return R2F_OK;
+    }
     if (!strcmp(name, "stencil_fft_epilogue_lds")) {
         ctx->opt_fft_epi_lds = value ? 1 : 0;
         return R2F_OK;
@@ -952,6 +985,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.built_q = 0;
     for (int c = 0; c < 3; ++c) {
         ctx->fft_kf_dims[which][c] = 0;
+        ctx->fft_last_real[which][c] = 0;
         for (bool& v : ctx->fft_kf_valid[which][c]) v = false;
     }
     if (which == R2F_KERNEL_GRAIN) ctx->grain_fixed_valid = false;
@@ -1117,7 +1151,7 @@ int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out) {
         const int sep = which == R2F_KERNEL_GRAIN && fr && ctx->grain_fixed_valid && ctx->grain_sep && ctx->opt_grain_sep;
         o[0] = d.n_entries, o[1] = d.n_rowsteps, o[2] = d.n_phases, o[3] = d.sym | (fr << 1) | (sep << 8);
         o[4] = d.kh, o[5] = d.kw, o[6] = set.built_q;
-        o[7] = fft_eligible(ctx, set, c) ? 1 | (ctx->fft_kf_dims[which][c] << 1) : 0;
+        o[7] = fft_eligible(ctx, set, c) ? 1 | (ctx->fft_kf_dims[which][c] << 1) | (ctx->fft_last_real[which][c] << 30) : 0;
     }
     return R2F_OK;
 }

@@ -41,10 +41,17 @@ constexpr int kTLine = 16 * kTPitch;  // 272 doubles per line: = 16 (mod 32), so
 
 // 256-point transform of the line whose element (l + 16 m) sits in v[m] of lane l (l = lane & 15); on return v[q] holds
 // output element (l + 16 q).  w1 = exp(-2 pi i l / 256).  tbuf: this WAVE's transpose buffer, 4 lines x 272 doubles.
+#ifndef R2F_FFT_EXPT
+#define R2F_FFT_EXPT 0  // development switch for fft256: bit 0 no LDS transpose (wrong results, timing only)
+#endif
 template <bool INV>
 __device__ __forceinline__ void fft256(cplx (&v)[16], const cplx w1, double* tbuf, int lane) {
     dft16<INV>(v);
     twiddle_powers<INV>(v, w1);
+    if (R2F_FFT_EXPT & 1) {
+        dft16<INV>(v);
+        return;
+    }
     // 16 x 16 transpose inside each 16-lane group, real parts then imaginary parts through the same buffer
     const int l = lane & 15;
     double* t = tbuf + (lane >> 4) * kTLine;
@@ -285,7 +292,8 @@ __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) 
 // grid (ny / rows per workgroup, pairs).  256-point rows: 16 lanes per row, a workgroup transforms 16 rows, a wave 4 of them;
 // 512-point rows: 32 lanes per row, 8 rows per workgroup, 2 per wave; 1024-point rows: a wave per row, 4 rows per workgroup.
 #ifndef R2F_FFT_EXP
-#define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform
+#define R2F_FFT_EXP 0  // development switch for pass 1: bit 0 no input loads, bit 1 no stores, bit 2 no transform,
+                       // bit 3 timing model of "shared rows are transformed once and stored into both windows' images" (wrong results)
 #endif
 // XL: row length 256 << XL
 template <int XL>
@@ -319,6 +327,10 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc;  // channel-major pair numbering
     const bool hasA = window_of(a, 2 * pc, wyA, wxA), hasB = window_of(a, 2 * pc + 1, wyB, wxB);
     const float* src = a.src.data + (long long)a.chan[ci] * a.src.plane_stride;
+    if (R2F_FFT_EXP & 8) {  // the window row above (same channel, same launch) transforms this workgroup's rows: nothing to do here
+        const int above = pair - (a.gx + 1) / 2;
+        if ((int)(blockIdx.x + 1) * G::ROWS <= a.ny - a.vy && above >= 0 && (a.pair0 + above) / a.ppc == ci && !a.raw) return;
+    }
     cplx v[16];  // v[m]: element l + LPL m of the row
     if (R2F_FFT_EXP & 1) {
 #pragma unroll
@@ -379,6 +391,14 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) sst<ST>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
+    if (R2F_FFT_EXP & 8) {  // ... and this workgroup's rows below the valid outputs are the first rows of the window row below
+        const int below = pair + (a.gx + 1) / 2;
+        if (r >= a.vy && below < a.npairs && (a.pair0 + below) / a.ppc == ci && !a.raw) {
+            char* s2 = simg<ST>(a.s1, below, (long long)a.ny * NX);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sst<ST>(s2, sidx(r - a.vy, G::out_col(l, q), G::NBX), v[q]);
+        }
+    }
 }
 
 #ifndef R2F_FFT_WPE1
@@ -397,33 +417,69 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 #ifndef R2F_FFT_EXP2
 #define R2F_FFT_EXP2 0  // development switch for pass 2: bit 0 no scratch loads, bit 1 no stores, bit 2 no spectrum loads
 #endif
-template <int NBX, int ST>
+// element `idx` of a REAL kernel spectrum (one double per element of the scratch layout)
+__device__ __forceinline__ double& rat(cplx* base, unsigned idx) {
+    return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (idx << 3));
+}
+__device__ __forceinline__ double rat(const cplx* base, unsigned idx) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+}
+
+// KR: the kernel spectrum is real (FftConvArgs::kreal): 8 bytes per element and two multiplies instead of a complex product.
+template <int NBX, int ST, bool KR>
 __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int pair = blockIdx.y, k = blockIdx.x * 16 + (threadIdx.x >> 4);
     char* s1 = simg<ST>(a.s1, pair, (long long)kN * (NBX * 16));
+    const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
+#ifndef R2F_FFT_KR_EARLY
+#define R2F_FFT_KR_EARLY 0  // (measured neutral either way: profiles/r05_fft_levers_ab.txt) bit 0: complex128 / 12-byte scratch, bit 1: complex64 scratch (there the 32 extra VGPRs spill)
+#endif
+    constexpr bool kEarly = (R2F_FFT_KR_EARLY >> (ST == 1 ? 1 : 0)) & 1;
+    // The real spectrum's 16 loads go out AHEAD of the scratch loads (32 VGPRs held through the forward transform): L2 hits that
+    // return first -- loads complete in order, so the transform can still start on the first scratch elements while the later ones
+    // travel -- instead of a second exposed round trip between the two transforms.
+    double kr[16];
+    if (KR && kEarly && mode != 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kr[q] = (R2F_FFT_EXP2 & 4) ? 0.5 + 0.25 * q : rat(kf, sidx(l + 16 * q, k, NBX));
+    }
     cplx v[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) v[m] = (R2F_FFT_EXP2 & 1) ? make_double2(1.0 + m + l, 0.5 * k) : sld<ST>(s1, sidx(l + 16 * m, k, NBX));
     const cplx w1 = a.tw[l];
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
-    const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
     if (mode == 1) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+        for (int q = 0; q < 16; ++q) {
+            if (KR)
+                rat(a.kf_out, sidx(l + 16 * q, k, NBX)) = v[q].x;  // (the imaginary part of a centred symmetric kernel's spectrum is rounding noise)
+            else
+                at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+        }
         return;
     }
+    if (KR) {
+        if (!kEarly) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (R2F_FFT_EXP2 & 4) ? make_double2(0.5, 0.25 * q) : at(kf, sidx(l + 16 * q, k, NBX)));
+            for (int q = 0; q < 16; ++q) kr[q] = (R2F_FFT_EXP2 & 4) ? 0.5 + 0.25 * q : rat(kf, sidx(l + 16 * q, k, NBX));
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = make_double2(v[q].x * kr[q], v[q].y * kr[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (R2F_FFT_EXP2 & 4) ? make_double2(0.5, 0.25 * q) : at(kf, sidx(l + 16 * q, k, NBX)));
+    }
     fft256<true>(v, w1, tbuf, lane);
     if (R2F_FFT_EXP2 & 2) {
         if (v[3].x == 1.2345e300) sst<ST>(s1, 0, v[5]);
         return;
     }
+    // pass 3 only reads the rows that hold valid outputs: [oy, oy + vy)
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 16 * q < a.vy) sst<ST>(s1, sidx(l + 16 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
+        if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<ST>(s1, sidx(l + 16 * q, k, NBX), v[q]);
 }
 
 // 512-row windows: 32 lanes per column, 8 columns per workgroup, 2 per wave; forward by fft512, back by fft512_rev.
@@ -431,7 +487,7 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
 // of the four interleaved columns of the scratch layout, i.e. 32-byte pieces: measured ~25 % slower per byte than the
 // 256-row pass (the host's window choice prices that in; tall kernels have no alternative).  (Pairs as the fast grid index,
 // to share spectrum blocks between the workgroups in flight, was slower for every shape: 7.04 -> 7.46 ms at 256 x 256.)
-template <int NBX, int ST>
+template <int NBX, int ST, bool KR>
 __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const int mode, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 31;
     const int pair = blockIdx.y, k = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -446,27 +502,40 @@ __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const i
     const int f0 = 256 * (l & 1) + (l >> 1);  // spectrum row of register q: f0 + 16 q
     if (mode == 1) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) at(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+        for (int q = 0; q < 16; ++q) {
+            if (KR)
+                rat(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = v[q].x;
+            else
+                at(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+        }
         return;
     }
+    if (KR) {
+        double kr[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(f0 + 16 * q, k, NBX)));
+        for (int q = 0; q < 16; ++q) kr[q] = rat(kf, sidx(f0 + 16 * q, k, NBX));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = make_double2(v[q].x * kr[q], v[q].y * kr[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], at(kf, sidx(f0 + 16 * q, k, NBX)));
+    }
     fft512_rev<true>(v, w1, tbuf, lane);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        if (l + 32 * q < a.vy) sst<ST>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 never reads the rows past the valid outputs
+        if ((unsigned)(l + 32 * q - a.oy) < (unsigned)a.vy) sst<ST>(s1, sidx(l + 32 * q, k, NBX), v[q]);  // pass 3 only reads the valid rows
 }
 
 #ifndef R2F_FFT_WPE2
 #define R2F_FFT_WPE2 2
 #endif
-template <int NBX, bool Y512, int ST>
+template <int NBX, bool Y512, int ST, bool KR>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE2, 8))) void fft_cols_kernel(const FftConvArgs a, const int mode) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     if (Y512)
-        fft_cols_y512_body<NBX, ST>(a, mode, fsm);
+        fft_cols_y512_body<NBX, ST, KR>(a, mode, fsm);
     else
-        fft_cols_body<NBX, ST>(a, mode, fsm);
+        fft_cols_body<NBX, ST, KR>(a, mode, fsm);
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -484,8 +553,10 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     typedef RowGeom<XL> G;
     constexpr int NX = G::NX, LPL = G::LPL;
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
-    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
-    const bool live = r < a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
+    // The grid starts at the workgroup-aligned row at or above oy: a wave's 4 / 2 rows then share their 16-row scratch blocks
+    // and 128-byte lines as they do for oy = 0 (an odd first row had cost the MTF's pass 0.10 of 0.44 ms).  ro: output row.
+    const int pair = blockIdx.y, r = (a.oy & ~(G::ROWS - 1)) + blockIdx.x * G::ROWS + threadIdx.x / LPL, ro = r - a.oy;
+    const bool live = (unsigned)ro < (unsigned)a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
     const char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
     // The epilogue's curve cells: 32 divergent 16-byte gathers per lane.  From global memory they go through the texture path at
     // 0.9 lanes per clock and CU (profiles/r02_gather_rate.txt) -- more of its cycles than all of the pass's coalesced scratch
@@ -504,7 +575,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
     } else {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : 0, l + LPL * m, G::NBX));
+        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
     }
     if (!(R2F_FFT_EXP3 & 4)) {
         G::template fft<true>(v, a, l, wave_tbuf(fsm), lane);
@@ -521,7 +592,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     for (int half = 0; half < 2; ++half) {
         int wy, wx;
         if (!window_of(a, 2 * pc + half, wy, wx)) continue;
-        const int gy = wy + a.ay + r;
+        const int gy = wy + a.ay + ro;
         if (gy >= a.y1) continue;
         float* dbase = dplane + (long long)(gy - a.dst.gy0) * a.W + wx + a.ax;
         // the 16 outputs of this lane first, then the curve on all of them at once (independent gathers), then the stores
@@ -547,13 +618,16 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
                 for (int q = 0; q < CB; ++q) o[CB * b + q] = ob[q];
             }
         }
-        const int c_end = min(a.vx, a.W - (wx + a.ax));  // columns [0, c_end) of the window are valid outputs inside the frame
+        // output columns [0, c_end) of the window -- its scratch columns [ox, ox + c_end) -- are valid outputs inside the frame
+        const int c_end = min(a.vx, a.W - (wx + a.ax));
         if (a.vec4) {
             // through this line's (idle) transpose buffer every lane gets four neighbouring columns and stores them as one
-            // float4 (window origins and the frame width are multiples of 4 here)
-            float* tf = reinterpret_cast<float*>(G::line_buf(wave_tbuf(fsm), lane));
+            // float4 (window origins and the frame width are multiples of 4 here); scratch column c lands at tf[c - ox + pad],
+            // pad = ox rounded up to a multiple of 4, so that output column 0 sits on a 16-byte boundary (a line buffer holds
+            // at least 2 nx + 32 floats and ox < nx / 2: room for the pad in front)
+            float* tf = reinterpret_cast<float*>(G::line_buf(wave_tbuf(fsm), lane)) + ((a.ox + 3) & ~3);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) tf[G::out_col(l, q)] = o[q];
+            for (int q = 0; q < 16; ++q) tf[G::out_col(l, q) - a.ox] = o[q];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -565,7 +639,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (G::out_col(l, q) < c_end) dbase[G::out_col(l, q)] = o[q];
+                if ((unsigned)(G::out_col(l, q) - a.ox) < (unsigned)c_end) dbase[G::out_col(l, q) - a.ox] = o[q];
         }
     }
 }
@@ -605,15 +679,23 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int NBX, bool Y512>
-static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
+template <int NBX, bool Y512, bool KR>
+static void launch_cols_kr(const FftConvArgs& a, int mode, hipStream_t s) {
     const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
     if (a.s32 == 1)
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1>), grid, block, fft_lds_bytes(), s, a, mode);
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1, KR>), grid, block, fft_lds_bytes(), s, a, mode);
     else if (a.s32 == 2)
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 2>), grid, block, fft_lds_bytes(), s, a, mode);
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 2, KR>), grid, block, fft_lds_bytes(), s, a, mode);
     else
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 0>), grid, block, fft_lds_bytes(), s, a, mode);
+        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 0, KR>), grid, block, fft_lds_bytes(), s, a, mode);
+}
+
+template <int NBX, bool Y512>
+static void launch_cols(const FftConvArgs& a, int mode, hipStream_t s) {
+    if (a.kreal)
+        launch_cols_kr<NBX, Y512, true>(a, mode, s);
+    else
+        launch_cols_kr<NBX, Y512, false>(a, mode, s);
 }
 
 template <bool Y512>
@@ -637,7 +719,7 @@ hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
 template <int XL, int EPI>
 static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
     const int rows = RowGeom<XL>::ROWS;
-    const dim3 grid((a0.vy + rows - 1) / rows, a0.npairs);  // rows beyond the valid outputs are never stored
+    const dim3 grid(((a0.oy & (rows - 1)) + a0.vy + rows - 1) / rows, a0.npairs);  // rows without valid outputs are never stored
     FftConvArgs a = a0;
     size_t lds = fft_lds_bytes();
     a.epi_lds_off = 0;

@@ -183,8 +183,13 @@ struct FftConvArgs {
     const double2* tw;        // exp(-2 pi i k / 256), k < 256
     const double2* tw512;     // exp(-2 pi i k / 512), k < 256 (the 512-point lines use k < 32)
     const double2* tw1024;    // exp(-2 pi i k / 1024), k < 64
-    const double2* kfs[3];    // per launch channel: conj of the kernel's 2-D spectrum (scratch layout)
+    const double2* kfs[3];    // per launch channel: conj of the kernel's 2-D spectrum (scratch layout); with `kreal` the same
+                              // layout holds one double per element (read through a const double*)
     double2* kf_out;          // pass 2, mode 1
+    int kreal;                // 1: the kernel is centrally symmetric and was laid out with its anchor on the window origin, so its
+                              // spectrum is REAL: one multiply per component, half the spectrum bytes (pass 2), and the valid
+                              // outputs of a window start at row / column (oy, ox) = the anchor instead of (0, 0)
+    int oy, ox;               // first scratch row / column that holds a valid output (0, 0 unless kreal)
     double2* s1;              // npairs x ny x nx scratch images, transformed in place (layout: sidx in r2f_fft.hip)
     int s32;                  // scratch element: 0 complex128, 1 complex64 (half the bytes; the arithmetic stays fp64), 2 the 12-byte form
     int epilogue;

@@ -265,3 +265,59 @@ def test_twelve_byte_scratch_is_an_opt_in_for_the_halation(ctx):
         ctx.set_option("stencil_fft_scratch96", 0)
     assert_close(packed, ref, 2e-6, 1e-3, "12-byte scratch")
     assert not np.array_equal(packed, exact)
+
+
+@pytest.mark.parametrize("window", WINDOWS)
+def test_real_spectrum_of_centrally_symmetric_taps(ctx, window):
+    """Round 5.  Both production stencils are centrally symmetric around an anchor at the centre of their tap
+    box (effects.py:200-217, :123-143), so with the box wrapped around the window origin the kernel spectrum is real: pass 2 reads
+    8 instead of 16 bytes of it per element and the valid outputs start at the anchor row / column.  Same results as the complex
+    form to a handful of fp32 ulps (both are one rounding of an fp64 correlation), same contract against the oracle, on ragged
+    frames, the scalar store path (odd width) and a row range; `stencil_fft_real_spectrum = 0` is the A/B switch."""
+    force_window(ctx, window)
+    rng = np.random.default_rng(11)
+    for which, k, shape in ((0, ok.compute_halation_kernel(341.33, halation_green_factor=0.3), (300, 700)),
+                            (1, ok.mtf_kernel(stocks()[0].mtf, 341.33), (300, 700)),
+                            (1, ok.mtf_kernel(stocks()[0].mtf, 341.33), (263, 517))):  # odd width: scalar stores, oy = 17 (odd)
+        img = rng.uniform(0.05, 2.0, shape + (3,)).astype(np.float32)
+        img[shape[0] // 3, shape[1] // 2] = 400.0
+        ref = st.convolve_2d(img, k)
+        real = run(ctx, which, img, k, 1, stencil_fft_scratch32=0)
+        flags = [c["real_spectrum"] for c in ctx.stencil_stats(which) if c["fft"]]
+        assert flags and all(flags)
+        cplx = run(ctx, which, img, k, 1, stencil_fft_scratch32=0, stencil_fft_real_spectrum=0)
+        assert not any(c["real_spectrum"] for c in ctx.stencil_stats(which))
+        ctx.set_option("stencil_fft_real_spectrum", 1)
+        assert_close(real, ref, 2e-6, 1e-3, "real spectrum")
+        assert_close(cplx, ref, 2e-6, 1e-3, "complex spectrum")
+        ulps = np.abs(real.astype(np.float64) - cplx) / np.spacing(np.maximum(np.abs(cplx), 1e-3).astype(np.float32))
+        assert ulps.max() <= 2, ulps.max()
+        # a row range with halo rows (what a shard calls) through the real form
+        y0, y1 = 40, shape[0] - 30
+        part = run(ctx, which, img, k, 1, rows=(y0, y1), stencil_fft_scratch32=0)
+        assert_close(part, ref[y0:y1], 2e-6, 1e-3, "row range, real spectrum")
+
+
+def test_asymmetric_or_off_centre_taps_keep_the_complex_spectrum(ctx):
+    """The real form needs k[i][j] == k[bh-1-i][bw-1-j] bit for bit, an odd x odd box and the anchor at its centre; anything else
+    multiplies by the complex spectrum as before."""
+    rng = np.random.default_rng(12)
+    img = rng.uniform(0, 1, (200, 310, 3)).astype(np.float32)
+    base = ok.mtf_kernel(stocks()[0].mtf, 341.33)  # 35 x 35 x 3, symmetric
+    cases = {}
+    k = base.copy()
+    k[3, 5, :] *= np.float32(1.0 + 2 ** -20)  # one tap a few ulps off its mirror image
+    cases["one tap off"] = k
+    k = np.zeros((41, 41, 3), np.float32)
+    k[0:35, 0:35] = base  # symmetric box, but its centre is not the stencil's anchor
+    cases["off-centre box"] = k
+    k = np.zeros((35, 36, 3), np.float32)
+    k[:, :35] = base  # even stencil width: anchor (17, 18), box centre column 17
+    cases["even width"] = k
+    for name, k in cases.items():
+        out = run(ctx, 1, img, k, 1, stencil_fft_scratch32=0)
+        assert uses_fft(ctx, 1) == [1, 1, 1], name
+        assert not any(c["real_spectrum"] for c in ctx.stencil_stats(1)), name
+        assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-3, name)
+    run(ctx, 1, img, base, 1)
+    assert all(c["real_spectrum"] for c in ctx.stencil_stats(1))
