@@ -105,6 +105,8 @@ struct r2f_ctx {
     // |ifft2| MTF kernel the reference builds, effects.py:200-217, :123-143) is laid out with its anchor on the window origin, so its
     // spectrum is real: pass 2 reads 8 instead of 16 bytes of it per element (FftConvArgs::kreal).  0: complex spectra for all (A/B).
     int opt_fft_real = 1;
+    int opt_fft_cols_walk = 1;  // pass 2 of real-spectrum launches as a resident grid walking the launch's pairs (0: one workgroup per pair; A/B)
+    int cu_count = 0;           // multiprocessors of the context's device (grid size of that form)
     bool fft_kf_real[3][3][kFftShapes] = {};  // what the cached spectrum of (stencil, channel, shape) holds
     DeviceBuf lanczos_buf;  // [xofs | yofs | xcoef | ycoef] of the last LANCZOS4 geometry
     DeviceBuf lanczos_f32_buf;  // the same for the float32 up-scale before the path
@@ -509,6 +511,13 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.kreal = kreal ? 1 : 0;
     a.oy = kreal ? a.ay : 0;
     a.ox = kreal ? a.ax : 0;
+    if (!ctx->cu_count) {
+        int n = 0;
+        R2F_HIP(ctx, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        ctx->cu_count = n > 0 ? n : 256;
+    }
+    a.cols_walk = ctx->opt_fft_cols_walk;
+    a.cols_slots = 2 * ctx->cu_count;
     int rc = ensure_bytes(ctx, ctx->fft_s1, img * sizeof(double2));
     if (rc) return rc;
     for (int i = 0; i < nch; ++i) {
@@ -877,6 +886,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "stencil_fft_streams")) {
         if (value < 1 || value > 4) return fail(ctx, R2F_EINVAL, "stencil_fft_streams must be in [1, 4]");
         ctx->opt_fft_streams = value;
+        return R2F_OK;
+    }
+    if (!strcmp(name, "stencil_fft_cols_walk")) {
+        ctx->opt_fft_cols_walk = value ? 1 : 0;
         return R2F_OK;
     }
     if (!strcmp(name, "stencil_fft_real_spectrum")) {

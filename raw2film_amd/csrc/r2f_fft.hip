@@ -27,6 +27,8 @@
 // the row passes absorb in their addressing; the column pass of 512-row windows comes back through fft512_rev, the
 // transposed flow graph.  The host picks the window shape that moves the fewest scratch bytes for the stencil and the
 // frame (an 87-tap disc keeps 66 % of a 256-wide window's columns but 83 % of a 512-wide one's); cfg 4: 256 x 512.
+#include <algorithm>
+
 #include "r2f_launch.h"
 #include "r2f_fft_math.h"
 
@@ -538,6 +540,55 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
         fft_cols_body<NBX, ST, KR>(a, mode, fsm);
 }
 
+
+// ------------------------------------------------------------------------------------- pass 2 as a walk over the launch's pairs
+// 256-row windows with a real spectrum (both production stencils): a grid of resident workgroups (2 per CU), each walking the
+// launch's pairs for ITS 16 columns -- grid (nx / 16, G): pair = blockIdx.y, + G, ... -- with the kernel spectrum's 16 reals per
+// lane kept in registers from pair to pair (same columns, same channel) and no workgroup start-up per pair.  Frame -0.11 ms at
+// 100 MP (4.93 -> 4.82, interleaved A/B, profiles/r05_fft_levers_ab.txt); alone on the GPU the complex64 pass gains (0.64 ->
+// 0.61 ms) and the complex128 pass loses a little (0.82 -> 0.85), the frame gains either way.  A variant whose next pair travelled
+// into a wave-private LDS tile by LDS-DMA (global_load_lds_dwordx4, counted vmcnt waits; complex64 only, 8 KB per wave) while the
+// current one is transformed measured the same as this one (0.59-0.60 against 0.61 alone, 4.84 against 4.82 in the frame): what
+// the pass does not hide is not the latency of its loads (round 3 found the same with a register prefetch); removed again.
+// Loop-invariant values the compiler would otherwise keep in VGPRs from pair to pair (the fifteen twiddle powers: 60 VGPRs; sixteen
+// store offsets) are made opaque per iteration -- recomputing them is what the one-shot kernel does too: 207-209 VGPRs, no spill.
+template <int NBX, int ST>
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fft_cols_walk_kernel(const FftConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
+    double* tbuf = wave_tbuf(fsm);
+    const long long img = (long long)kN * (NBX * 16);
+    const int G = gridDim.y;
+    const cplx w1 = a.tw[l];
+    double kr[16];
+    int ci_have = -1;
+    for (int pair = blockIdx.y; pair < a.npairs; pair += G) {
+        const int ci = (a.pair0 + pair) / a.ppc;
+        char* s1 = simg<ST>(a.s1, pair, img);
+        unsigned sbase = sidx(l, k, NBX);  // element (row l + 16 q, column k) = sbase + q * NBX * 256
+        cplx w = w1;
+        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(sbase));
+        if (ci != ci_have) {
+            const cplx* kf = a.kfs[ci];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) kr[q] = rat(kf, sbase + q * (NBX * 256));
+            ci_have = ci;
+        }
+        cplx v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sbase + m * (NBX * 256));
+        fft256<false>(v, w, tbuf, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = make_double2(v[q].x * kr[q], v[q].y * kr[q]);
+        asm volatile("" : "+v"(w.x), "+v"(w.y));
+        fft256<true>(v, w, tbuf, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<ST>(s1, sbase + q * (NBX * 256), v[q]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- pass 3
 // grid (ceil(vy / rows per workgroup), pairs); lanes and rows as in pass 1
 #ifndef R2F_FFT_EXP3
@@ -708,7 +759,37 @@ static void launch_cols_nx(const FftConvArgs& a, int mode, hipStream_t s) {
         launch_cols<16, Y512>(a, mode, s);
 }
 
+// The walk applies to 256-row windows with a real spectrum in convolution mode.
+static bool cols_walk_applies(const FftConvArgs& a, int mode) { return a.cols_walk && mode == 0 && a.ny == 256 && a.kreal; }
+
+template <int NBX>
+static void launch_cols_walk_st(const FftConvArgs& a, dim3 grid, hipStream_t s) {
+    const dim3 block(kFftThreads);
+    if (a.s32 == 1)
+        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 1>), grid, block, fft_lds_bytes(), s, a);
+    else if (a.s32 == 2)
+        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 2>), grid, block, fft_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 0>), grid, block, fft_lds_bytes(), s, a);
+}
+
+static void launch_cols_walk(const FftConvArgs& a, hipStream_t s) {
+    // as many workgroups as fit the GPU at two per CU (cols_slots), every one walking the same number of pairs when that divides
+    const int cb = a.nx / 16, per = std::max(1, a.cols_slots / cb), iters = (a.npairs + per - 1) / per, G = (a.npairs + iters - 1) / iters;
+    const dim3 grid(cb, G);
+    if (a.nx == 1024)
+        launch_cols_walk_st<64>(a, grid, s);
+    else if (a.nx == 512)
+        launch_cols_walk_st<32>(a, grid, s);
+    else
+        launch_cols_walk_st<16>(a, grid, s);
+}
+
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
+    if (cols_walk_applies(a, mode)) {
+        launch_cols_walk(a, s);
+        return hipGetLastError();
+    }
     if (a.ny == 512)
         launch_cols_nx<true>(a, mode, s);
     else

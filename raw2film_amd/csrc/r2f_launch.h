@@ -190,6 +190,8 @@ struct FftConvArgs {
                               // spectrum is REAL: one multiply per component, half the spectrum bytes (pass 2), and the valid
                               // outputs of a window start at row / column (oy, ox) = the anchor instead of (0, 0)
     int oy, ox;               // first scratch row / column that holds a valid output (0, 0 unless kreal)
+    int cols_walk;            // 1: pass 2 of 256-row windows with a real spectrum walks the launch's pairs per column block
+    int cols_slots;           // ... on a grid of (up to) this many resident workgroups (2 per CU)
     double2* s1;              // npairs x ny x nx scratch images, transformed in place (layout: sidx in r2f_fft.hip)
     int s32;                  // scratch element: 0 complex128, 1 complex64 (half the bytes; the arithmetic stays fp64), 2 the 12-byte form
     int epilogue;

@@ -321,3 +321,28 @@ def test_asymmetric_or_off_centre_taps_keep_the_complex_spectrum(ctx):
         assert_close(out, st.convolve_2d(img, k), 2e-6, 1e-3, name)
     run(ctx, 1, img, base, 1)
     assert all(c["real_spectrum"] for c in ctx.stencil_stats(1))
+
+
+@pytest.mark.parametrize("window", [(256, 256), (256, 512), (256, 1024)])
+def test_pass2_walk_over_the_pairs_is_bit_identical_to_one_workgroup_per_pair(ctx, window):
+    """Round 5: with a real spectrum, pass 2 of 256-row windows runs as a resident grid whose workgroups walk the launch's pairs for
+    their 16 columns (spectrum in registers from pair to pair; `stencil_fft_cols_walk`, default 1).  Same loads, same arithmetic:
+    bit-identical to the one-shot kernel -- on three channels with three different kernels (the spectrum is re-read when the walk
+    crosses into the next channel), with launches that hold fewer pairs than the grid has rows, and on both scratch element types."""
+    force_window(ctx, window)
+    rng = np.random.default_rng(21)
+    H, W = 700, 1900
+    img = rng.uniform(0.2, 3.5, (H, W, 3)).astype(np.float32)
+    k = ok.mtf_kernel(stocks()[0].mtf, 341.33).copy()
+    k[..., 1] = k[..., 1] * np.float32(0.5) + np.float32(0.5) * k[..., 0]  # three different symmetric kernels
+    k[..., 2] = k[::-1, ::-1, 2] * np.float32(0.75)
+    ref = st.convolve_2d(img, k)
+    for s32 in (0, 2):
+        for batch in (192, 3):
+            walk = run(ctx, 1, img, k, 1, stencil_fft_scratch32=s32, stencil_fft_batch=batch, stencil_fft_cols_walk=1)
+            assert all(c["real_spectrum"] for c in ctx.stencil_stats(1))
+            shot = run(ctx, 1, img, k, 1, stencil_fft_scratch32=s32, stencil_fft_batch=batch, stencil_fft_cols_walk=0)
+            np.testing.assert_array_equal(walk, shot)
+            assert_close(walk, ref, 1e-6, 1e-3, f"walk, scratch32={s32}, batch={batch}")
+    ctx.set_option("stencil_fft_batch", 192)
+    ctx.set_option("stencil_fft_scratch32", 2)
