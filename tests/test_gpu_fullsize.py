@@ -209,7 +209,7 @@ def _oracle_window(frame, p, H, W, y0, x0, n, halo, *, mono=False):
     ya, yb = max(y0 - halo, 0), min(y0 + n + halo, H)
     xa, xb = max(x0 - halo, 0), min(x0 + n + halo, W)
     crop = frame[ya:yb, xa:xb].cpu().numpy()
-    x = st.apply_2d_lut(st.apply_matrix3x3(crop, p.matrix), p.lut_2d)
+    x = st.apply_2d_lut(st.apply_matrix3x3(crop, p.matrix) if p.matrix is not None else crop, p.lut_2d)
     if p.halation_kernel is not None:
         x = st.halation(x, p.halation_kernel)
     x = st.multi_channel_interp(st.log_clip(x), p.lut_1d)
@@ -272,6 +272,58 @@ def test_cfg3_45mp_full_pipeline_windows_match_the_oracle():
         _check_windows(out, u8, frame, p, H, W, [(0, 0), (2750, 4100), (H - 128, W - 128), (200, W - 250), (H - 140, 3)], 128, halo)
     finally:
         ctx.close()
+
+
+def test_cfg5_24mp_full_pipeline_windows_match_the_oracle():
+    """BASELINE config 5's frame at its own size with every effect on: 6000 x 4000, 43 / 17 / 5-tap stencils --
+    the halation's 41 x 41 box by FFT (ragged last window row and column on this frame), the 17 x 17 MTF in the unrolled direct
+    form --, once through r2f_render on the context and once through the batch surface the reference's export loop calls,
+    HipProcessor.extract_image_data_cpu -> process_preloaded (gpu_processor.py:715-783, 1643-1693): uint8, <= 1 LSB on <= 1e-4."""
+    from raw2film_amd import HipProcessor
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame_device
+    from test_gpu_parity import setup_ctx
+
+    W, H = 6000, 4000
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, W / 36.0, seed=SEED)
+    assert p.halation_kernel.shape[0] == 43 and p.mtf_kernel.shape[0] == 17
+    halo = p.halation_kernel.shape[0] // 2 + p.mtf_kernel.shape[0] // 2 + p.grain_kernel.shape[0] // 2
+    frame = synthetic_frame_device(H, W, seed=23)
+    ctx = HipContext(0)
+    try:
+        params = setup_ctx(ctx, p)
+        out, u8 = ctx.render(frame, params, want_f32=True, want_u8=True)
+        stats = ctx.stencil_stats(0)
+        assert [c["fft"] for c in stats] == [1, 1, 0] and all(c["fft"] == 0 and c["unrolled"] == 8 for c in ctx.stencil_stats(1))
+        ny, nx = stats[0]["window"]
+        vy, vx = ny - 41 + 1, (nx - 41 + 1) & ~3
+        ly, lx = (H - 1) // vy * vy, (W - 1) // vx * vx  # first row / column of the last (ragged) window row / column
+        assert H - ly < vy and W - lx < vx
+        spots = [(0, 0), (1999, 2873), (H - 128, W - 128), (ly - 64, lx - 64), (ly - 64, 77), (300, lx - 64)]
+        _check_windows(out, u8, frame, p, H, W, spots, 128, halo)
+    finally:
+        ctx.close()
+    # the batch surface: the same frame as a decoded XYZ host array (no 3 x 3), phase 1 + phase 2
+    host = frame.cpu().numpy()
+    q = oracle_inputs(neg, prt, W / 36.0, seed=SEED, matrix=False)
+    proc = HipProcessor(device=0)
+    try:
+        payload = proc.extract_image_data_cpu(host, frame_width=36, frame_height=24)
+        assert tuple(payload["pipeline_resolution"]) == (W, H)
+        got = proc.process_preloaded(payload, neg, 6, 0.4, print_film=prt, frame_width=36, frame_height=24, halation_green_factor=0.3,
+                                     exp_kelvin=6000, color_masking=1.0, seed=SEED)
+        assert got.dtype == np.uint8 and got.shape == (H, W, 3)
+        bad = total = 0
+        for y0, x0 in spots:
+            ref = st.to_uint8(_oracle_window(frame, q, H, W, y0, x0, 128, halo))
+            d = np.abs(got[y0:y0 + 128, x0:x0 + 128].astype(int) - ref.astype(int))
+            assert d.max() <= 1, (y0, x0)
+            bad += int((d > 0).sum())
+            total += d.size
+        assert bad / total <= 1e-4, (bad, total)
+    finally:
+        proc.close()
 
 
 def test_cfg4_100mp_uint8_windows_match_the_oracle(full):
