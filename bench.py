@@ -109,7 +109,8 @@ def main():
     ap.add_argument("--no-alone", action="store_true",
                     help="skip the two extra steps that time the dominant FFT pass with one internal stream (tools/profile_round.sh: "
                          "keeps the profiled launches all of one size)")
-    ap.add_argument("--no-pcie", action="store_true", help="cfg5_batch: skip the PCIe-inclusive BatchSharder leg")
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="skip the host <-> device legs (cfg5_batch: the PCIe-inclusive BatchSharder leg; the others: host_device_copies)")
     ap.add_argument("--no-graph", action="store_true",
                     help="A/B: launch every kernel from the host instead of replaying the frame's HIP graph (the default: everything "
                          "downstream of the halo exchange is captured once and replayed, raw2film_amd/sharding.py)")
@@ -547,6 +548,61 @@ def main():
                     "serial: process_preloaded frame after frame.  Upload-bound (384 MB per 24 MP frame); without_alpha_plane: the same "
                     "with the (H, W, 3) payload of HipProcessor(payload_alpha=False), 288 MB per frame; uint16_payload: the decoded frame handed over as LibRaw's 16-bit output "
                     "(144 MB per frame), converted by r2f_decode_u16 on the device.  Not part of `value`"}
+
+    if not batch and world == 1 and not args.no_pcie:
+        # host <-> device copies reported separately, never in `value`.  What the reference pays at the same boundary:
+        # queue.write_texture of the float frame (gpu_processor.py:279-305) and read_texture of the uint8 result (:1311-1357).
+        # Event-timed on the launch stream, best of 5, pinned host memory; then one end-to-end HipProcessor.process() on a host array.
+        def best_ms(fn, n=5):
+            best = float("inf")
+            for _ in range(n):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b))
+            return best
+
+        copies = {}
+        host_f32 = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True)
+        host_f32.copy_(frame)
+        dev_f32 = torch.empty_like(frame)
+        copies["h2d_f32_ms"] = best_ms(lambda: dev_f32.copy_(host_f32, non_blocking=True))
+        host_u16 = torch.empty((H, W, 3), dtype=torch.int16, pin_memory=True)  # the 16 bits of LibRaw's uint16 output
+        host_u16.copy_((frame.clamp(0, 1) * 65535).to(torch.int32).to(torch.int16))
+        dev_u16 = torch.empty((H, W, 3), dtype=torch.int16, device=frame.device)
+
+        def up_u16():
+            dev_u16.copy_(host_u16, non_blocking=True)
+            proc.ctx.decode_u16(dev_u16, 1.0)  # raw_conversion.py:50-52 on the device (r2f_decode_u16)
+
+        copies["h2d_u16_ms"] = best_ms(up_u16)
+        dev_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=frame.device)
+        host_u8 = torch.empty((H, W, 3), dtype=torch.uint8, pin_memory=True)
+        copies["d2h_u8_ms"] = best_ms(lambda: host_u8.copy_(dev_u8, non_blocking=True))
+        del dev_f32, dev_u16, dev_u8, host_u16, host_u8
+        # the drop-in call on a host array, as the GUI's export makes it: upload (pageable NumPy memory), render, uint8 download
+        host_np = host_f32.numpy()
+        e2e = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + i, lens_correction=False, **settings)
+            e2e.append((time.perf_counter() - t0) * 1e3)
+        assert res.dtype == np.uint8 and res.shape == (H, W, 3)
+        copies["process_end_to_end_ms"] = min(e2e)
+        copies["process_end_to_end_first_ms"] = e2e[0]
+        gb = H * W * 3 / 1e9
+        copies["GB_per_s"] = {"h2d_f32": 4 * gb / (copies["h2d_f32_ms"] * 1e-3), "h2d_u16": 2 * gb / (copies["h2d_u16_ms"] * 1e-3),
+                              "d2h_u8": gb / (copies["d2h_u8_ms"] * 1e-3)}
+        copies["note"] = ("SURVEY 8(d): host <-> device copies of this frame, never part of `value`.  h2d_f32: pinned fp32 HWC3 frame -> device "
+                          "(the reference's write_texture, gpu_processor.py:279-305); h2d_u16: pinned uint16 frame -> device + r2f_decode_u16 "
+                          "(raw_conversion.py:50-52 on the device); d2h_u8: the uint8 result -> pinned host (read_texture, :1311-1357); events on "
+                          "the launch stream, best of 5.  process_end_to_end: wall clock of HipProcessor.process(host ndarray, cache=False) -> "
+                          "uint8 ndarray, best of 3 (first call listed too: it builds tables and pinned staging buffers)")
+        result["host_device_copies"] = copies
+        del host_f32, host_np
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
