@@ -147,10 +147,20 @@ struct r2f_ctx {
         r2f_params p{};  // seed zeroed
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        hipEvent_t done = nullptr;  // recorded behind every launch of `exec`: the executable graph must outlive its last replay
         uint64_t last_use = 0;
         bool never = false;  // a capture of this entry failed: kernel by kernel from now on
     };
     std::vector<RenderGraph> graphs;
+    // Executable graphs that left the cache (evicted, or dropped because the generation moved) while a replay of them may still be
+    // running: destroyed once their `done` event has completed -- polled at the next r2f_render, no device-wide synchronisation
+    // inside a render (a caller cycling through more than 8 buffer sets would otherwise stall every stream of the device per eviction).
+    struct RetiredGraph {
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        hipEvent_t done;
+    };
+    std::vector<RetiredGraph> retired;
     uint64_t graphs_generation = 0;  // `generation` the entries (and `warm`) belong to
     uint64_t graph_clock = 0;
     RenderGraph warm;                // structure (shape, layout, parameters) of the last frame launched kernel by kernel
@@ -381,18 +391,48 @@ int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s) {
     return R2F_OK;
 }
 
+// Destroy the retired graphs whose last replay has completed (wait = true: all of them, after their events -- r2f_destroy).
+void reap_retired_graphs(r2f_ctx* ctx, bool wait) {
+    size_t kept = 0;
+    for (auto& r : ctx->retired) {
+        hipError_t e = r.done ? (wait ? hipEventSynchronize(r.done) : hipEventQuery(r.done)) : hipSuccess;
+        if (e == hipErrorNotReady) {
+            ctx->retired[kept++] = r;
+            continue;
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // (an event recorded inside a caller's stream capture cannot be queried: keep the graph until
+            if (!wait) {              //  the context goes, where the device has been synchronised)
+                ctx->retired[kept++] = r;
+                continue;
+            }
+        }
+        if (r.exec) (void)hipGraphExecDestroy(r.exec);
+        if (r.graph) (void)hipGraphDestroy(r.graph);
+        if (r.done) (void)hipEventDestroy(r.done);
+    }
+    ctx->retired.resize(kept);
+}
+
+// Take entry `g` out of service: its executable graph may still be replaying, so it is parked behind its `done` event.
+void retire_render_graph(r2f_ctx* ctx, r2f_ctx::RenderGraph& g) {
+    if (g.exec) {
+        ctx->retired.push_back({g.graph, g.exec, g.done});
+        ++ctx->stat_dropped;
+    } else {
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        if (g.done) (void)hipEventDestroy(g.done);
+    }
+    g.graph = nullptr, g.exec = nullptr, g.done = nullptr;
+}
+
 void drop_render_graphs(r2f_ctx* ctx) {
     // a replay of one of them may still be running (an option changed between two asynchronous frames; table uploads and buffer
-    // growth have synchronised already): an executable graph must outlive its last launch
-    bool any = false;
-    for (const auto& g : ctx->graphs) any = any || g.exec;
-    if (any) (void)hipDeviceSynchronize();
-    for (auto& g : ctx->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec), ++ctx->stat_dropped;
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
+    // growth have synchronised already): an executable graph must outlive its last launch -- parked, not waited for
+    for (auto& g : ctx->graphs) retire_render_graph(ctx, g);
     ctx->graphs.clear();
     ctx->warm_valid = false;
+    reap_retired_graphs(ctx, false);
 }
 
 plan::Taps taps_of(const StencilSet& s) { return plan::Taps{s.host.data(), s.kh, s.kw, s.kc}; }
@@ -772,6 +812,7 @@ void r2f_destroy(r2f_ctx* ctx) {
     DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();  // nothing in flight may still read what is freed below
     drop_render_graphs(ctx);
+    reap_retired_graphs(ctx, true);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     ctx->frame_buf.release();
     ctx->lut2d_buf.release();
@@ -1683,6 +1724,7 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
         ++ctx->stat_eager;
         return render_launches(ctx, p, in, in_layout, out_f32, out_u8, H, W, workspace, stream);
     }
+    if (!ctx->retired.empty()) reap_retired_graphs(ctx, false);
     if (ctx->graphs_generation != ctx->generation) {  // a table, stencil, option or internal buffer moved: frozen pointers are stale
         drop_render_graphs(ctx);
         ctx->graphs_generation = ctx->generation;
@@ -1733,6 +1775,7 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
             if (rc) return rc;
         }
         R2F_HIP(ctx, hipGraphLaunch(g.exec, s));
+        if (g.done) R2F_HIP(ctx, hipEventRecord(g.done, s));
         ++ctx->stat_replays;
         return R2F_OK;
     }
@@ -1746,13 +1789,7 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
             size_t lru = 0;
             for (size_t i = 1; i < ctx->graphs.size(); ++i)
                 if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
-            if (ctx->graphs[lru].exec) {
-                // a replay of it may still be running: its executable graph must outlive that
-                R2F_HIP(ctx, hipDeviceSynchronize());
-                (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
-                ++ctx->stat_dropped;
-            }
-            if (ctx->graphs[lru].graph) (void)hipGraphDestroy(ctx->graphs[lru].graph);
+            retire_render_graph(ctx, ctx->graphs[lru]);  // (a replay of it may still be running: destroyed behind its event, later)
             ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
         }
         ctx->graphs.push_back(key);
@@ -1789,12 +1826,14 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     g.graph = graph;
     g.exec = exec;
     g.last_use = ++ctx->graph_clock;
+    if (hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) g.done = nullptr, (void)hipGetLastError();
     ++ctx->stat_captures;
     if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
         rc = write_frame_params(ctx, p, s);
         if (rc) return rc;
     }
     R2F_HIP(ctx, hipGraphLaunch(g.exec, s));
+    if (g.done) R2F_HIP(ctx, hipEventRecord(g.done, s));
     ++ctx->stat_replays;
     return R2F_OK;
 }

@@ -203,6 +203,49 @@ def test_more_than_eight_buffer_sets_evict_the_least_recently_used_graph():
     proc.close()
 
 
+def test_an_eviction_does_not_wait_for_other_work_on_the_device():
+    """evicting a captured graph used to hipDeviceSynchronize() inside r2f_render -- a caller cycling through
+    more than eight buffer sets (a preview with a ring of destination textures) stalled every stream of the device per eviction.
+    The executable graph is now parked behind an event recorded at its last launch and destroyed once that has completed.  Here
+    a long spin kernel runs on another stream (standing in for a second context's work) while this context evicts: the renders
+    return while the spin is still running, the results are the eager ones', and the parked graphs go away afterwards."""
+    import time
+
+    from raw2film_amd import HipProcessor
+
+    H, W = 96, 160
+    neg, kw = _settings(H, W, 0.5)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=2)).cuda()
+    proc = HipProcessor(device=0)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=1, matrix=_rec709(), **kw)
+    outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(12)]
+    for _ in range(2):  # seen, then captured: 12 captures through 8 slots, 4 evictions already
+        for o in outs:
+            proc.ctx.render(frame, params, out_f32=o)
+    torch.cuda.synchronize()
+    want = outs[0].clone()
+    side = torch.cuda.Stream()
+    busy = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(int(4e9))  # seconds of spinning on the other stream
+        busy.record()
+    t0 = time.perf_counter()
+    for o in outs:  # every one of these evicts (the cache holds the 8 most recent sets, these come round-robin)
+        proc.ctx.render(frame, params, out_f32=o)
+    torch.cuda.current_stream().synchronize()
+    dt = time.perf_counter() - t0
+    still_running = not busy.query()
+    s = proc.ctx.render_stats()
+    torch.cuda.synchronize()
+    assert still_running, "the spin kernel was meant to outlast the renders: lengthen it"
+    assert dt < 0.5, dt
+    assert s["captures"] == 24 and s["dropped"] >= 16, s
+    assert all(torch.equal(o, want) for o in outs)
+    proc.ctx.render(frame, params, out_f32=outs[0])  # (polls the parked graphs: all of their events have completed by now)
+    torch.cuda.synchronize()
+    proc.close()
+
+
 def test_fresh_buffers_every_frame_are_never_captured_and_two_alternating_sets_are():
     """Results a caller keeps alive arrive in new buffers every frame: capturing those would cost a graph per frame that is never
     replayed.  Double buffering (A, B, A, B, ...) is captured from the second round on."""
