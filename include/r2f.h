@@ -113,6 +113,12 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int 
  * Stencils of >= 400 taps run as fp64 overlap-save FFTs (like cv.filter2D's own DFT branch above 11 x 11 taps, which the
  * reference's CPU path takes for both of them); their pass scratch (1 MiB per window pair in flight, 192 by default) and
  * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use.
+ * Non-finite samples: in the direct form a NaN / infinity in a stencil's input comes out as NaN in every output whose tap box
+ * (plus up to three zero-weight padding rows / columns) covers it, like the per-tap loop of the reference's convolution.wgsl; the FFT form takes such a sample as 0 instead (a NaN
+ * handed to the transforms would come back in every output of its 256 x 512 window) -- the outputs inside the tap box are then
+ * those of the frame with that sample zeroed, everything further away is untouched in both forms.  The same stencil therefore
+ * treats a bad sample differently depending on which form its size selects (r2f_stencil_stats); through r2f_render both end
+ * finite, because S3's max(x, log_eps) replaces a NaN (tests/test_gpu_hostile.py pins both behaviours).
  *
  * One submit per frame, like the reference's single command encoder (gpu_processor.py:1760 create_command_encoder ...
  * :1877 queue.submit): the second time a frame arrives with the same buffers, shape and parameters (the seed excepted) its

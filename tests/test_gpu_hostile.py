@@ -301,6 +301,61 @@ def test_non_finite_and_absurd_samples_stay_inside_the_stencils_reach(scale, sha
         c.close()
 
 
+def test_a_non_finite_sample_in_a_stencil_stage_direct_form_against_fft_form():
+    """what each form of ONE stencil does with a NaN / infinity in its input plane, pinned at the stage entry (no
+    epilogue).  Direct form (like the per-tap loop of convolution.wgsl): NaN in every output whose tap box covers the sample,
+    everything else bit-identical to the clean plane's result.  FFT form: the sample enters the correlation as 0 (pass 1; a NaN
+    handed to the transforms would come back in every output of its window), so every output is finite, the outputs inside the
+    tap box are those of the plane with that sample zeroed, and the rest agrees with the clean result to the transforms' rounding.
+    include/r2f.h documents the divergence."""
+    from oracle import kernels as ok
+    from raw2film_amd.context import HipContext
+
+    rng = np.random.default_rng(8)
+    H, W = 300, 420
+    img = rng.uniform(0.05, 2.0, (H, W, 3)).astype(np.float32)
+    k = ok.compute_halation_kernel(200.0, halation_green_factor=0.3)  # 51 x 51: by FFT by default, direct with stencil_fft = 0
+    r = k.shape[0] // 2
+    c = HipContext(0)
+    try:
+        def run(a, fft):
+            c.set_option("stencil_fft", fft)
+            c.set_kernel(0, k)
+            src = torch.from_numpy(np.ascontiguousarray(np.transpose(a, (2, 0, 1)))).cuda()
+            dst = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+            c.stage_stencil(0, src, dst, y0=0, y1=H, H_global=H)
+            return np.transpose(dst.cpu().numpy(), (1, 2, 0))
+
+        for bad_value in (np.nan, np.inf, -np.inf):
+            bad, zeroed = img.copy(), img.copy()
+            y, x = 140, 200
+            bad[y, x, 0] = bad_value
+            zeroed[y, x, 0] = 0.0
+            box = np.zeros((H, W), bool)
+            box[y - r:y + r + 1, x - r:x + r + 1] = True
+            for fft in (0, 1):
+                clean, got, zero = run(img, fft), run(bad, fft), run(zeroed, fft)
+                assert [s["fft"] for s in c.stencil_stats(0)][:2] == [fft, fft]
+                np.testing.assert_array_equal(got[..., 1:], clean[..., 1:])  # the other channels never see the sample
+                g, cl, z = got[..., 0], clean[..., 0], zero[..., 0]
+                if fft:
+                    assert np.isfinite(g).all()
+                    np.testing.assert_array_equal(g, z)  # exactly the plane with the sample zeroed
+                    assert np.max(np.abs(g[~box] - cl[~box]) / np.maximum(np.abs(cl[~box]), 1e-3)) <= 1e-6
+                else:
+                    taps = k[::-1, ::-1, 0] != 0  # correlation: output (y - i + r, x - j + r) reads the sample through tap (i, j)
+                    hit = np.zeros((H, W), bool)
+                    hit[y - r:y + r + 1, x - r:x + r + 1] = taps
+                    assert not np.isfinite(g[hit]).any()  # (inf - inf and 0 * inf included: NaN or +-inf, never a finite number)
+                    # (the entry list pads the box with zero weights -- columns to a radius of 2 mod 4 for the mirrored pairs, rows to
+                    # the four output rows a lane owns per input row -- and 0 * NaN is NaN: up to three more rows / columns are poisoned)
+                    wide = np.zeros((H, W), bool)
+                    wide[y - r - 3:y + r + 4, x - r - 3:x + r + 4] = True
+                    np.testing.assert_array_equal(g[~wide], cl[~wide])
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("scale,shape", [(341.33, (300, 600)), (60.0, (200, 300))])
 def test_non_finite_values_inside_tables_and_stencils_neither_fault_nor_hang(scale, shape):
     """NaN / infinities sprinkled over each table and stencil in turn: the result may be garbage (so is the reference's), the
