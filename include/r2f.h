@@ -135,7 +135,12 @@ int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
 
 /* The per-render uniform write: p->seed -> the context's device-side frame block, asynchronously on `stream`
  * (gpu_processor.py:585-597: the uniform buffer `buffer_params_grain` with a fresh random seed, made ahead of the dispatches;
- * noise.wgsl:1-6 reads it).  r2f_render and, unless R2F_F_FRAME_RESIDENT is set, every stage entry point that makes grain does this itself. */
+ * noise.wgsl:1-6 reads it).  r2f_render and, unless R2F_F_FRAME_RESIDENT is set, every stage entry point that makes grain does this itself.
+ * ONE STREAM IN FLIGHT PER CONTEXT: the frame block, like the context's FFT scratch, internal streams and capture stream, exists once
+ * per context.  Frames (or stage calls) of one context must be ordered on one stream (or by events): issued on two streams at once,
+ * the write for frame B may land before frame A's grain kernels have read the seed, and both would share the scratch.  The
+ * reference's processors are entered by one thread at a time for the same reason (mutable caches; gui.py:2119-2129); callers that
+ * want frames in flight side by side use one context each (BatchSharder does). */
 int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream);
 
 /* --- stage entry points (row-shard aware): one per compute pass of

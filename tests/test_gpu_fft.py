@@ -87,6 +87,12 @@ def test_eligibility_limits(ctx):
         out = run(ctx, 1, img, k, 1)
         assert uses_fft(ctx, 1) == [1, 1, 1], shape
         assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 2e-6, 1e-3, f"mixed-sign {shape}")  # (as tight as the large kernels of the FFT form)
+        # ... unless the override is switched off: the size rules and the min-taps / scratch32 knobs are back in charge
+        out = run(ctx, 1, img, k, 1, stencil_fft_mixed_sign=0)
+        assert uses_fft(ctx, 1) == [0, 0, 0], shape
+        # (a float32 sum of cancelling taps is accurate relative to sum |w x|, not to the result: the reason for the override)
+        assert_close(out, st.convolve_2d(img, np.repeat(k, 3, axis=2)), 1e-4, 1e-2, f"mixed-sign {shape}, direct form")
+        ctx.set_option("stencil_fft_mixed_sign", 1)
 
     # rectangular boxes count too
     k = np.zeros((87, 87, 1), np.float32)
