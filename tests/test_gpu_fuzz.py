@@ -111,10 +111,22 @@ def test_random_configuration(ctx, c):
         # float32 sum of products -- the device's direct form or the reference's own -- can be; 4 of 1 620 soak cases with stepped
         # grain LUTs sat 3-10 % over the bound without this term (profiles/r04_parity_budget.txt)
         cond = truth.conditioning(base, p, chroma_nr=c["nr"], ulps=1.0, exact=exact)
-        bound = 1e-5 * np.maximum(np.abs(exact), 1e-3) + slack + cond
-        worst = float(np.max(np.abs(got.astype(np.float64) - exact) / bound))
+        contract = 1e-5 * np.maximum(np.abs(exact), 1e-3)
+        bound = contract + slack + cond
+        err = np.abs(got.astype(np.float64) - exact)
+        worst = float(np.max(err / bound))
         _report("truth", worst, c)
         assert worst <= 1.0, f"|hip - truth| reaches {worst:.3f} x (1e-5 max(|truth|, 1e-3) + |oracle - truth| + conditioning): {c}"
+        # How much of the frame is judged by the slack rather than by the contract: where the float32 oracle itself
+        # jumps (a stepped grain or output LUT), |oracle - truth| makes the bound as wide as the step, and a kernel wrong exactly
+        # there would pass.  Reported per case (soak statistics) -- and the samples that NEED the slack, i.e. where the device is
+        # further from the truth than the bare contract allows, must be rare: jumps sit on isolated samples, not on regions.
+        wide = float(np.mean(slack + cond > contract))
+        needs = float(np.mean(err > contract))
+        _report("slack_covers", wide, c)
+        _report("needs_slack", needs, c)
+        assert needs <= 0.002, f"{needs:.4f} of the samples are outside the bare contract (inside the slack): {c}"
+        assert wide <= 0.05, f"the slack is wider than the contract on {wide:.4f} of the samples: {c}"
     else:
         _report("contract", assert_close(got, ref, 1e-5, 1e-3, str(c)) / 1e-5, c)
     assert np.abs(u8.cpu().numpy().astype(int) - st.to_uint8(ref).astype(int)).max() <= 1
