@@ -243,6 +243,12 @@ def main():
     def drain_timing():
         return [proc.ctx.kernel_timing(cls) for cls in range(6)]  # (total ms, launches, algorithmic bytes) per class
 
+    # N > 1: the renderer measures its candidate schedules (one / two exchanges, interior halation ahead of the exchange or not)
+    # on its first frames -- untimed warm-up frames like the others, the same number on every rank
+    tune_steps = 0
+    while not use_processor and getattr(renderer, "tuning", False) and tune_steps < 32:
+        step()
+        tune_steps += 1
     for _ in range(max(args.warmup, 2 if replaying else 0)):  # (the graph is captured on the second frame)
         step()
     barrier()
@@ -301,10 +307,18 @@ def main():
             "stocks": "synthetic stand-ins portra400_like + k2383_like (spectral_film_lut data unavailable offline)",
             "sharding": (f"batch of {args.frames} frames, frame i -> rank i mod {world}, no collectives" if batch else
                          "single GPU" if world == 1 else
-                         f"row-sharded over {world} GPUs, one RCCL halo exchange per frame (exposure rows for both stencils)"),
+                         f"row-sharded over {world} GPUs, RCCL halo exchange(s) per frame: schedule measured on the first frames (shard_schedule)"),
             "options": args.opt,
         },
     }
+    if not use_processor and world > 1:
+        ex, sp = renderer.schedule or (1, False)
+        result["config"]["shard_schedule"] = {
+            "exchanges": ex, "interior_halation_ahead_of_the_exchange": bool(sp),
+            "candidates": [list(c) for c in renderer._candidates], "measured_ms_max_over_ranks": renderer.tuned_ms,
+            "note": "RowShardedRenderer times every candidate schedule on its first frames (events on the launch stream, exchange "
+                    "included) and all ranks take the one whose slowest rank was fastest; 1 exchange = exposure halo widened by the MTF "
+                    "reach, 2 = exposure halo, then density halo (saves a halation window row per shard)"}
 
     if use_processor:
         stats1 = proc.ctx.render_stats()

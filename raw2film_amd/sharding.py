@@ -198,7 +198,8 @@ class RowShardedRenderer:
     """
 
     def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,
-                 group=None, rank=None, world=None, side_grain: bool = False, graph: bool = False, split_halation="auto"):
+                 group=None, rank=None, world=None, side_grain: bool = False, graph: bool = False, split_halation="auto",
+                 exchanges="auto", tune_frames: int = 2):
         import torch
         import torch.distributed as dist
 
@@ -213,19 +214,28 @@ class RowShardedRenderer:
         ha, hb = backend.halation_taps if halation else (0, 0)
         ma, mb = backend.mtf_taps if mtf else (0, 0)
         self.halation, self.mtf, self.grain, self.burn = halation, mtf, grain, burn
-        # With both stencils on, ONE exchange: the exposure halo is widened by the MTF reach and every rank also computes
-        # the halation for the density rows its own MTF stencil will read (2 x 17 rows of redundant halation per shard at
-        # 100 MP) -- the same bytes on the wire as two exchanges, one latency instead of two.
-        self.single_exchange = halation and mtf
-        ea, eb = (ha + ma, hb + mb) if self.single_exchange else (ha, hb)
+        # With both stencils on there are two ways to feed the MTF's halo rows:
+        #   ONE exchange: the exposure halo is widened by the MTF reach and every rank also computes the halation for the density
+        #     rows its own MTF stencil will read (2 x 17 rows of redundant halation per shard at 100 MP) -- the same bytes on the
+        #     wire as two exchanges, one latency instead of two;
+        #   TWO exchanges: exposure halo for the halation only, the halation covers exactly the own rows, then r_m rows of DENSITY
+        #     travel.  A second latency -- but the halation's FFT form works in window rows (172 rows at 100 MP), and a 1/8 shard's
+        #     1 024 own rows are 5.95 of them where 1 058 rows are 6.15, i.e. seven: one window row in seven saved.
+        # Buffers are laid out for the wider (single-exchange) halo; which schedule runs is decided below (`exchanges`).
+        both = halation and mtf
+        self.single_exchange = both
+        ea, eb = (ha + ma, hb + mb) if both else (ha, hb)
         self.plan = ShardPlan(H, W, rank, world, r0, r1, (ea, eb), (ma, mb))
         # Per plane: a channel whose halation stencil is a single tap (blue on a colour stock) needs exposure halo rows only for
         # the MTF reach, not for the halation's -- 17 instead of 59 rows at 100 MP, 6.7 instead of 8.7 MB per direction.
         per = getattr(backend, "halation_taps_per_channel", None) if halation else None
         if per:
-            self.halo_e_ch = [((a + ma, b + mb) if self.single_exchange else (a, b)) for a, b in per]
+            self._halo_e_single = [((a + ma, b + mb) if both else (a, b)) for a, b in per]
+            self._halo_e_two = [(a, b) for a, b in per]
         else:
-            self.halo_e_ch = [(ea, eb)] * 3
+            self._halo_e_single = [(ea, eb)] * 3
+            self._halo_e_two = [(ha, hb)] * 3
+        self.halo_e_ch = self._halo_e_single
         smallest = min(b - a for a, b in shard_rows(H, world))
         need = max(ea, eb, ma, mb)
         if world > 1 and smallest < need:
@@ -253,8 +263,7 @@ class RowShardedRenderer:
         # per kernel, which is what a 1/8 row shard (~1 ms of device work) needs to stay device-bound.  With world == 1 there
         # is no exchange and the front kernel is part of the graph.  Results are the eager path's, bit for bit.
         self.graph = bool(graph and not burn and not self.side_grain and getattr(backend, "device", None) is not None
-                          and torch.cuda.is_available() and (halation or mtf or grain)
-                          and (world == 1 or self.single_exchange or not mtf))  # no exchange downstream of the front
+                          and torch.cuda.is_available() and (halation or mtf or grain))
         # The halation in three calls: the interior rows -- whose stencil reads own exposure rows only -- are launched BEFORE the
         # halo exchange is waited for (they run while the halos travel), a band at each inner boundary after it.  A band is one
         # window row of the FFT form high (172 rows at 100 MP) where that is known, so the three calls together cover the same
@@ -263,25 +272,114 @@ class RowShardedRenderer:
         # bands are small launches: measured on one GPU, tools/shard_model.py), the interior front kernel already covers
         # 4.9 ns per kilopixel of own rows, and the exchange is MODELLED at 30 us + bytes / 55 GB/s (one xGMI link; no multi-GPU
         # node was available to measure it).  split_halation = True / False overrides the estimate.
+        self._graphs = {}   # key -> [calls seen, captured graphs or None], most recently used last
+        self._graphs_state = None  # _graph_state() the graphs were captured from
+        self._identity_done = 0  # channel mask front_split finished (world == 1 only)
         self.split = None
-        want_split = bool(split_halation)
-        if split_halation == "auto":
-            halo_bytes = sum(a for a, _ in self.halo_e_ch) * W * 4
-            exchange_ms = 0.03 + halo_bytes / 55e6
-            front_ms = 4.9e-6 * max(p.rows - (ea + eb), 0) * W / 1e3
-            want_split = exchange_ms - front_ms > 0.05
-        if halation and self.single_exchange and world > 1 and want_split:
+        self._split_plan = None
+        band_of = getattr(backend, "halation_band_rows", lambda W, rows: 0)
+        if halation and both and world > 1:
             need_t, need_b = (ha + ma, hb + mb)
-            band = getattr(backend, "halation_band_rows", lambda W, rows: 0)(W, self.d_hi - self.d_lo)
+            band = band_of(W, self.d_hi - self.d_lo)
             top = max(need_t, band) if rank > 0 else 0
             bot = max(need_b, band) if rank < world - 1 else 0
             lo, hi = self.d_lo + top, self.d_hi - bot
             if hi - lo >= max(need_t, need_b, 1):
-                self.split = (lo, hi)
+                self._split_plan = (lo, hi)
+        # The schedules a rank can run: (exchanges, split).  Which one is fastest depends on what nobody can know ahead of the first
+        # frames -- how long the exchange takes on this node's links and how much of it the interior front kernel already covers
+        # (round 4 decided from a MODELLED 30 us + bytes / 55 GB/s) -- so "auto" MEASURES: after the first
+        # frame (which builds tables) every candidate renders `tune_frames` frames between two events on the launch stream, the
+        # ranks agree on the schedule whose slowest rank is fastest (one all-reduce of a few floats; the two-exchange form needs
+        # both neighbours to send density rows, so the choice must be the same everywhere), and graphs are captured for that one.
+        # Every candidate renders the frame correctly (results agree to the FFT form's rounding noise), so tuning costs no frame.
+        # Two exchanges are a candidate only where they save a halation window row on this rank's shard.
+        # (the candidate list must be the same on every rank -- they walk it in lockstep and reduce one time per candidate -- so it
+        # is derived from the geometry of a MIDDLE rank's shard, not from this rank's own; a rank without room for the split runs
+        # that candidate unsplit)
+        saves_row = False
+        if both and world > 1:
+            base = H // world
+            vy = band_of(W, base)
+            if vy > 0:
+                saves_row = -(-base // vy) < -(-(base + ma + mb) // vy)
+        cands = []
+        if both and world > 1:
+            ex_opts = [1, 2] if exchanges == "auto" else [int(exchanges)]
+            if exchanges == "auto" and not saves_row:
+                ex_opts = [1]
+            for ex in ex_opts:
+                if ex == 1:
+                    cands += [(1, sp) for sp in ([False, True] if split_halation == "auto" else [bool(split_halation)])]
+                else:
+                    cands.append((2, False))
+        self._candidates = cands
+        self._tune = None  # tuning state: {"i": candidate index, "n": frames timed, "ms": [[...], ...]} while measuring
+        self.tune_frames = int(tune_frames)
+        self.schedule = None
+        self.tuned_ms = None  # per candidate: the measured frame time (max over ranks) the choice was made from
+        can_measure = (getattr(backend, "device", None) is not None and torch.cuda.is_available())
+        if len(cands) > 1 and can_measure and self.tune_frames > 0:
+            self._tune = {"i": 0, "n": -1, "ms": [[] for _ in cands]}
+            self._set_schedule(cands[0])
+        elif cands:
+            # nothing to choose from, or a backend without a device to time (the CPU backends of the test-suite): the first
+            # candidate -- one exchange, no split -- unless the caller fixed the schedule
+            self._set_schedule(cands[0])
         self.trace = None   # a list here collects (event name) in issue order: tests look at the overlap structure
-        self._graphs = {}   # key -> [calls seen, CUDAGraph or None], most recently used last
-        self._graphs_state = None  # _graph_state() the graphs were captured from
-        self._identity_done = 0  # channel mask front_split finished (world == 1 only)
+
+    # ------------------------------------------------------------------ schedule
+    @property
+    def tuning(self) -> bool:
+        """True while the first frames are still measuring the candidate schedules (they render correctly, kernel by kernel)."""
+        return self._tune is not None
+
+    def _set_schedule(self, sched):
+        """sched = (exchanges, split): 1 exchange (exposure halo widened by the MTF reach) with the halation in one call or as
+        interior + bands, or 2 exchanges (exposure halo for the halation, then density halo for the MTF)."""
+        ex, sp = sched
+        both = self.halation and self.mtf
+        self.single_exchange = both and ex == 1
+        self.halo_e_ch = self._halo_e_single if (self.single_exchange or not both) else self._halo_e_two
+        self.split = self._split_plan if (self.single_exchange and sp) else None
+        self.schedule = (ex, bool(self.split))
+        self.reset_graphs()
+
+    def _tune_frame(self, image_rows, out_f32, out_u8):
+        """One frame of the measuring phase: rendered kernel by kernel under the current candidate, timed between two events on the
+        launch stream (exchange included); moves on to the next candidate / to the decision when this one has its frames."""
+        torch, t = self.torch, self._tune
+        if t["n"] < 0:  # the very first frame builds tables, spectra and scratch: not timed
+            t["n"] = 0
+            return self._render_eager(image_rows, out_f32, out_u8)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        res = self._render_eager(image_rows, out_f32, out_u8)
+        b.record()
+        b.synchronize()
+        t["ms"][t["i"]].append(a.elapsed_time(b))
+        t["n"] += 1
+        if t["n"] >= self.tune_frames:
+            t["i"], t["n"] = t["i"] + 1, 0
+            if t["i"] < len(self._candidates):
+                self._set_schedule(self._candidates[t["i"]])
+            else:
+                self._decide()
+        return res
+
+    def _decide(self):
+        """The schedule whose slowest rank was fastest (best frame of each candidate; MAX over the ranks, so every rank picks the
+        same one -- the two-exchange form needs its neighbours to play along)."""
+        torch, dist = self.torch, self.dist
+        ms = torch.tensor([min(m) for m in self._tune["ms"]], dtype=torch.float64)
+        if self.plan.world > 1 and dist.is_available() and dist.is_initialized() and type(self)._exchange is RowShardedRenderer._exchange:
+            dev = self.backend.device if dist.get_backend(self.group) != "gloo" else "cpu"
+            buf = ms.to(dev)
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+            ms = buf.cpu()
+        self.tuned_ms = [float(x) for x in ms]
+        self._tune = None
+        self._set_schedule(self._candidates[int(torch.argmin(ms))])
 
     # ------------------------------------------------------------------ neighbour exchange
     def _exchange(self, buf, buf_gy0: int, above, below, wait: bool = True):
@@ -358,6 +456,8 @@ class RowShardedRenderer:
         None keeps the backend's.  A new seed does not cost a captured graph: it lives in a device-side block."""
         if hasattr(self.backend, "begin_frame"):
             self.backend.begin_frame(seed)
+        if self._tune is not None:
+            return self._tune_frame(image_rows, out_f32, out_u8)
         if not self.graph:
             return self._render_eager(image_rows, out_f32, out_u8)
         torch, p = self.torch, self.plan
@@ -391,22 +491,36 @@ class RowShardedRenderer:
         pending = None
         if not whole:
             pending = self._front_and_start_exchange(image_rows)
+        # What is captured: world == 1: one graph, front included.  world > 1, one exchange: [the interior halation, replayed
+        # while the halos travel,] then everything downstream of the exchange.  Two exchanges (or the MTF alone): the density
+        # (halation of the own rows), then -- after the density halo exchange, which is issued every frame like the first one --
+        # the MTF and the tail.
+        mid_exchange = (not whole) and self.mtf and not self.single_exchange
         if slot[1] is None:
-            graphs = []
-            try:
-                # thread_local: other threads (RCCL's watchdog polls events) may keep calling into HIP during the capture
-                if not whole and self.split:
-                    g1 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                        self._halation_interior()
-                    graphs.append(g1)
+            graphs = {"pre": None, "a": None, "b": None}
+
+            def capture(fn):
                 g = torch.cuda.CUDAGraph()
+                # thread_local: other threads (RCCL's watchdog polls events) may keep calling into HIP during the capture
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    if whole:
+                    fn()
+                return g
+
+            try:
+                if not whole and self.split:
+                    graphs["pre"] = capture(self._halation_interior)
+                if whole:
+                    def everything():
                         self._exchange_finish(self._front_and_start_exchange(image_rows))
                         self._halation_interior()
-                    self._after_exchange(out_f32, out_u8, None)
-                graphs.append(g)
+                        self._after_exchange(out_f32, out_u8, None)
+                    graphs["a"] = capture(everything)
+                elif mid_exchange:
+                    if self.halation:
+                        graphs["a"] = capture(self._density)
+                    graphs["b"] = capture(lambda: self._finish(out_f32, out_u8, None))
+                else:
+                    graphs["a"] = capture(lambda: self._after_exchange(out_f32, out_u8, None))
             except Exception:  # noqa: BLE001 -- a failed capture must not cost the frame: eager launches from here on
                 self.graph = False
                 self._graphs.clear()
@@ -420,13 +534,23 @@ class RowShardedRenderer:
                 torch.cuda.synchronize()
                 return self._finish_eager(image_rows, pending, out_f32, out_u8, whole)
             slot[1] = graphs
-        if len(slot[1]) == 2:
+        graphs = slot[1]
+        if graphs["pre"] is not None:
             self._note("replay:halation_interior")
-            slot[1][0].replay()
+            graphs["pre"].replay()
         self._note("exchange_finish")
         self._exchange_finish(pending)
-        self._note("replay:after_exchange")
-        slot[1][-1].replay()
+        if mid_exchange:
+            if graphs["a"] is not None:
+                self._note("replay:density")
+                graphs["a"].replay()
+            self._note("exchange_density")
+            self._exchange(self.D, self.d_lo, *p.halo_d)
+            self._note("replay:finish")
+            graphs["b"].replay()
+        else:
+            self._note("replay:after_exchange")
+            graphs["a"].replay()
         return out_f32, out_u8
 
     def _finish_eager(self, image_rows, pending, out_f32, out_u8, whole):
@@ -523,28 +647,41 @@ class RowShardedRenderer:
 
     def _after_exchange(self, out_f32, out_u8, field_ready):
         """Everything downstream of the exposure planes: S2 .. S8 on this renderer's own buffers."""
+        self._density()
+        if self.mtf and not self.single_exchange:
+            self._note("exchange_density")
+            self._exchange(self.D, self.d_lo, *self.plan.halo_d)
+        return self._finish(out_f32, out_u8, field_ready)
+
+    def _density(self):
+        """S2 + S3 + S4: the halation of the rows this schedule wants density for (nothing without halation: the front kernel
+        wrote density already)."""
+        p, be = self.plan, self.backend
+        H = p.H
+        if not self.halation:
+            return
+        kw = {"identity_done": self._identity_done} if self._identity_done else {}
+        if self.split:  # the interior rows are under way (or done): the bands next to the neighbours' rows
+            lo, hi = self.split
+            self._note("halation_bands")
+            if lo > self.d_lo:
+                be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, lo, H)
+            if hi < self.d_hi:
+                be.halation(self.E, self.e_lo, self.D, self.d_lo, hi, self.d_hi, H)
+        elif self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
+            be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H, **kw)
+        else:
+            be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H, **kw)
+
+    def _finish(self, out_f32, out_u8, field_ready):
+        """S5 .. S8 from the density planes (their halo rows in place)."""
         p, be = self.plan, self.backend
         H = p.H
         if not (self.halation or self.mtf):
             cur, cur_lo = self.Dplain, p.r0
         else:
-            if self.halation:
-                kw = {"identity_done": self._identity_done} if self._identity_done else {}
-                if self.split:  # the interior rows are under way (or done): the bands next to the neighbours' rows
-                    lo, hi = self.split
-                    self._note("halation_bands")
-                    if lo > self.d_lo:
-                        be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, lo, H)
-                    if hi < self.d_hi:
-                        be.halation(self.E, self.e_lo, self.D, self.d_lo, hi, self.d_hi, H)
-                elif self.single_exchange:  # density for the rows the MTF stencil reads, halo rows included
-                    be.halation(self.E, self.e_lo, self.D, self.d_lo, self.d_lo, self.d_hi, H, **kw)
-                else:
-                    be.halation(self.E, self.e_lo, self.D, self.d_lo, p.r0, p.r1, H, **kw)
             cur, cur_lo = self.D, self.d_lo
             if self.mtf:
-                if not self.single_exchange:
-                    self._exchange(self.D, self.d_lo, *p.halo_d)
                 be.mtf(self.D, self.d_lo, self.D2, p.r0, p.r0, p.r1, H)
                 cur, cur_lo = self.D2, p.r0
         if not self.burn:

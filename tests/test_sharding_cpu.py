@@ -141,15 +141,23 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        flags = dict(flags)
+        flags_ex = flags.pop("exchanges", "auto")
         p, img = _inputs(H, W, scale, **flags)
         be = OracleStageBackend(p)
         rr = sharding.RowShardedRenderer(be, H, W, halation=p.halation_kernel is not None, mtf=p.mtf_kernel is not None,
-                                         grain=p.grain_lut is not None, burn=bool(p.highlight_burn), split_halation=True)
+                                         grain=p.grain_lut is not None, burn=bool(p.highlight_burn), split_halation=True, exchanges=flags_ex)
         rr.trace = []
         r0, r1 = rr.plan.r0, rr.plan.r1
         out = torch.zeros((r1 - r0, W, 3), dtype=torch.float32)
         rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
-        if world > 1 and rr.halation and rr.mtf:
+        if world > 1 and rr.halation and rr.mtf and flags_ex == 2:
+            # two exchanges: exposure halo for the halation alone, the halation on exactly the own rows, then the density halo
+            ha, ma = be.halation_taps[0], be.mtf_taps[0]
+            assert rr.schedule == (2, False) and not rr.single_exchange
+            assert rr.halo_e_ch[0] == (ha, ha) and rr.halo_e_ch[2] == (0, 0), rr.halo_e_ch
+            assert rr.trace == ["exchange_start", "exchange_finish", "exchange_density"], rr.trace
+        elif world > 1 and rr.halation and rr.mtf:
             # one exchange; the blue plane (a single halation tap) travels with the MTF's halo only; the interior halation is
             # issued while the halos are in flight, the boundary bands after they arrived
             ha, ma = be.halation_taps[0], be.mtf_taps[0]
@@ -187,6 +195,8 @@ def _worker(rank, world, port, H, W, scale, flags, result_path):
         (40, 32, 60.0, dict(halation=False, mtf=False, grain=0)),  # LUTs only: fused pointwise pass
         (97, 64, 120.0, dict(burn=0.7)),  # S7 on top of everything: all-reduce of the low-res cell sums
         (64, 48, 100.0, dict(burn=0.7, halation=False, mtf=False, grain=0)),
+        (97, 64, 120.0, dict(exchanges=2)),  # the two-exchange schedule: exposure halo, halation on the own rows, density halo
+        (97, 64, 120.0, dict(exchanges=2, burn=0.7)),
     ],
 )
 def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
@@ -194,6 +204,7 @@ def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
     path = str(tmp_path / "out.npy")
     mp.spawn(_worker, args=(world, _free_port(), H, W, scale, flags, path), nprocs=world, join=True)
     got = np.load(path)
+    flags = {k: v for k, v in flags.items() if k != "exchanges"}
     p, img = _inputs(H, W, scale, **flags)
     ref = st.render(img, p)
     assert got.shape == ref.shape
@@ -204,11 +215,13 @@ def test_two_rank_row_shards_match_whole_frame(tmp_path, H, W, scale, flags):
     (4, 131, 48, 100.0, dict()),            # interior ranks talk to BOTH neighbours (a 2-rank world never does); shards of 33 / 33 / 33 / 32
     (3, 100, 40, 80.0, dict(burn=0.7)),     # odd world, S7's all-reduce over three ranks
     (8, 163, 40, 100.0, dict()),            # the node's full width: eight ranks, six of them interior, shards of 21 / 21 / 21 / 20 x 5 rows
+    (4, 131, 48, 100.0, dict(exchanges=2)),  # two exchanges with interior ranks
 ])
 def test_interior_ranks_exchange_with_both_neighbours(tmp_path, world, H, W, scale, flags):
     path = str(tmp_path / "out.npy")
     mp.spawn(_worker, args=(world, _free_port(), H, W, scale, flags, path), nprocs=world, join=True)
     got = np.load(path)
+    flags = {k: v for k, v in flags.items() if k != "exchanges"}
     p, img = _inputs(H, W, scale, **flags)
     ref = st.render(img, p)
     assert got.shape == ref.shape

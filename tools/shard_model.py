@@ -1,6 +1,8 @@
 """Device time of a 1/N row shard of the 100 MP frame on ONE GPU (what each of N GPUs would do per frame), eager launches vs HIP
 graph replay: the measured inputs of DESIGN.md section 5's modelled 1 -> 8 GPU curve.
 
+Round 5: every schedule RowShardedRenderer can run (one exchange with the halation in one call or as interior + bands, two
+exchanges) is measured for the middle rank, then the renderer's own measured choice ("auto").
 Round 4: the shard measured is a MIDDLE rank's -- RowShardedRenderer(rank = N // 2, world = N) with the exchange itself stubbed out
 (nothing travels: the halo rows keep whatever the buffer held), so the launches are exactly a real rank's: front kernels on the
 own rows, the interior halation, the two boundary bands, the halation of the MTF's halo rows, MTF, tail.  Round 3 measured a
@@ -45,33 +47,50 @@ mb_all = (ha[0] + ma[0]) * W * 3 * 4 / 1e6
 mb_per = sum(a + ma[0] for a, _ in per) * W * 4 / 1e6
 print(f"halo rows: halation {ha} (per plane {per}), MTF {ma}; exchange per boundary and direction: {mb_per:.2f} MB "
       f"(all planes with the full halo: {mb_all:.2f} MB)")
-SPLIT = {"0": False, "1": True}.get(os.environ.get("R2F_SHARD_SPLIT", "auto"), "auto")  # A/B: 0 = one halation call after the exchange (round 3), 1 = always split
+SCHEDULES = (("1 exchange, halation in one call", dict(exchanges=1, split_halation=False)),
+             ("1 exchange, interior halation + bands", dict(exchanges=1, split_halation=True)),
+             ("2 exchanges, halation on the own rows", dict(exchanges=2)),
+             ("measured on the first frames (auto)", dict()))
+
+
+def run(n, rank, graph, kw):
+    rr = NoTransport(be, H, W, halation=True, mtf=True, rank=rank, world=n, graph=graph, **kw)
+    rows = rr.plan.rows
+    frame = synthetic_frame_device(rows, W, seed=n)
+    out = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+    i = 0
+    while rr.tuning:  # the measuring phase of "auto"
+        rr.render(frame, out_f32=out, seed=100 + i)
+        i += 1
+    for _ in range(3):  # ... then the frames that capture the graphs
+        rr.render(frame, out_f32=out, seed=100 + i)
+        i += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 10
+    for i in range(iters):
+        rr.render(frame, out_f32=out, seed=200 + i)
+    t_host = (time.perf_counter() - t0) / iters * 1e3
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / iters * 1e3
+    info = (rows, rr.schedule, rr.split, rr.d_lo, rr.d_hi, rr.tuned_ms)
+    del rr, frame, out
+    return t_all, t_host, info
+
+
+base = None
 for n in (1, 2, 4, 8):
     rank = n // 2 if n > 2 else 0
-    res, rr = {}, None
-    for graph in (False, True):
-        rr = NoTransport(be, H, W, halation=True, mtf=True, rank=rank, world=n, graph=graph, split_halation=SPLIT)
-        rows = rr.plan.rows
-        frame = synthetic_frame_device(rows, W, seed=n)
-        out = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
-        for i in range(3):
-            rr.render(frame, out_f32=out, seed=100 + i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        iters = 10
-        for i in range(iters):
-            rr.render(frame, out_f32=out, seed=200 + i)
-        t_host = (time.perf_counter() - t0) / iters * 1e3
-        torch.cuda.synchronize()
-        t_all = (time.perf_counter() - t0) / iters * 1e3
-        res[graph] = (t_all, t_host)
-        split, dl, dh = rr.split, rr.d_lo, rr.d_hi
-        del rr, frame, out
-    what = (f"halation rows [{dl}, {dh}) as interior [{split[0]}, {split[1]}) + bands" if split else f"halation rows [{dl}, {dh}) in one call")
-    print(f"N = {n}: rank {rank}, shard {W} x {rows} ({what}): eager {res[False][0]:.3f} ms/frame (host issue {res[False][1]:.3f}), "
-          f"graph replay {res[True][0]:.3f} ms/frame (host issue {res[True][1]:.3f})  -> 1/N of the N = 1 time would be {res[True][0] if n == 1 else base / n:.3f}")
-    if n == 1:
-        base = res[True][0]
+    for name, kw in (SCHEDULES if n > 1 else SCHEDULES[:1]):
+        res = {g: run(n, rank, g, kw) for g in (False, True)}
+        rows, sched, split, dl, dh, tuned = res[True][2]
+        if n == 1:
+            base = res[True][0]
+        what = f"schedule {sched}" + (f", halation interior [{split[0]}, {split[1]}) of [{dl}, {dh})" if split else "")
+        if tuned:
+            what += ", measured " + " / ".join(f"{t:.3f}" for t in tuned) + " ms per candidate"
+        print(f"N = {n}: rank {rank}, shard {W} x {rows}, {name} ({what}): eager {res[False][0]:.3f} ms/frame (host issue {res[False][1]:.3f}), "
+              f"graph replay {res[True][0]:.3f} ms/frame (host issue {res[True][1]:.3f})  -> 1/N of the N = 1 time would be {base / n:.3f}", flush=True)
 for which, name in ((0, "halation"), (1, "MTF")):
     print(name, "windows of the last call:", [c["window"] for c in proc.ctx.stencil_stats(which)])
 
