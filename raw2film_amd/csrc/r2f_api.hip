@@ -99,7 +99,15 @@ struct r2f_ctx {
     // Default: the MTF only -- it acts on density, whose values are bounded, so two fp32 roundings of the spectrum cost ~1e-7
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
-    int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (fp32 heads + bf16 residuals, 2^-33) -- experimental
+    int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (doubles rounded to 48 bits, 2^-37) whatever the frame holds -- A/B
+    // 1: a whole-frame render (r2f_render) lets the halation's FFT passes choose between complex128 and the 12-byte element ON THE
+    // DEVICE, per frame, from the range of the exposure samples its front kernel wrote (FrameParams::e_min / e_max): the 12-byte
+    // element costs a shadow at most ~2.1e-12 x (max |x| / shadow) of itself (profiles/r05_scratch96_probe.txt), which the density
+    // curve turns into 0.434 x slope x that; the bound keeps it under two fp32 ulps of a density in [1, 2) -- less than the MTF's
+    // complex64 scratch is allowed (3) -- and frames with a wider range (a 65 504 specular over 1e-4 shadows) keep complex128.
+    int opt_fft_s96_auto = 1;
+    float curve_slope_max = 0.f;  // max |d density / d log10 exposure| over the density curve's cells (host copy, r2f_set_curve1d)
+    bool frame_track_request = false, frame_tracked = false, frame_dyn_request = false;  // render_launches -> the stage entries
     int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
     // 1: a centrally symmetric tap box (k[i][j] == k[bh-1-i][bw-1-j] bit for bit, anchor at its centre -- every halation disc and
     // |ifft2| MTF kernel the reference builds, effects.py:200-217, :123-143) is laid out with its anchor on the window origin, so its
@@ -389,6 +397,7 @@ int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
 int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s) {
     FrameParams v{};
     v.seed = p->seed;
+    v.e_min = kFrameMinReset, v.e_max = kFrameMaxReset;
     R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, s));
     return R2F_OK;
 }
@@ -611,7 +620,17 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.s32 = ((ctx->opt_fft_s96 >> which) & 1) ? 2 : (s32_eff ? 1 : 0);
     for (int i = 0; i < nch; ++i)
         if (set.mixed_sign[chans[i]] && ctx->opt_fft_mixed_sign) a.s32 = 0;  // (the 12-byte element neither)
-    const plan::FftBatches fb = plan::fft_batches(fo, ny, nx, bh, bw, W, y0, y1, nch, a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));
+    // the halation of a whole-frame render whose front kernel recorded the range of the exposure planes: element chosen on the device
+    if (a.s32 == 0 && which == R2F_KERNEL_HALATION && epilogue == 1 && ctx->frame_dyn_request && ctx->opt_fft_s96_auto && a.kreal &&
+        ny == 256 && ctx->opt_fft_cols_walk && ctx->curve.cells) {
+        a.s32 = 3;
+        a.dyn = static_cast<const FrameParams*>(ctx->frame_buf.p);
+        // |delta density| <= 0.434 slope_max x 2.1e-12 x (max / shadow) <= 2.4e-7  (two ulps of a density in [1, 2))
+        const double slope = std::max((double)ctx->curve_slope_max, 1e-3);
+        a.dyn_bound = (float)std::min(2.4e-7 / (0.4343 * slope * 2.1e-12), 1e7);
+        a.dyn_floor = (float)std::pow(10.0, (double)ctx->curve.x0);  // below the curve's first breakpoint np.interp clamps: no slope
+    }
+    const plan::FftBatches fb = plan::fft_batches(fo, ny, nx, bh, bw, W, y0, y1, nch, a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));  // (3: sized for 16)
     a.gx = fb.gx;
     a.ntiles = fb.ntiles;
     a.ppc = fb.ppc;
@@ -954,6 +973,10 @@ int r2f_set_option(r2f_ctx* ctx, const char* name, int value) {
         ctx->opt_fft_epi_lds = value ? 1 : 0;
         return R2F_OK;
     }
+    if (!strcmp(name, "stencil_fft_scratch96_auto")) {
+        ctx->opt_fft_s96_auto = value ? 1 : 0;
+        return R2F_OK;
+    }
     if (!strcmp(name, "stencil_fft_scratch96")) {
         if (value < 0 || value > 7) return fail(ctx, R2F_EINVAL, "stencil_fft_scratch96 is a mask over the three stencils (0..7)");
         ctx->opt_fft_s96 = value;
@@ -1020,7 +1043,16 @@ int r2f_set_lut3d(r2f_ctx* ctx, const float* lut, int n) {
 int r2f_set_curve1d(r2f_ctx* ctx, const float* lut4xm, int m) {
     if (!ctx) return R2F_EINVAL;
     R2F_GUARD(ctx);
-    return upload_curve(ctx, ctx->curve_buf, ctx->curve, lut4xm, m);
+    int rc = upload_curve(ctx, ctx->curve_buf, ctx->curve, lut4xm, m);
+    if (rc) return rc;
+    double smax = 0.0;
+    for (int c = 1; c <= 3; ++c)
+        for (int i = 0; i + 1 < m; ++i) {
+            const double dx = (double)lut4xm[i + 1] - (double)lut4xm[i];
+            if (dx > 0.0) smax = std::max(smax, std::fabs(((double)lut4xm[(size_t)c * m + i + 1] - (double)lut4xm[(size_t)c * m + i]) / dx));
+        }
+    ctx->curve_slope_max = (float)smax;
+    return R2F_OK;
 }
 
 int r2f_set_grain_lut(r2f_ctx* ctx, const float* lut4xm, int m) {
@@ -1142,6 +1174,10 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
         f.vec = (vec && planes_vec_ok(finish_dst, W)) ? 1 : 0;
         if (f.finish_mask && f.finish_mask != 7 && front_fast_eligible(f)) {
             *finished_mask = f.finish_mask;
+            if (ctx->frame_track_request && ctx->opt_fft_s96_auto) {  // a whole-frame render: the exposure planes' range for the FFT passes
+                f.track = static_cast<FrameParams*>(ctx->frame_buf.p);
+                ctx->frame_tracked = true;
+            }
             R2F_HIP(ctx, launch_front_fast(f, static_cast<hipStream_t>(stream)));
             return R2F_OK;
         }
@@ -1677,9 +1713,16 @@ static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, in
     r2f_planes A{base, (int64_t)(set_floats / 3), 0, H};
     r2f_planes B{base + set_floats, (int64_t)(set_floats / 3), 0, H};
     int rc, finished = 0;
-    if (hal)  // the halation's identity channels (blue on a colour stock) are finished by the front kernel, straight into B
+    ctx->frame_tracked = false;
+    if (hal) {  // the halation's identity channels (blue on a colour stock) are finished by the front kernel, straight into B
+        if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // kernel by kernel: the frame block (seed, exposure range reset) ahead of the front kernel
+            rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
+            if (rc) return rc;
+        }
+        ctx->frame_track_request = true;  // ... which also records the range of the exposure planes it writes (every row of them)
         rc = r2f_stage_front_split(ctx, p, in, in_layout, 0, H, &A, &B, 0, H, W, H, &finished, stream);
-    else
+        ctx->frame_track_request = false;
+    } else
         rc = r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_DENSITY, &A, nullptr, nullptr, 0, 0, H, W, H, stream);
     if (rc) return rc;
     const r2f_planes* cur = &A;
@@ -1687,7 +1730,9 @@ static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, in
     if (hal) {
         r2f_params q = *p;
         if (finished) q.flags |= R2F_F_IDENTITY_DONE;
+        ctx->frame_dyn_request = ctx->frame_tracked;
         rc = r2f_stage_halation(ctx, &q, cur, other, 0, H, W, H, stream);
+        ctx->frame_dyn_request = false;
         if (rc) return rc;
         std::swap(cur, other);
     }

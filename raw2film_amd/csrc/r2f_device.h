@@ -80,8 +80,14 @@ struct DevPlanes {
 // render (gpu_processor.py:585-597 `buffer_params_grain`, read at noise.wgsl:1-6).
 struct FrameParams {
     uint32_t seed;  // grain seed of this render
-    uint32_t reserved[3];
+    // Range of the exposure samples the halation's FFT passes are about to read, as float bit patterns: min of the samples and max
+    // of their magnitudes over the channels that take the FFT form, accumulated by the front kernel of a whole-frame render
+    // (atomicMin / atomicMax on the bits: non-negative floats order like integers; a negative minimum only has to stay negative).
+    // Reset with every write of the block (+inf, 0).  The passes choose their scratch element from it (FftConvArgs::dyn).
+    uint32_t e_min, e_max;
+    uint32_t reserved;
 };
+constexpr uint32_t kFrameMinReset = 0x7f800000u, kFrameMaxReset = 0u;
 
 // ---------------------------------------------------------------------------- streaming accesses
 // Non-temporal 16-byte accesses for frame-sized buffers that are written once and read back a stage later (1.2 GB per plane set

@@ -248,10 +248,12 @@ __device__ __forceinline__ const cplx& at(const cplx* base, unsigned idx) {
 // S32 = true: complex64 -- only the two roundings between the passes are fp32, every butterfly stays fp64 -- for stencils on
 // DENSITY (the MTF): values in [0, 4], so those roundings cost ~1e-7 absolute (under one fp32 ulp of a density >= 1; measured
 // in tests/test_gpu_fft.py) and the three passes move half the bytes.
-// ST = 2: a 12-byte element {fp32 head of re, fp32 head of im, the two residuals v - head as bf16}: 2^-33 relative, a quarter
-// fewer bytes than complex128 -- enough for linear exposure (a 65 504 specular in the window costs its shadows 1e-7 absolute).
+// ST = 2: a 12-byte element, each component a double rounded to its upper 48 bits (sign, exponent, 36 mantissa bits: 2^-37
+// relative to the component, full double range): {upper word of re, upper word of im, bits 16..31 of both lower words}.  A
+// quarter fewer bytes than complex128 for 2^-37 of the WINDOW's magnitude per rounding (round 2's first form of this element, two
+// fp32 heads + two bf16 residuals, was 2^-33 and cost 14 instructions per element to pack where this one costs 5).
 struct __attribute__((packed, aligned(4))) C96 {
-    float hr, hi;
+    unsigned hr, hi;
     unsigned lo;
 };
 template <int ST>
@@ -262,28 +264,34 @@ __device__ __forceinline__ cplx sld(const void* base, unsigned idx) {
     }
     if (ST == 2) {
         const C96 e = *reinterpret_cast<const C96*>(reinterpret_cast<const char*>(base) + idx * 12u);
-        const float lr = __uint_as_float(e.lo << 16), li = __uint_as_float(e.lo & 0xffff0000u);
-        return make_double2((double)e.hr + (double)lr, (double)e.hi + (double)li);
+        return make_double2(__hiloint2double((int)e.hr, (int)(e.lo << 16)), __hiloint2double((int)e.hi, (int)(e.lo & 0xffff0000u)));
     }
     return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + (idx << 4));
-}
-__device__ __forceinline__ unsigned bf16_bits(float x) {  // round to nearest even, like v_cvt_pk_bf16_f32
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 template <int ST>
 __device__ __forceinline__ void sst(void* base, unsigned idx, const cplx v) {
     if (ST == 1)
         *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + (idx << 3)) = make_float2((float)v.x, (float)v.y);
     else if (ST == 2) {
+        // round to nearest at bit 16 of the lower word: the IEEE bit pattern is monotonic, a carry out of the mantissa lands in the
+        // exponent as it should (finite values only: pass 1 zeroes the others)
+        const unsigned long long br = (unsigned long long)__double_as_longlong(v.x) + 0x8000ull;
+        const unsigned long long bi = (unsigned long long)__double_as_longlong(v.y) + 0x8000ull;
         C96 e;
-        e.hr = (float)v.x, e.hi = (float)v.y;
-        const float rr = (float)(v.x - (double)e.hr), ri = (float)(v.y - (double)e.hi);
-        e.lo = bf16_bits(rr) | (bf16_bits(ri) << 16);
+        e.hr = (unsigned)(br >> 32), e.hi = (unsigned)(bi >> 32);
+        e.lo = ((unsigned)br >> 16) | ((unsigned)bi & 0xffff0000u);
         *reinterpret_cast<C96*>(reinterpret_cast<char*>(base) + idx * 12u) = e;
     } else
         *reinterpret_cast<cplx*>(reinterpret_cast<char*>(base) + (idx << 4)) = v;
 }
+// s32 == 3 (FftConvArgs::dyn): the 12-byte element when the range of the samples this frame's launches read allows it -- max |x|
+// within dyn_bound times the smallest sample that matters (samples below dyn_floor end on the clamped part of the density curve).
+// Wave-uniform (scalar loads of the frame block); a NaN anywhere makes the comparison false: complex128.
+__device__ __forceinline__ bool dyn_packed(const FftConvArgs& a) {
+    const float lo = __uint_as_float(a.dyn->e_min), hi = __uint_as_float(a.dyn->e_max);
+    return hi <= a.dyn_bound * fmaxf(lo, a.dyn_floor);
+}
+
 // scratch image of pair `pair` (n elements each)
 template <int ST>
 __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) {
@@ -409,7 +417,14 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
 template <int XL, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE1, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_fwd_body<XL, ST>(a, fsm);
+    if (ST == 3) {  // element chosen per frame on the device
+        if (dyn_packed(a))
+            fft_rows_fwd_body<XL, 2>(a, fsm);
+        else
+            fft_rows_fwd_body<XL, 0>(a, fsm);
+    } else {
+        fft_rows_fwd_body<XL, ST>(a, fsm);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
@@ -553,8 +568,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 // Loop-invariant values the compiler would otherwise keep in VGPRs from pair to pair (the fifteen twiddle powers: 60 VGPRs; sixteen
 // store offsets) are made opaque per iteration -- recomputing them is what the one-shot kernel does too: 207-209 VGPRs, no spill.
 template <int NBX, int ST>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fft_cols_walk_kernel(const FftConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
+__device__ __forceinline__ void fft_cols_walk_body(const FftConvArgs& a, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
     double* tbuf = wave_tbuf(fsm);
@@ -586,6 +600,19 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<ST>(s1, sbase + q * (NBX * 256), v[q]);
+    }
+}
+
+template <int NBX, int ST>
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fft_cols_walk_kernel(const FftConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    if (ST == 3) {
+        if (dyn_packed(a))
+            fft_cols_walk_body<NBX, 2>(a, fsm);
+        else
+            fft_cols_walk_body<NBX, 0>(a, fsm);
+    } else {
+        fft_cols_walk_body<NBX, ST>(a, fsm);
     }
 }
 
@@ -701,7 +728,14 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 template <int XL, int EPI, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (XL ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    fft_rows_inv_body<XL, EPI, ST>(a, fsm);
+    if (ST == 3) {
+        if (dyn_packed(a))
+            fft_rows_inv_body<XL, EPI, 2>(a, fsm);
+        else
+            fft_rows_inv_body<XL, EPI, 0>(a, fsm);
+    } else {
+        fft_rows_inv_body<XL, EPI, ST>(a, fsm);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
@@ -714,6 +748,8 @@ static void launch_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     const dim3 block(kFftThreads), grid(a.ny / RowGeom<XL>::ROWS, a.npairs);
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 1>), grid, block, fft_lds_bytes(), s, a);
+    else if (a.s32 == 3)
+        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 3>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 2)
         hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 2>), grid, block, fft_lds_bytes(), s, a);
     else
@@ -767,6 +803,8 @@ static void launch_cols_walk_st(const FftConvArgs& a, dim3 grid, hipStream_t s) 
     const dim3 block(kFftThreads);
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 1>), grid, block, fft_lds_bytes(), s, a);
+    else if (a.s32 == 3)
+        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 3>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 2)
         hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 2>), grid, block, fft_lds_bytes(), s, a);
     else
@@ -812,6 +850,8 @@ static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
     }
     if (a.s32 == 1)
         hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 1>), grid, dim3(kFftThreads), lds, s, a);
+    else if (a.s32 == 3)
+        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 3>), grid, dim3(kFftThreads), lds, s, a);
     else if (a.s32 == 2)
         hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 2>), grid, dim3(kFftThreads), lds, s, a);
     else

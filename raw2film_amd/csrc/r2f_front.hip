@@ -156,13 +156,16 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         __syncthreads();
     }
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (x >= a.W) return;
+    // range of the exposure samples this lane writes for the halation's FFT passes (UPTO = EXPOSURE with a.track): min and max |.|
+    float t_lo = __builtin_inff(), t_hi = 0.f;
+    const bool track = UPTO == R2F_UPTO_EXPOSURE && a.track != nullptr;
+    if (x >= a.W && !track) return;
     const int W = a.W;
     const float* in = static_cast<const float*>(a.in);
     const float s3 = a.lut3d_scale * (float)(a.lut3d.n - 1);
     const long long plane = (long long)a.in_rows * W;
     const Mat3Pairs mat = pairs_of(a.mat);
-    for (int gy = a.y0 + blockIdx.y * BY + threadIdx.y; gy < a.y1; gy += gridDim.y * BY) {
+    for (int gy = a.y0 + blockIdx.y * BY + threadIdx.y; gy < a.y1 && x < W; gy += gridDim.y * BY) {
         const long long irow = gy - a.in_gy0;
         float r[4], g[4], b[4];
         if (LAYOUT == R2F_LAYOUT_CHW) {
@@ -193,6 +196,11 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             p = lut2d(lut_lds, a.lut2d.n, p);
             if (UPTO == R2F_UPTO_EXPOSURE) {
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
+                if (track) {  // (fminf / fmaxf drop a NaN: pass 1 of the FFT form takes a non-finite sample as 0 anyway; an infinity stays)
+                    if (!(a.finish_mask & 1)) t_lo = fminf(t_lo, r[q]), t_hi = fmaxf(t_hi, fabsf(r[q]));
+                    if (!(a.finish_mask & 2)) t_lo = fminf(t_lo, g[q]), t_hi = fmaxf(t_hi, fabsf(g[q]));
+                    if (!(a.finish_mask & 4)) t_lo = fminf(t_lo, b[q]), t_hi = fmaxf(t_hi, fabsf(b[q]));
+                }
                 if (FIN) {  // same arithmetic as single_tap_kernel with the halation epilogue: w * x, log10, curve
                     if (a.finish_mask & 1) r[q] = curve_eval_at((const float4*)cells_lds, a.curve, 0, log10_fast(a.finish_w[0] * r[q], a.log_eps));
                     if (a.finish_mask & 2) g[q] = curve_eval_at((const float4*)cells_lds, a.curve, 1, log10_fast(a.finish_w[1] * g[q], a.log_eps));
@@ -260,6 +268,17 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             o32[0] = u8_of(r[0]) | (u8_of(g[0]) << 8) | (u8_of(b[0]) << 16) | (u8_of(r[1]) << 24);
             o32[1] = u8_of(g[1]) | (u8_of(b[1]) << 8) | (u8_of(r[2]) << 16) | (u8_of(g[2]) << 24);
             o32[2] = u8_of(b[2]) | (u8_of(r[3]) << 8) | (u8_of(g[3]) << 16) | (u8_of(b[3]) << 24);
+        }
+    }
+    if (track) {  // one pair of atomics per wave (a persistent grid: a few thousand per frame)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            t_lo = fminf(t_lo, __shfl_xor(t_lo, m));
+            t_hi = fmaxf(t_hi, __shfl_xor(t_hi, m));
+        }
+        if (threadIdx.x == 0) {
+            atomicMin(reinterpret_cast<int*>(&a.track->e_min), __float_as_int(t_lo));
+            atomicMax(reinterpret_cast<int*>(&a.track->e_max), __float_as_int(t_hi));
         }
     }
 }

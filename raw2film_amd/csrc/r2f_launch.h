@@ -34,6 +34,9 @@ struct FrontArgs {
     int finish_mask;
     float finish_w[3];
     DevPlanes finish_dst;
+    // fast kernel, upto = EXPOSURE: min / max |.| of the exposure samples written to `dst` (the channels NOT in finish_mask) are
+    // accumulated into this frame block (nullptr: not tracked)
+    FrameParams* track;
 };
 bool front_fast_eligible(const FrontArgs& a);
 hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s);
@@ -193,7 +196,12 @@ struct FftConvArgs {
     int cols_walk;            // 1: pass 2 of 256-row windows with a real spectrum walks the launch's pairs per column block
     int cols_slots;           // ... on a grid of (up to) this many resident workgroups (2 per CU)
     double2* s1;              // npairs x ny x nx scratch images, transformed in place (layout: sidx in r2f_fft.hip)
-    int s32;                  // scratch element: 0 complex128, 1 complex64 (half the bytes; the arithmetic stays fp64), 2 the 12-byte form
+    int s32;                  // scratch element: 0 complex128, 1 complex64 (half the bytes; the arithmetic stays fp64), 2 the 12-byte form,
+                              // 3 chosen ON THE DEVICE per frame between 0 and 2 from the input's range (dyn, below)
+    // s32 == 3: the frame block holding the range of the samples this launch reads (written by the front kernel of the same
+    // frame, in stream order), and the rule: the 12-byte element when max|x| <= dyn_bound * max(min x, dyn_floor)
+    const FrameParams* dyn;
+    float dyn_bound, dyn_floor;
     int epilogue;
     DevCurve curve;
     float log_eps;

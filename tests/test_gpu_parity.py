@@ -406,7 +406,11 @@ def test_row_shards_match_whole_frame_bitwise(ctx):
     img = synthetic_frame(H, W, seed=22)
     params = setup_ctx(ctx, p)
     t = dev(img)
+    # (like for like: the stage entry points keep complex128 scratch for the halation; a whole-frame render may choose the 12-byte
+    # element from the frame's range -- tests/test_gpu_fft.py -- and then agrees to that element's rounding instead of bit for bit)
+    ctx.set_option("stencil_fft_scratch96_auto", 0)
     whole, _ = ctx.render(t, params)
+    ctx.set_option("stencil_fft_scratch96_auto", 1)
     rh = p.halation_kernel.shape[0] // 2
     rm = p.mtf_kernel.shape[0] // 2
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
@@ -854,10 +858,12 @@ def test_identity_halation_channels_are_finished_by_the_front_kernel(ctx, bw):
         ctx.stage_halation(E, D, params, y0=0, y1=H, H_global=H, identity_done=mask)
         assert torch.equal(D, D_ref)
     outs = []
+    ctx.set_option("stencil_fft_scratch96_auto", 0)  # (only the fast front kernel records the exposure range the 12-byte element is chosen from)
     for fast in (1, 0):  # r2f_render takes the split front when the fast kernel applies
         ctx.set_option("front_fast", fast)
         outs.append(ctx.render(t, params)[0])
     ctx.set_option("front_fast", 1)
+    ctx.set_option("stencil_fft_scratch96_auto", 1)
     assert torch.equal(outs[0], outs[1])
     assert_close(outs[0].cpu().numpy(), ref, 1e-5, 1e-3, "render with the split front")
 
