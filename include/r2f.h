@@ -113,6 +113,12 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int 
  * Stencils of >= 400 taps run as fp64 overlap-save FFTs (like cv.filter2D's own DFT branch above 11 x 11 taps, which the
  * reference's CPU path takes for both of them); their pass scratch (1 MiB per window pair in flight, 192 by default) and
  * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use.
+ * Scratch element of the halation's passes: complex128, or -- chosen on the device, frame by frame, by r2f_render only -- a
+ * 12-byte element (each component a double rounded to 48 bits) when the range of the exposure samples the front kernel wrote
+ * allows it: max |x| <= bound x max(min x, first breakpoint of the density curve), the bound derived from the curve's steepest
+ * cell so that the element costs a density at most two fp32 ulps (option stencil_fft_scratch96_auto, default 1; a frame with a
+ * 65 504 specular over 1e-4 shadows keeps complex128).  The stage entry points always use complex128 for the halation, so a
+ * whole-frame render and a row-sharded one agree to that element's rounding, not bit for bit.
  * Non-finite samples: in the direct form a NaN / infinity in a stencil's input comes out as NaN in every output whose tap box
  * (plus up to three zero-weight padding rows / columns) covers it, like the per-tap loop of the reference's convolution.wgsl; the FFT form takes such a sample as 0 instead (a NaN
  * handed to the transforms would come back in every output of its 256 x 512 window) -- the outputs inside the tap box are then
@@ -318,7 +324,16 @@ int r2f_stream_copy(r2f_ctx* ctx, const void* src, void* dst, size_t bytes, void
  * caller that replays captured launches must re-capture when this value moves. */
 uint64_t r2f_generation(const r2f_ctx* ctx);
 
-/* Tuning knob for A/B runs: stencil tile variant (0 = auto). */
+/* Tuning knobs for A/B runs (every one of them bumps r2f_generation).  Round 5's, all defaulting to the faster form:
+ *   stencil_fft_real_spectrum  1: centrally symmetric tap boxes (every halation disc / MTF kernel the reference builds) are laid
+ *                                 out around the window origin, pass 2 multiplies by a REAL spectrum (8 B per element)
+ *   stencil_fft_cols_walk      1: pass 2 of 256-row windows with a real spectrum runs as a resident grid walking the launch's
+ *                                 pairs per column block (spectrum in registers); 0: one workgroup per (column block, pair)
+ *   stencil_fft_scratch96_auto 1: r2f_render lets the halation's passes take the 12-byte scratch element when the frame's
+ *                                 exposure range allows (above); stencil_fft_scratch96 (mask per stencil) forces it
+ *   stencil_fft_mixed_sign     1: channels with taps of both signs take the float64 FFT form whatever their size
+ * (older ones: stencil_fft, stencil_fft_window[_rows|_max], stencil_fft_batch, stencil_fft_streams, stencil_fft_scratch32,
+ *  stencil_fft_min_taps, stencil_fft_epilogue_lds, render_graph, front_fast, ... -- see r2f_set_option in r2f_api.hip) */
 int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
 
 /* --- plan-only entry points: the host-side planners of this library (raw2film_amd/csrc/r2f_plan.cpp), callable without a GPU and
