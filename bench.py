@@ -270,6 +270,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    # which scratch element the halation's passes of the LAST TIMED frame took (r2f_render chooses on the device, frame by frame);
+    # asked now, before the eager breakdown steps overwrite the frame block
+    scratch_choice = proc.ctx.frame_exposure_range() if (use_processor and effects) else None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=frame.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -458,37 +461,75 @@ def main():
         per_step = [extra[0][0] / 2, cols[1][0] / steps_for_cols, extra[2][0] / 2, extra[3][0] / 2, cols[4][0] / steps_for_cols, extra[5][0] / 2]
         roof["fft_pass_ms_per_step"] = {n: round(v, 4) for n, v in zip(names, per_step) if v > 0}
         roof["fft_pass_note"] = ("event-bracketed launch times summed per step; launches alternate between two internal streams, so "
-                                 "the sums exceed the stage wall time. cols: inside the timed steps; rows_*: two extra steps after them")
+                                 "the sums exceed the stage wall time. cols: inside the timed steps when those launch kernel by kernel, else -- "
+                                 "like rows_* -- from two extra eager steps after them (stage entry points: complex128 for the halation)")
+        # which scratch element the halation's passes of the TIMED steps took (r2f_render chooses on the device per frame; the eager
+        # stage-by-stage steps behind these pass times go through the stage entry points, which keep complex128)
+        rng = scratch_choice
+        if rng is not None:
+            roof["halation_scratch_element"] = dict(
+                rng, note="what r2f_render's front kernel recorded about the exposure planes of the last timed frame and what the halation's "
+                          "FFT passes made of it: the 12-byte element (doubles rounded to 48 bits) when max_abs <= bound x max(min, floor), "
+                          "else complex128.  stage_ms / fft_pass_ms_per_step come from eager stage calls, which always use complex128")
+        packed = bool(rng and rng["twelve_byte_element"])
+        # The dominant kernel of a step: the tail (one launch per frame) or one of the six FFT pass classes (summed per step)
+        cand = {"tail": float(stage_ms.get("tail", 0.0))}
+        cand.update({f"fft{c}": v for c, v in enumerate(per_step)})
+        top = max(cand, key=cand.get)
         dom = 1 if cols[1][0] >= cols[4][0] else 4
+        if top == "tail" and not batch:
+            tail_ms = cand["tail"]
+            tb = 24.0 * (r1 - r0) * W if not out_u8 else 15.0 * (r1 - r0) * W
+            roof["dominant_kernel"] = {
+                "kernel": "r2f::tail_kernel<4, true> (S6 hash noise + separable 9 x 9 grain stencil + grain LUT + clip + S8 tetrahedral 3-D LUT "
+                          "+ interleaved store: planar fp32 density in, HWC out)",
+                "bound": "hbm", "achieved": tb / (tail_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": tb / (tail_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": tail_ms, "launches_per_step": 1.0, "bytes_per_launch": tb,
+                "bytes_counted": "12 B/px of density planes read + the output written (12 B/px fp32, 3 B/px uint8): its algorithmic bytes; the noise is generated, the LUTs are cache-resident",
+                "share_of_step": tail_ms / ms_per_step,
+                "note": "the largest single kernel of a step since round 5 (event-timed eager stage call); the FFT pass classes follow in "
+                        "fft_pass_ms_per_step, the largest of them in largest_fft_pass"}
+            if traffic_rec is not None:
+                for name, v in traffic_rec.items():
+                    if isinstance(v, dict) and "tail_kernel" in name and "hbm_bytes_per_launch" in v:
+                        roof["dominant_kernel"]["traffic"] = v["hbm_bytes_per_launch"]
+                        roof["dominant_kernel"]["traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / tb
         if cols[dom][1] > 0:
             tot_ms, launches, bytes_alg = cols[dom]
             stats = st_h if dom == 1 else st_m
             win = next((c["window"] for c in stats if c["fft"]), None)
+            real = any(c.get("real_spectrum") for c in stats if c["fft"])
+            walk = real and win[0] == 256
             g = bytes_alg / (tot_ms * 1e-3) / 1e9
+            kname = (f"r2f::fft_cols_walk_kernel<{win[1] // 16}, {1 if dom == 4 else 0}>" if walk else
+                     f"r2f::fft_cols_kernel<{win[1] // 16}, {'true' if win[0] == 512 else 'false'}, {1 if dom == 4 else 0}, {'true' if real else 'false'}>")
             dk = {
-                "kernel": f"r2f::fft_cols_kernel<{win[1] // 16}, {'true' if win[0] == 512 else 'false'}, {1 if dom == 4 else 0}> "
+                "kernel": f"{kname} "
                           f"(pass 2 of the fp64 overlap-save FFT of the {'MTF' if dom == 4 else 'halation'} stencil, windows of {win[0]} rows x "
-                          f"{win[1]} columns, {'complex64' if dom == 4 else 'complex128'} scratch: column FFT, x kernel spectrum, inverse "
-                          "column FFT, in place)",
+                          f"{win[1]} columns, {'complex64' if dom == 4 else 'complex128'} scratch: column FFT, x "
+                          f"{'real ' if real else ''}kernel spectrum, inverse column FFT, in place"
+                          + ("; a resident grid walking the launch's pairs per column block" if walk else "") + ")",
                 "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
                 "kernel_ms": tot_ms / launches, "launches_per_step": launches / steps_for_cols, "bytes_per_launch": bytes_alg / launches,
                 "bytes_counted": "per window pair: the scratch image read + its rows that hold valid outputs written back; the kernel "
-                                 "spectrum (L2-resident) is not counted",
+                                 "spectrum (registers / L2) is not counted",
                 "share_of_step": tot_ms / steps_for_cols / ms_per_step,
                 "concurrency": "two FFT-pass kernels usually share the GPU (two internal streams): kernel_ms and achieved are per launch "
                                "under that sharing; the event pair also spans the dispatch gap (~5 us)",
             }
+            if dom == 1 and packed:
+                dk["note"] = ("measured on eager stage calls (complex128 scratch); in the timed steps r2f_render chose the 12-byte element for "
+                              "this frame: the same pass then moves 3/4 of these bytes (kernel fft_cols_walk_kernel<.., 3>)")
             if solo[dom][1]:
                 ms, n, b = solo[dom]
                 dk["alone"] = {"kernel_ms": ms / n, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                "note": "the same launches (twice the pairs each) with one internal stream, two extra steps"}
             if traffic_rec is not None:  # the same capture, this kernel's launches: L2 <-> fabric bytes per launch
-                kname = dk["kernel"].split(" (")[0]
                 for name, v in traffic_rec.items():
-                    if isinstance(v, dict) and kname in name and "hbm_bytes_per_launch" in v:
+                    if isinstance(v, dict) and kname.split("r2f::")[1] in name and "hbm_bytes_per_launch" in v:
                         dk["traffic"] = v["hbm_bytes_per_launch"]
                         dk["traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / dk["bytes_per_launch"]
-            roof["dominant_kernel"] = dk
+            roof["largest_fft_pass" if "dominant_kernel" in roof else "dominant_kernel"] = dk
         # all FFT passes of both stencils over the two stages' wall time
         sb = (sum(extra[c][2] / 2 for c in (0, 2, 3, 5)) + sum(cols[c][2] / steps_for_cols for c in (1, 4))) / frames_here  # per frame
         sms = float(stage_ms["halation"]) + float(stage_ms.get("mtf", 0.0))

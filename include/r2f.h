@@ -139,6 +139,13 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
  * kernel by kernel, out[3] graphs dropped (context changes, evictions, failed captures). */
 int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
 
+/* Introspection for the measurement harness (synchronises the device): what the front kernel of the last whole-frame render
+ * recorded about the exposure planes the halation's FFT passes read, and what they made of it.  out4 = {min x, max |x|, bound,
+ * floor}; *armed = 1 when that render's halation launches carried the rule (stencil_fft_scratch96_auto, 256-row windows, real
+ * spectrum: r2f_render above), *packed = 1 when they then took the 12-byte scratch element (max <= bound x max(min, floor)).
+ * Valid until the next write of the frame block (the next render).  Nothing upstream corresponds to it. */
+int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed);
+
 /* The per-render uniform write: p->seed -> the context's device-side frame block, asynchronously on `stream`
  * (gpu_processor.py:585-597: the uniform buffer `buffer_params_grain` with a fresh random seed, made ahead of the dispatches;
  * noise.wgsl:1-6 reads it).  r2f_render and, unless R2F_F_FRAME_RESIDENT is set, every stage entry point that makes grain does this itself.

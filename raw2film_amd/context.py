@@ -113,6 +113,14 @@ class HipContext:
         self._check(self._lib.r2f_render_stats(self._h, out))
         return {"replays": int(out[0]), "captures": int(out[1]), "eager": int(out[2]), "dropped": int(out[3])}
 
+    def frame_exposure_range(self) -> dict:
+        """r2f_frame_exposure_range: min / max |.| of the exposure planes the last whole-frame render's halation read, the rule
+        (bound, floor) and whether its FFT passes took the 12-byte scratch element (synchronises the device)."""
+        out, armed, packed = (C.c_float * 4)(), C.c_int(), C.c_int()
+        self._check(self._lib.r2f_frame_exposure_range(self._h, out, C.byref(armed), C.byref(packed)))
+        return {"min": float(out[0]), "max_abs": float(out[1]), "bound": float(out[2]), "floor": float(out[3]),
+                "armed": bool(armed.value), "twelve_byte_element": bool(packed.value)}
+
     def write_frame_params(self, params):
         """The per-render uniform write (r2f_write_frame_params): params.seed -> the context's device-side frame block, in
         stream order.  Stage calls whose params carry F_FRAME_RESIDENT read it instead of writing their own seed."""

@@ -108,6 +108,7 @@ struct r2f_ctx {
     int opt_fft_s96_auto = 1;
     float curve_slope_max = 0.f;  // max |d density / d log10 exposure| over the density curve's cells (host copy, r2f_set_curve1d)
     bool frame_track_request = false, frame_tracked = false, frame_dyn_request = false;  // render_launches -> the stage entries
+    bool frame_dyn_armed = false;  // the last whole-frame render's halation launches carried the rule (r2f_frame_exposure_range)
     int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
     // 1: a centrally symmetric tap box (k[i][j] == k[bh-1-i][bw-1-j] bit for bit, anchor at its centre -- every halation disc and
     // |ifft2| MTF kernel the reference builds, effects.py:200-217, :123-143) is laid out with its anchor on the window origin, so its
@@ -394,11 +395,12 @@ int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
 
 // p->seed -> the context's device-side frame block, in stream order (a one-lane kernel: its by-value argument is copied at
 // launch time, so no host staging buffer has to outlive the call).
-int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s) {
+// new_frame: also reset the exposure range (the start of a render); false: a stage entry's own seed write in the middle of one
+int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s, bool new_frame = true) {
     FrameParams v{};
     v.seed = p->seed;
     v.e_min = kFrameMinReset, v.e_max = kFrameMaxReset;
-    R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, s));
+    R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, new_frame ? 1 : 0, s));
     return R2F_OK;
 }
 
@@ -494,6 +496,15 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
     if (ctx->opt_stencil_fixed && ctx->opt_variant <= 0 && s.built_q && fixed_stencil_radius(s, &c, 1, fixed_preferred_max_r(ctx, which)))
         return false;
     return true;
+}
+
+// The rule of the halation's scratch element (FftConvArgs::dyn): the 12-byte element when max |x| <= bound x max(min x, floor).
+//   |delta density| <= 0.434 x steepest curve cell x 2.1e-12 x (max / shadow) <= 2.4e-7  (two ulps of a density in [1, 2));
+//   below the curve's first breakpoint np.interp clamps: no slope, so shadows under it do not count.
+void dyn_rule(const r2f_ctx* ctx, float* bound, float* floor) {
+    const double slope = std::max((double)ctx->curve_slope_max, 1e-3);
+    *bound = (float)std::min(2.4e-7 / (0.4343 * slope * 2.1e-12), 1e7);
+    *floor = (float)std::pow(10.0, (double)ctx->curve.x0);
 }
 
 plan::FftOptions fft_options(const r2f_ctx* ctx) {
@@ -625,10 +636,8 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
         ny == 256 && ctx->opt_fft_cols_walk && ctx->curve.cells) {
         a.s32 = 3;
         a.dyn = static_cast<const FrameParams*>(ctx->frame_buf.p);
-        // |delta density| <= 0.434 slope_max x 2.1e-12 x (max / shadow) <= 2.4e-7  (two ulps of a density in [1, 2))
-        const double slope = std::max((double)ctx->curve_slope_max, 1e-3);
-        a.dyn_bound = (float)std::min(2.4e-7 / (0.4343 * slope * 2.1e-12), 1e7);
-        a.dyn_floor = (float)std::pow(10.0, (double)ctx->curve.x0);  // below the curve's first breakpoint np.interp clamps: no slope
+        dyn_rule(ctx, &a.dyn_bound, &a.dyn_floor);
+        ctx->frame_dyn_armed = true;
     }
     const plan::FftBatches fb = plan::fft_batches(fo, ny, nx, bh, bw, W, y0, y1, nch, a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));  // (3: sized for 16)
     a.gx = fb.gx;
@@ -1379,7 +1388,7 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         a.grain_lut = ctx->grain_lut;
     }
     if (a.grain && !(p->flags & R2F_F_FRAME_RESIDENT)) {  // the seed of THIS call, ahead of the kernel that reads it
-        rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
+        rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), false);
         if (rc) return rc;
     }
     R2F_HIP(ctx, launch_tail(a, static_cast<hipStream_t>(stream)));
@@ -1684,7 +1693,7 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
     a.frame = static_cast<const FrameParams*>(ctx->frame_buf.p);
     a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
     if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
-        int rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
+        int rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), false);
         if (rc) return rc;
     }
     R2F_HIP(ctx, launch_noise(a, static_cast<hipStream_t>(stream)));
@@ -1714,6 +1723,7 @@ static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, in
     r2f_planes B{base + set_floats, (int64_t)(set_floats / 3), 0, H};
     int rc, finished = 0;
     ctx->frame_tracked = false;
+    ctx->frame_dyn_armed = false;
     if (hal) {  // the halation's identity channels (blue on a colour stock) are finished by the front kernel, straight into B
         if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // kernel by kernel: the frame block (seed, exposure range reset) ahead of the front kernel
             rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
@@ -1899,6 +1909,21 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
 int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4) {
     if (!ctx || !out4) return R2F_EINVAL;
     out4[0] = ctx->stat_replays, out4[1] = ctx->stat_captures, out4[2] = ctx->stat_eager, out4[3] = ctx->stat_dropped;
+    return R2F_OK;
+}
+
+int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed) {
+    if (!ctx || !out4 || !armed || !packed) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    R2F_HIP(ctx, hipDeviceSynchronize());
+    FrameParams v{};
+    R2F_HIP(ctx, hipMemcpy(&v, ctx->frame_buf.p, sizeof v, hipMemcpyDeviceToHost));
+    memcpy(&out4[0], &v.e_min, 4);
+    memcpy(&out4[1], &v.e_max, 4);
+    dyn_rule(ctx, &out4[2], &out4[3]);
+    *armed = ctx->frame_dyn_armed ? 1 : 0;
+    // (the kernels' own comparison; a block nobody has written a range into since its reset tells nothing)
+    *packed = (*armed && v.e_min != kFrameMinReset && out4[1] <= out4[2] * std::max(out4[0], out4[3])) ? 1 : 0;
     return R2F_OK;
 }
 

@@ -1318,10 +1318,16 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-__global__ void frame_params_kernel(FrameParams* dst, const FrameParams v) { *dst = v; }
+// (new_frame = 0: only the seed -- a stage entry's own write in the middle of a frame keeps the exposure range the front kernel recorded)
+__global__ void frame_params_kernel(FrameParams* dst, const FrameParams v, const int new_frame) {
+    if (new_frame)
+        *dst = v;
+    else
+        dst->seed = v.seed;
+}
 
-hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, hipStream_t s) {
-    hipLaunchKernelGGL(frame_params_kernel, dim3(1), dim3(1), 0, s, dst, v);
+hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int new_frame, hipStream_t s) {
+    hipLaunchKernelGGL(frame_params_kernel, dim3(1), dim3(1), 0, s, dst, v, new_frame);
     return hipGetLastError();
 }
 

@@ -254,7 +254,7 @@ hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s);
 hipError_t launch_lanczos4_u8(const LanczosArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 // *dst <- v on stream s (one lane): the per-render write of the context's FrameParams block ahead of a frame's launches
-hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, hipStream_t s);
+hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int new_frame, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
 hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s);
