@@ -350,8 +350,10 @@ def main():
         result["checksum"] = int(cs.item())
     eager = None
     if replaying or use_processor:  # the breakdowns below need per-launch events: the same frame, stage by stage, eagerly
+        sched = {} if (use_processor or renderer is None or renderer.schedule is None) else \
+            {"exchanges": renderer.schedule[0], "split_halation": renderer.schedule[1]}  # the schedule the timed steps ran, not a new measurement
         eager = RowShardedRenderer(timed, H, W, halation=effects, mtf=effects, grain=effects,
-                                   **({"rank": 0, "world": 1} if use_processor else {}))
+                                   **({"rank": 0, "world": 1} if use_processor else sched))
         if renderer is not None:
             eager.E, eager.D, eager.D2 = renderer.E, renderer.D, renderer.D2  # share the planes (no second 2.4 GB set)
 

@@ -126,7 +126,9 @@ def test_process_under_random_settings(proc, c):
     # LANCZOS4 enlargement; the free rotation's bilinear weights and the chroma NR round in float32 on both sides
     scaled = ref.shape[:2] != (pipeline_hw if c["canvas"] == "No" else None)
     lim, frac = (3, 5e-3) if (scaled or c["rotation"] or c["nr"]) else (1, 1e-4)
-    assert d.max() <= lim and (d > 0).mean() <= frac, (int(d.max()), float((d > 0).mean()), c)
+    # (the contract's fraction has a quantum: on a frame of fewer than 1 / frac samples -- 39 x 59 x 3 here and there -- ONE truncation
+    # flip at a float32 rounding boundary is already 1.4e-4 of the samples; one flip is always within the contract)
+    assert d.max() <= lim and int((d > 0).sum()) <= max(1, frac * d.size), (int(d.max()), float((d > 0).mean()), c)
 
 
 @pytest.mark.parametrize("c", _cases(int(os.environ.get("R2F_PROC_FUZZ_CASES", "12"))), ids=lambda c: f"{c['H']}x{c['W']}-f{c['frame'][0]:g}-z{c['zoom']:g}-t{c['turns']}-ms{c['max_scale']}-{c['canvas'].split()[0]}")
