@@ -821,7 +821,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
 // =============================================================================== C ABI
 extern "C" {
 
-const char* r2f_version(void) { return "r2f-hip 0.4 gfx950 abi4"; }
+const char* r2f_version(void) { return "r2f-hip 0.5 gfx950 abi5"; }
 
 int r2f_create(int device, r2f_ctx** out) {
     if (!out) return R2F_EINVAL;
