@@ -15,6 +15,15 @@
 //   pass 2  columns:  forward FFT along r, multiply by conj(K^)[r'][k], inverse FFT along r', in place  -> S[r][k]
 //   pass 3  rows:     inverse FFT along k, scale 1 / (ny nx), crop to the valid outputs, [log + density curve], store
 //
+// Round 5, all three behind options that default on (records: profiles/r05_fft_levers_ab.txt, r05_scratch96_probe.txt):
+//   * a centrally symmetric tap box (both production stencils) is laid out around the window origin, so its spectrum is REAL:
+//     8 bytes per element in pass 2, two multiplies, and the valid outputs of a window start at (oy, ox) = the anchor (kreal);
+//   * pass 2 of 256-row windows with a real spectrum runs as a resident grid whose workgroups WALK the launch's pairs for their
+//     16 columns, the spectrum in registers from pair to pair (fft_cols_walk_kernel);
+//   * the scratch element is a template parameter of every pass: complex128, complex64 (the MTF: density is bounded), or a
+//     12-byte element of doubles rounded to 48 bits -- for the halation of a whole-frame render chosen ON THE DEVICE per frame
+//     from the exposure range the front kernel recorded (ST = 3 kernels branch on dyn_packed once, wave-uniformly).
+//
 // A 256-point line is transformed by 16 lanes holding 16 elements each (element n = lane + 16 m): a 16-point DFT in
 // registers, the twiddles W_256^(lane p), a 16 x 16 transpose through LDS, a second 16-point DFT -- natural order in and
 // out, one LDS round trip per transform.  (The first version ran four radix-4 stages through LDS and was bound by

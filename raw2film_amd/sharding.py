@@ -3,7 +3,7 @@
 RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GPU
     (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
     Pixels are independent except for the two stencils, so a frame costs ONE neighbour
-    exchange (two with single_exchange=False) and no reduction:
+    exchange (or two: `exchanges`, measured on the first frames when left on "auto") and no reduction:
         S0+S1 on own rows -> exposure E            exchange r_h + r_m rows of E  (both stencils' halo)
         S2+S3+S4 on own rows + r_m -> density D    [or: exchange r_m rows of D  (MTF halo)]
         S5 -> S6 (hash noise at GLOBAL coordinates, no exchange) -> S8 -> own output rows
@@ -17,6 +17,10 @@ RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GP
     one.  The default fp64 FFT form anchors its overlap-save windows at the first row of the call, so a shard
     tiles the frame differently from the whole-frame render: the fp64 rounding noise (~1e-13) differs, and after
     the one rounding to fp32 a handful of pixels of a 100 MP frame may differ by one ulp (tests/test_gpu_fullsize.py).
+    Which schedule runs -- one exchange with the halation in one call, or as interior + bands with the interior ahead of the
+    exchange, or two exchanges (exposure halo, then density halo: one halation window row fewer per 1/8 shard at 100 MP) -- is
+    MEASURED: the first frames render under each candidate between events on the launch stream, the ranks all-reduce (MAX)
+    the times and take the one whose slowest rank was fastest (`schedule`, `tuned_ms`); graphs are captured for that one.
 
 BatchSharder -- MANY frames (batch export, gui.py:2393-2514): frame i -> rank i mod world, no
     collectives; per rank a producer thread runs the host phase (`extract_image_data_cpu`) one
@@ -486,15 +490,13 @@ class RowShardedRenderer:
                 self._graphs = {key: slot}
             self._graphs_state = new_state
             return res
-        # world > 1: the front kernels and the exchange are issued every frame; what is captured is (1) the interior halation, which
-        # runs while the halos travel, and (2) everything downstream of the exchange.  world == 1: one graph, front included.
+        # world > 1: the front kernels and the exchange(s) are issued every frame.  What is captured: world == 1: one graph, front
+        # included.  world > 1, one exchange: [the interior halation, replayed while the halos travel,] then everything downstream
+        # of the exchange.  Two exchanges (or the MTF alone): the density (halation of the own rows), then -- after the density halo
+        # exchange, which is issued every frame like the first one -- the MTF and the tail.
         pending = None
         if not whole:
             pending = self._front_and_start_exchange(image_rows)
-        # What is captured: world == 1: one graph, front included.  world > 1, one exchange: [the interior halation, replayed
-        # while the halos travel,] then everything downstream of the exchange.  Two exchanges (or the MTF alone): the density
-        # (halation of the own rows), then -- after the density halo exchange, which is issued every frame like the first one --
-        # the MTF and the tail.
         mid_exchange = (not whole) and self.mtf and not self.single_exchange
         if slot[1] is None:
             graphs = {"pre": None, "a": None, "b": None}
