@@ -650,6 +650,17 @@ def main():
         assert res.dtype == np.uint8 and res.shape == (H, W, 3)
         copies["process_end_to_end_ms"] = min(e2e)
         copies["process_end_to_end_first_ms"] = e2e[0]
+        # the same call with the result handed back as a view of a pinned buffer (HipProcessor(result_buffers=2): interactive use)
+        # instead of a fresh pageable array like upstream's: the download then runs at the link's rate
+        proc.result_buffers = 2
+        e2e = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + 10 + i, lens_correction=False, **settings)
+            e2e.append((time.perf_counter() - t0) * 1e3)
+        proc.result_buffers = 0
+        copies["process_end_to_end_pinned_result_ms"] = min(e2e)
         gb = H * W * 3 / 1e9
         copies["GB_per_s"] = {"h2d_f32": 4 * gb / (copies["h2d_f32_ms"] * 1e-3), "h2d_u16": 2 * gb / (copies["h2d_u16_ms"] * 1e-3),
                               "d2h_u8": gb / (copies["d2h_u8_ms"] * 1e-3)}
@@ -657,7 +668,9 @@ def main():
                           "(the reference's write_texture, gpu_processor.py:279-305); h2d_u16: pinned uint16 frame -> device + r2f_decode_u16 "
                           "(raw_conversion.py:50-52 on the device); d2h_u8: the uint8 result -> pinned host (read_texture, :1311-1357); events on "
                           "the launch stream, best of 5.  process_end_to_end: wall clock of HipProcessor.process(host ndarray, cache=False) -> "
-                          "uint8 ndarray, best of 3 (first call listed too: it builds tables and pinned staging buffers)")
+                          "uint8 ndarray, best of 3 (first call listed too: it builds tables and pinned staging buffers): upload 21 + render 5 + a download "
+                          "into a FRESH pageable array (33 ms for 0.3 GB -- upstream's ownership semantics); process_end_to_end_pinned_result: the "
+                          "same with result_buffers = 2 (a view of a pinned buffer comes back)")
         result["host_device_copies"] = copies
         del host_f32, host_np
 
