@@ -116,7 +116,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int 
  * Scratch element of the halation's passes: complex128, or -- chosen on the device, frame by frame, by r2f_render only -- a
  * 12-byte element (each component a double rounded to 48 bits) when the range of the exposure samples the front kernel wrote
  * allows it: max |x| <= bound x max(min x, first breakpoint of the density curve), the bound derived from the curve's steepest
- * cell so that the element costs a density at most two fp32 ulps (option stencil_fft_scratch96_auto, default 1; a frame with a
+ * cell so that the element costs a density at most three fp32 ulps -- the MTF's complex64 scratch is allowed the same -- (option stencil_fft_scratch96_auto, default 1; a frame with a
  * 65 504 specular over 1e-4 shadows keeps complex128).  The stage entry points always use complex128 for the halation, so a
  * whole-frame render and a row-sharded one agree to that element's rounding, not bit for bit.
  * Non-finite samples: in the direct form a NaN / infinity in a stencil's input comes out as NaN in every output whose tap box

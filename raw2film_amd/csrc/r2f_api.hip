@@ -102,9 +102,10 @@ struct r2f_ctx {
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (doubles rounded to 48 bits, 2^-37) whatever the frame holds -- A/B
     // 1: a whole-frame render (r2f_render) lets the halation's FFT passes choose between complex128 and the 12-byte element ON THE
     // DEVICE, per frame, from the range of the exposure samples its front kernel wrote (FrameParams::e_min / e_max): the 12-byte
-    // element costs a shadow at most ~2.1e-12 x (max |x| / shadow) of itself (profiles/r05_scratch96_probe.txt), which the density
-    // curve turns into 0.434 x slope x that; the bound keeps it under two fp32 ulps of a density in [1, 2) -- less than the MTF's
-    // complex64 scratch is allowed (3) -- and frames with a wider range (a 65 504 specular over 1e-4 shadows) keep complex128.
+    // element costs a shadow at most 6e-12 x (max |x| / shadow) of itself -- the worst of isolated speculars (2.1e-12), bright blocks,
+    // a half-bright frame and bright stripes, profiles/r05_scratch96_probe.txt -- which the density curve turns into 0.434 x slope x
+    // that; the bound keeps it under three fp32 ulps of a density in [1, 2), what the MTF's complex64 scratch is allowed, and frames
+    // with a wider range (a 65 504 specular over 1e-4 shadows) keep complex128.
     int opt_fft_s96_auto = 1;
     float curve_slope_max = 0.f;  // max |d density / d log10 exposure| over the density curve's cells (host copy, r2f_set_curve1d)
     bool frame_track_request = false, frame_tracked = false, frame_dyn_request = false;  // render_launches -> the stage entries
@@ -499,11 +500,12 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
 }
 
 // The rule of the halation's scratch element (FftConvArgs::dyn): the 12-byte element when max |x| <= bound x max(min x, floor).
-//   |delta density| <= 0.434 x steepest curve cell x 2.1e-12 x (max / shadow) <= 2.4e-7  (two ulps of a density in [1, 2));
+//   |delta density| <= 0.434 x steepest curve cell x 6e-12 x (max / shadow) <= 3.6e-7  (three ulps of a density in [1, 2); 6e-12: the
+//   worst coefficient measured over isolated speculars, bright blocks, a half-bright frame and stripes);
 //   below the curve's first breakpoint np.interp clamps: no slope, so shadows under it do not count.
 void dyn_rule(const r2f_ctx* ctx, float* bound, float* floor) {
     const double slope = std::max((double)ctx->curve_slope_max, 1e-3);
-    *bound = (float)std::min(2.4e-7 / (0.4343 * slope * 2.1e-12), 1e7);
+    *bound = (float)std::min(3.6e-7 / (0.4343 * slope * 6.0e-12), 1e7);
     *floor = (float)std::pow(10.0, (double)ctx->curve.x0);
 }
 

@@ -287,7 +287,7 @@ def test_the_halation_scratch_element_is_chosen_per_frame_on_the_device():
     """Round 5.  A whole-frame render lets the halation's FFT passes choose between complex128 and the 12-byte element on the
     device: the front kernel records min and max |.| of the exposure samples it writes for them (atomics into the context's frame
     block), and every pass takes the 12-byte element when max <= bound x max(min, floor) -- bound from the density curve's
-    steepest cell, so that the element costs a density at most two fp32 ulps, floor = the curve's first breakpoint (below it
+    steepest cell, so that the element costs a density at most three fp32 ulps, floor = the curve's first breakpoint (below it
     np.interp clamps).  Per FRAME: the same captured graph replays with either element, depending on what the input buffer holds.
     Stage calls (row shards) never take it: their halo rows come from elsewhere."""
     from helpers import SEED, oracle_inputs, stocks as _stocks
