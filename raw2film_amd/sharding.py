@@ -203,7 +203,7 @@ class RowShardedRenderer:
 
     def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,
                  group=None, rank=None, world=None, side_grain: bool = False, graph: bool = False, split_halation="auto",
-                 exchanges="auto", tune_frames: int = 2):
+                 exchanges="auto", tune_frames: int = 2, frame_timer=None):
         import torch
         import torch.distributed as dist
 
@@ -322,7 +322,10 @@ class RowShardedRenderer:
         self.tune_frames = int(tune_frames)
         self.schedule = None
         self.tuned_ms = None  # per candidate: the measured frame time (max over ranks) the choice was made from
-        can_measure = (getattr(backend, "device", None) is not None and torch.cuda.is_available())
+        # frame_timer(candidate, render) -> ms: how a measuring frame is timed; default: two events on the launch stream around
+        # render() (device backends only).  Tests of the tuning protocol itself inject a clock of their own (CPU backends, gloo).
+        self._frame_timer = frame_timer
+        can_measure = frame_timer is not None or (getattr(backend, "device", None) is not None and torch.cuda.is_available())
         if len(cands) > 1 and can_measure and self.tune_frames > 0:
             self._tune = {"i": 0, "n": -1, "ms": [[] for _ in cands]}
             self._set_schedule(cands[0])
@@ -356,12 +359,18 @@ class RowShardedRenderer:
         if t["n"] < 0:  # the very first frame builds tables, spectra and scratch: not timed
             t["n"] = 0
             return self._render_eager(image_rows, out_f32, out_u8)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        res = self._render_eager(image_rows, out_f32, out_u8)
-        b.record()
-        b.synchronize()
-        t["ms"][t["i"]].append(a.elapsed_time(b))
+        if self._frame_timer is not None:
+            box = []
+            ms = self._frame_timer(self._candidates[t["i"]], lambda: box.append(self._render_eager(image_rows, out_f32, out_u8)))
+            res = box[0]
+        else:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            res = self._render_eager(image_rows, out_f32, out_u8)
+            b.record()
+            b.synchronize()
+            ms = a.elapsed_time(b)
+        t["ms"][t["i"]].append(float(ms))
         t["n"] += 1
         if t["n"] >= self.tune_frames:
             t["i"], t["n"] = t["i"] + 1, 0

@@ -374,3 +374,62 @@ def test_batch_sharder_progress_counts_finished_frames_and_a_failure_keeps_the_f
     with pytest.raises(RuntimeError, match="submit failed"):
         bs.run([0, 1, 2, 3], lambda t: t, execute, collect=lambda t, h: log.append(("collect", t)))
     assert log == [("submit", 0), ("submit", 1), ("collect", 0), ("collect", 1)]  # frame 1 was in flight when frame 2 failed
+
+
+class _BandedBackend(OracleStageBackend):
+    """... that also tells the row tiler how many rows one window row of its (imaginary) FFT form yields, so that the two-exchange
+    schedule becomes a candidate."""
+
+    def halation_band_rows(self, W, rows):
+        return 10
+
+
+def _tuning_worker(rank, world, port, H, W, scale, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p, img = _inputs(H, W, scale)
+        be = _BandedBackend(p)
+        # a clock per rank: locally rank 0 and 2 would pick (1, True), rank 1 (2, False); the slowest rank of (1, True) is slower
+        # than the slowest rank of (2, False), so every rank has to end on (2, False)
+        clock = {(1, False): [5.0, 5.0, 5.0], (1, True): [3.0, 6.0, 3.0], (2, False): [4.0, 4.5, 4.2]}
+        seen = []
+
+        def timer(cand, render):
+            seen.append(cand)
+            render()
+            return clock[cand][rank] + 0.01 * len(seen)  # (later frames of a candidate a little slower: the best one counts)
+
+        rr = sharding.RowShardedRenderer(be, H, W, halation=True, mtf=True, grain=p.grain_lut is not None, frame_timer=timer, tune_frames=2)
+        assert rr.tuning and rr._candidates == [(1, False), (1, True), (2, False)], rr._candidates
+        r0, r1 = rr.plan.r0, rr.plan.r1
+        out = torch.zeros((r1 - r0, W, 3), dtype=torch.float32)
+        ref = st.render(img, p)[r0:r1]
+        frames = 0
+        while rr.tuning:  # every measuring frame is a correct frame, whatever the candidate
+            rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
+            frames += 1
+            np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=2e-6)
+        assert frames == 1 + 2 * 3 and seen == [(1, False)] * 2 + [(1, True)] * 2 + [(2, False)] * 2, (frames, seen)
+        assert rr.schedule == (2, False) and not rr.single_exchange, rr.schedule
+        assert [round(t, 2) for t in rr.tuned_ms] == [5.01, 6.03, 4.55], rr.tuned_ms  # the MAX over the ranks of each rank's best frame
+        rr.trace = []
+        rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
+        assert rr.trace == ["exchange_start", "exchange_finish", "exchange_density"], rr.trace
+        np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=2e-6)
+        if rank == 0:
+            np.save(result_path, np.asarray(rr.tuned_ms))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_schedule_is_measured_and_agreed_across_ranks(tmp_path):
+    """Round 5: with `exchanges` / `split_halation` on "auto" the ranks walk the candidate schedules in lockstep on their first
+    frames, time each (here: an injected clock per rank), all-reduce the times (MAX) and take the schedule whose SLOWEST rank was
+    fastest -- the same one everywhere, whatever each rank would have picked on its own (the two-exchange form needs its neighbours
+    to send density rows)."""
+    path = str(tmp_path / "tuned.npy")
+    mp.spawn(_tuning_worker, args=(3, _free_port(), 120, 40, 80.0, path), nprocs=3, join=True)
+    assert np.load(path).shape == (3,)
