@@ -25,6 +25,10 @@ Pinning status:
   vector for them.  Their restatements here follow the reference's in-tree WGSL
   twins (`shaders/lut_2d.wgsl`, `lut_1d.wgsl`, `noise.wgsl`, `noise_bw.wgsl`,
   `grain.wgsl`) and the LUT layouts in `gpu_processor.py:307-409,565-611`.
+  `tools/make_golden_sfl.py` turns that into a one-command job wherever sfl is
+  installed: it runs sfl's own functions on this repo's fixture frame and writes
+  `tests/golden/sfl.npz`; `tests/test_oracle_golden.py -k sfl` (skipping while the
+  file is absent) then pins S1 / S3 / S4 and the grain factor of S6 to it.
 * `cv.filter2D` (OpenCV is not installed): restated from its documented
   semantics -- correlation, centred anchor, BORDER_REFLECT_101, float32 in/out --
   and cross-checked against `scipy.ndimage.correlate(mode="mirror")`.
