@@ -108,7 +108,6 @@ struct r2f_ctx {
     // with a wider range (a 65 504 specular over 1e-4 shadows) keep complex128.
     int opt_fft_s96_auto = 1;
     float curve_slope_max = 0.f;  // max |d density / d log10 exposure| over the density curve's cells (host copy, r2f_set_curve1d)
-    bool frame_track_request = false, frame_tracked = false, frame_dyn_request = false;  // render_launches -> the stage entries
     bool frame_dyn_armed = false;  // the last whole-frame render's halation launches carried the rule (r2f_frame_exposure_range)
     int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
     // 1: a centrally symmetric tap box (k[i][j] == k[bh-1-i][bw-1-j] bit for bit, anchor at its centre -- every halation disc and
@@ -161,6 +160,7 @@ struct r2f_ctx {
         hipEvent_t done = nullptr;  // recorded behind every launch of `exec`: the executable graph must outlive its last replay
         uint64_t last_use = 0;
         bool never = false;  // a capture of this entry failed: kernel by kernel from now on
+        bool dyn_armed = false;  // the captured halation launches choose their scratch element on the device
     };
     std::vector<RenderGraph> graphs;
     // Executable graphs that left the cache (evicted, or dropped because the generation moved) while a replay of them may still be
@@ -522,8 +522,10 @@ plan::FftOptions fft_options(const r2f_ctx* ctx) {
 
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
 // their window pairs share the launches.
+// dyn: the caller (a whole-frame render) vouches that the context's frame block holds the range of exactly the samples `src` holds:
+// the passes may then choose their scratch element on the device (FftConvArgs::dyn).
 int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2f_planes* src, const r2f_planes* dst, int y0, int y1,
-                    int W, int H, int epilogue, float log_eps, hipStream_t s) {
+                    int W, int H, int epilogue, float log_eps, hipStream_t s, bool dyn) {
     StencilSet& set = ctx->stencil[which];
     int b[4];
     tap_box(set, chans[0], b);
@@ -634,7 +636,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     for (int i = 0; i < nch; ++i)
         if (set.mixed_sign[chans[i]] && ctx->opt_fft_mixed_sign) a.s32 = 0;  // (the 12-byte element neither)
     // the halation of a whole-frame render whose front kernel recorded the range of the exposure planes: element chosen on the device
-    if (a.s32 == 0 && which == R2F_KERNEL_HALATION && epilogue == 1 && ctx->frame_dyn_request && ctx->opt_fft_s96_auto && a.kreal &&
+    if (a.s32 == 0 && which == R2F_KERNEL_HALATION && epilogue == 1 && dyn && ctx->opt_fft_s96_auto && a.kreal &&
         ny == 256 && ctx->opt_fft_cols_walk && ctx->curve.cells) {
         a.s32 = 3;
         a.dyn = static_cast<const FrameParams*>(ctx->frame_buf.p);
@@ -710,7 +712,7 @@ bool single_tap_channel(const StencilSet& set, int c, float* w) { return plan::s
 
 // skip_identity: the single-tap channels were finished by the front kernel (r2f_stage_front_split) -- leave them alone.
 int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W, int H,
-                int epilogue, float log_eps, hipStream_t s, bool skip_identity = false) {
+                int epilogue, float log_eps, hipStream_t s, bool skip_identity = false, bool dyn = false) {
     if (y1 <= y0) return R2F_OK;
     if (W <= 0 || H <= 0 || y0 < 0 || y1 > H) return fail(ctx, R2F_EINVAL, "stencil: bad geometry");
     StencilSet& set = ctx->stencil[which];
@@ -772,7 +774,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
                 tap_box(set, d, ob);
                 if (!done[d] && fft_eligible(ctx, set, d) && !memcmp(ob, tb, sizeof tb)) group[ng++] = d, done[d] = true;
             }
-            rc = run_stencil_fft(ctx, which, group, ng, src, dst, y0, y1, W, H, epilogue, log_eps, s);
+            rc = run_stencil_fft(ctx, which, group, ng, src, dst, y0, y1, W, H, epilogue, log_eps, s, dyn);
             if (rc) return rc;
         } else if (tb[0] == tb[1] && tb[2] == tb[3] && tb[0] == set.kh / 2 && tb[2] == set.kw / 2 && ctx->opt_ablate == 0) {
             if (skip_identity) continue;
@@ -1106,7 +1108,7 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
 // ------------------------------------------------------------------------------- stages
 static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
                             const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
-                            int H_global, void* stream, const r2f_planes* finish_dst, int* finished_mask);
+                            int H_global, void* stream, const r2f_planes* finish_dst, int* finished_mask, bool* tracked = nullptr);
 
 int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
                     const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
@@ -1124,9 +1126,12 @@ int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int
                             stream, density, finished_mask);
 }
 
+// tracked (whole-frame renders): when given, the fast kernel records the range of the exposure planes it writes in the context's frame
+// block and *tracked says whether that happened (only the split fast kernel does it).
 static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows, int upto,
                             const r2f_planes* dst, float* out_f32, uint8_t* out_u8, int out_gy0, int y0, int y1, int W,
-                            int H_global, void* stream, const r2f_planes* finish_dst, int* finished_mask) {
+                            int H_global, void* stream, const r2f_planes* finish_dst, int* finished_mask, bool* tracked) {
+    if (tracked) *tracked = false;
     if (!ctx || !p) return R2F_EINVAL;
     R2F_GUARD(ctx);
     if (y1 <= y0) return R2F_OK;
@@ -1185,9 +1190,9 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
         f.vec = (vec && planes_vec_ok(finish_dst, W)) ? 1 : 0;
         if (f.finish_mask && f.finish_mask != 7 && front_fast_eligible(f)) {
             *finished_mask = f.finish_mask;
-            if (ctx->frame_track_request && ctx->opt_fft_s96_auto) {  // a whole-frame render: the exposure planes' range for the FFT passes
+            if (tracked && ctx->opt_fft_s96_auto) {  // a whole-frame render: the exposure planes' range for the FFT passes
                 f.track = static_cast<FrameParams*>(ctx->frame_buf.p);
-                ctx->frame_tracked = true;
+                *tracked = true;
             }
             R2F_HIP(ctx, launch_front_fast(f, static_cast<hipStream_t>(stream)));
             return R2F_OK;
@@ -1724,27 +1729,24 @@ static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, in
     r2f_planes A{base, (int64_t)(set_floats / 3), 0, H};
     r2f_planes B{base + set_floats, (int64_t)(set_floats / 3), 0, H};
     int rc, finished = 0;
-    ctx->frame_tracked = false;
+    bool tracked = false;
     ctx->frame_dyn_armed = false;
     if (hal) {  // the halation's identity channels (blue on a colour stock) are finished by the front kernel, straight into B
         if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // kernel by kernel: the frame block (seed, exposure range reset) ahead of the front kernel
             rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
             if (rc) return rc;
         }
-        ctx->frame_track_request = true;  // ... which also records the range of the exposure planes it writes (every row of them)
-        rc = r2f_stage_front_split(ctx, p, in, in_layout, 0, H, &A, &B, 0, H, W, H, &finished, stream);
-        ctx->frame_track_request = false;
+        // ... and also records the range of the exposure planes it writes (every row of them)
+        rc = stage_front_impl(ctx, p, in, in_layout, 0, H, R2F_UPTO_EXPOSURE, &A, nullptr, nullptr, 0, 0, H, W, H, stream, &B, &finished, &tracked);
     } else
         rc = r2f_stage_front(ctx, p, in, in_layout, 0, H, R2F_UPTO_DENSITY, &A, nullptr, nullptr, 0, 0, H, W, H, stream);
     if (rc) return rc;
     const r2f_planes* cur = &A;
     const r2f_planes* other = &B;
     if (hal) {
-        r2f_params q = *p;
-        if (finished) q.flags |= R2F_F_IDENTITY_DONE;
-        ctx->frame_dyn_request = ctx->frame_tracked;
-        rc = r2f_stage_halation(ctx, &q, cur, other, 0, H, W, H, stream);
-        ctx->frame_dyn_request = false;
+        // (r2f_stage_halation with the vouching bit: the frame block holds the range of exactly these exposure planes)
+        rc = run_stencil(ctx, R2F_KERNEL_HALATION, cur, other, 0, H, W, H, 1, p->log_eps, static_cast<hipStream_t>(stream),
+                         finished != 0 || (p->flags & R2F_F_IDENTITY_DONE) != 0, tracked);
         if (rc) return rc;
         std::swap(cur, other);
     }
@@ -1840,6 +1842,7 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     if (slot >= 0 && ctx->graphs[slot].exec) {
         r2f_ctx::RenderGraph& g = ctx->graphs[slot];
         g.last_use = ++ctx->graph_clock;
+        ctx->frame_dyn_armed = g.dyn_armed;
         if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // (a caller that wrote the frame block itself says so with the flag)
             int rc = write_frame_params(ctx, p, s);
             if (rc) return rc;
@@ -1896,6 +1899,7 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     g.graph = graph;
     g.exec = exec;
     g.last_use = ++ctx->graph_clock;
+    g.dyn_armed = ctx->frame_dyn_armed;  // (what the captured halation launches carry; r2f_frame_exposure_range after a replay)
     if (hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) g.done = nullptr, (void)hipGetLastError();
     ++ctx->stat_captures;
     if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
