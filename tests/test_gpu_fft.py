@@ -340,8 +340,27 @@ def test_the_halation_scratch_element_is_chosen_per_frame_on_the_device():
             buf.copy_(torch.from_numpy(frame))
             c.render(buf, params, out_f32=out)
             np.testing.assert_array_equal(out.cpu().numpy(), want[name])
+            # ... and the diagnostic (r2f_frame_exposure_range) tells what the frame's passes compared and chose
+            rng = c.frame_exposure_range()
+            assert rng["armed"] and rng["twelve_byte_element"] == (name == "benign")
+            assert rng["max_abs"] <= rng["bound"] * max(rng["min"], rng["floor"]) if name == "benign" else rng["max_abs"] > 6e4
         s1 = c.render_stats()
         assert s1["replays"] - s0["replays"] == 3 and s1["captures"] == s0["captures"]
+        # a second captured graph without the halation is not armed, and replaying the first one again is (the flag belongs to
+        # the graph that ran last, not to the last capture)
+        import ctypes
+        q = type(params)()
+        ctypes.memmove(ctypes.byref(q), ctypes.byref(params), ctypes.sizeof(q))
+        from raw2film_amd import _lib as L
+        q.flags &= ~L.F_HALATION
+        out2 = torch.empty_like(out)
+        for _ in range(3):
+            c.render(buf, q, out_f32=out2)
+        assert not c.frame_exposure_range()["armed"]
+        c.render(buf, params, out_f32=out)
+        s2 = c.render_stats()
+        assert s2["replays"] - s1["replays"] == 3 and s2["captures"] - s1["captures"] == 1
+        assert c.frame_exposure_range()["armed"] and c.frame_exposure_range()["twelve_byte_element"]
         # the stage entry points keep complex128 whatever the frame holds
         E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
         D1, D2 = torch.empty_like(E), torch.empty_like(E)
