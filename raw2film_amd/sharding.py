@@ -9,8 +9,9 @@ RowShardedRenderer -- ONE large frame, contiguous row shards, one process per GP
         S5 -> S6 (hash noise at GLOBAL coordinates, no exchange) -> S8 -> own output rows
         [S7 highlight burn, when on: one all-reduce (SUM) of the ~50 x 75 low-res cell sums between S6 and S8]
     The exchange is one send + one receive per neighbour and plane, batched (`batch_isend_irecv`, i.e.
-    ncclGroupStart/End): at 100 MP that is 60 rows x 12288 px x 3 planes x 4 B = 8.8 MB per direction
-    -- latency-bound, every pair on its own xGMI link.  S0+S1 runs on the rows the neighbours wait for
+    ncclGroupStart/End): at 100 MP that is 60 rows x 12288 px x 4 B for the two planes the halation blurs and
+    17 rows for the single-tap blue plane (MTF halo only) = 6.6 MB per direction -- latency-bound, every pair
+    on its own xGMI link.  S0+S1 runs on the rows the neighbours wait for
     first and on the interior rows while the halos travel.  Global top/bottom edges are
     reflected (BORDER_REFLECT_101) inside the kernels.  With the DIRECT stencils (`stencil_fft = 0`) every
     stage sums its taps in a tile-independent order and the sharded result is bit-identical to the single-GPU
@@ -273,9 +274,9 @@ class RowShardedRenderer:
         # window row of the FFT form high (172 rows at 100 MP) where that is known, so the three calls together cover the same
         # number of window rows as one call would.
         # Worth it only where the exchange would otherwise be exposed: three calls cost ~0.05 ms more device time than one (the
-        # bands are small launches: measured on one GPU, tools/shard_model.py), the interior front kernel already covers
-        # 4.9 ns per kilopixel of own rows, and the exchange is MODELLED at 30 us + bytes / 55 GB/s (one xGMI link; no multi-GPU
-        # node was available to measure it).  split_halation = True / False overrides the estimate.
+        # bands are small launches: measured on one GPU, tools/shard_model.py) and the interior front kernel already covers
+        # part of the transfer -- so this is one of the candidate schedules the first frames MEASURE (below);
+        # split_halation = True / False fixes it either way.
         self._graphs = {}   # key -> [calls seen, captured graphs or None], most recently used last
         self._graphs_state = None  # _graph_state() the graphs were captured from
         self._identity_done = 0  # channel mask front_split finished (world == 1 only)
