@@ -341,7 +341,12 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     typedef RowGeom<XL> G;
     constexpr int NX = G::NX, LPL = G::LPL;
     const int lane = threadIdx.x & 63, l = lane & (LPL - 1);
-    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + threadIdx.x / LPL;
+    // (the row index is made from an opaque copy of the thread id here and again behind the transform: as one value it lived in two
+    // VGPRs -- with its sign extension -- from the first address to the last store, and in the kernel that holds both element
+    // forms it was computed ahead of the branch and spilled: 2-6 VGPRs of scratch at four waves per SIMD)
+    unsigned tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));
+    const int pair = blockIdx.y, r = blockIdx.x * G::ROWS + tid0 / LPL;
     int wyA = 0, wxA = 0, wyB = 0, wxB = 0;
     const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc;  // channel-major pair numbering
     const bool hasA = window_of(a, 2 * pc, wyA, wxA), hasB = window_of(a, 2 * pc + 1, wyB, wxB);
@@ -408,8 +413,13 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
         if (v[3].x == 1.2345e300) sst<ST>(s1, 0, v[5]);  // keep the transform alive without storing
         return;
     }
+    // register q sits 16 q columns on: the next 16 x 16 block of the layout, 256 elements further
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // the row index again (see the top)
+    const int rs = blockIdx.x * G::ROWS + tid / LPL;
+    const unsigned sb = sidx(rs, G::out_col(l, 0), G::NBX);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) sst<ST>(s1, sidx(r, G::out_col(l, q), G::NBX), v[q]);
+    for (int q = 0; q < 16; ++q) sst<ST>(s1, sb + q * 256, v[q]);
     if (R2F_FFT_EXP & 8) {  // ... and this workgroup's rows below the valid outputs are the first rows of the window row below
         const int below = pair + (a.gx + 1) / 2;
         if (r >= a.vy && below < a.npairs && (a.pair0 + below) / a.ppc == ci && !a.raw) {

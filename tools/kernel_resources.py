@@ -1,77 +1,44 @@
-#!/usr/bin/env python3
-"""Per-kernel register / scratch / occupancy table of one HIP source (hipcc -Rpass-analysis=kernel-resource-usage).
+"""Register / scratch / occupancy table of every kernel of the library, from hipcc's own remarks (no GPU needed):
 
-    python tools/kernel_resources.py r2f_front.hip [-DNAME=VALUE ...] [--filter substring] [--spills]
+    python tools/kernel_resources.py > profiles/rNN_kernel_resources.txt
 
-Objects go to /tmp; nothing is written under the repository.
+Compiles the kernel sources with the product's flags plus -Rpass-analysis=kernel-resource-usage and prints one line per kernel.
 """
-
-from __future__ import annotations
-
 import os
 import re
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "raw2film_amd", "csrc")
+sys.path.insert(0, ROOT)
+from raw2film_amd import build as B  # noqa: E402
 
-
-def demangle(names):
-    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout
-    return out.splitlines()
-
-
-def resources(src: str, defines=()):
-    path = src if os.path.isabs(src) else os.path.join(CSRC, src)
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", "-o", f"/tmp/_res_{os.path.basename(src)}.o", path,
-           "-Rpass-analysis=kernel-resource-usage", *defines]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise SystemExit(res.stderr)
-    rows, cur = [], None
-    for line in res.stderr.splitlines():
-        m = re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
-        if not m:
+rows = []
+with tempfile.TemporaryDirectory() as d:
+    for src in B.SOURCES:
+        if not src.endswith(".hip"):
             continue
-        body = m.group(1)
-        if body.startswith("Function Name:"):
-            cur = {"name": body.split(":", 1)[1].strip()}
-            rows.append(cur)
-        elif cur is not None and ":" in body:
-            k, v = body.split(":", 1)
-            cur[k.strip()] = v.strip()
-    names = demangle([r["name"] for r in rows])
-    for r, n in zip(rows, names):
-        n = re.sub(r"\(anonymous namespace\)::", "", n)
-        n = re.sub(r"^void ", "", n)
-        n = re.sub(r"\(r2f::\w+(?: const)?(?:, int)?\)$", "", n)
-        r["short"] = n.replace("r2f::", "")
-    return rows
+        cmd, rc, log = B._compile_one(B._hipcc(), src, os.path.join(d, src + ".o"), ["-Rpass-analysis=kernel-resource-usage"])
+        if rc:
+            raise SystemExit(log)
+        for blk in re.split(r"remark: Function Name: ", log)[1:]:
+            name = blk.split()[0]
 
+            def g(key):
+                m = re.search(re.escape(key) + r": (\d+)", blk)
+                return int(m.group(1)) if m else -1
 
-def main():
-    args = sys.argv[1:]
-    flt, spills_only = None, False
-    if "--filter" in args:
-        i = args.index("--filter")
-        flt = args[i + 1]
-        del args[i:i + 2]
-    if "--spills" in args:
-        spills_only = True
-        args.remove("--spills")
-    src = args[0]
-    rows = resources(src, [a for a in args[1:] if a.startswith("-D")])
-    print(f"{'kernel':70s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'scratch':>8s} {'occ':>4s} {'LDS':>7s}")
-    for r in rows:
-        if flt and flt not in r["short"]:
-            continue
-        scratch = int(r.get("ScratchSize [bytes/lane]", "0"))
-        if spills_only and scratch == 0:
-            continue
-        print(f"{r['short'][:70]:70s} {r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} {r.get('SGPRs', '?'):>5s} {scratch:8d} "
-              f"{r.get('Occupancy [waves/SIMD]', '?'):>4s} {r.get('LDS Size [bytes/block]', '?'):>7s}")
-
-
-if __name__ == "__main__":
-    main()
+            dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+            dem = re.sub(r"\((anonymous namespace)\)::", "", dem)
+            dem = re.sub(r"^void ", "", dem)
+            dem = re.sub(r"\(r2f::.*$", "", dem).replace("r2f::", "")
+            rows.append((src, dem, g("VGPRs"), g("AGPRs"), g("TotalSGPRs"), g("VGPRs Spill"), g("ScratchSize [bytes/lane]"),
+                         g("Occupancy [waves/SIMD]"), g("LDS Size [bytes/block]")))
+print("# hipcc --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py); LDS = static only (the FFT and")
+print("# tile kernels take theirs dynamically); waves/SIMD = the register-limited occupancy the compiler reports")
+print(f"{'file':<16}{'kernel':<58}{'VGPR':>5}{'AGPR':>5}{'SGPR':>5}{'spilled':>8}{'scratch B':>10}{'waves/SIMD':>11}{'LDS':>7}")
+for r in rows:
+    print(f"{r[0]:<16}{r[1][:57]:<58}{r[2]:>5}{r[3]:>5}{r[4]:>5}{r[5]:>8}{r[6]:>10}{r[7]:>11}{r[8]:>7}")
+spilled = [r for r in rows if r[5] > 0 or r[6] > 0]
+print(f"# {len(rows)} kernels; with spilled registers or scratch: {len(spilled)}" + "".join(f"\n#   {r[1]}: {r[5]} VGPRs spilled, {r[6]} B/lane" for r in spilled))
