@@ -22,6 +22,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols (tests/test_lib_symbols.py
+ * compares `nm -D --defined-only` with this header), so two builds of it can live in one process without interposing each other. */
+#if defined(__GNUC__) || defined(__clang__)
+#define R2F_API __attribute__((visibility("default")))
+#else
+#define R2F_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -85,26 +93,26 @@ typedef struct r2f_planes {
 } r2f_planes;
 
 /* --- lifetime: GpuProcessor.__init__ / device + pipeline creation, gpu_processor.py:73-257 --- */
-int r2f_create(int device, r2f_ctx** out);
-void r2f_destroy(r2f_ctx* ctx);
-const char* r2f_last_error(const r2f_ctx* ctx);
+R2F_API int r2f_create(int device, r2f_ctx** out);
+R2F_API void r2f_destroy(r2f_ctx* ctx);
+R2F_API const char* r2f_last_error(const r2f_ctx* ctx);
 /* "gfx950" build id + ABI version, for the loader's sanity check */
-const char* r2f_version(void);
+R2F_API const char* r2f_version(void);
 
 /* --- resource upload: the _ensure_* methods, gpu_processor.py:307-611 --- */
 /* S0 matrix, row-major 3x3 (data.py:128-135 for linear Rec.709 input). */
-int r2f_set_matrix3x3(r2f_ctx* ctx, const float* host_m9);
+R2F_API int r2f_set_matrix3x3(r2f_ctx* ctx, const float* host_m9);
 /* S1 (n, n, 3) input LUT = negative_film.get_input_lut(...)   -- _ensure_lut_2d :349-376 */
-int r2f_set_lut2d(r2f_ctx* ctx, const float* host_lut, int n);
+R2F_API int r2f_set_lut2d(r2f_ctx* ctx, const float* host_lut, int n);
 /* S4 (4, m) density curve: row 0 xp, rows 1..3 fp              -- _ensure_lut_1d :307-347 */
-int r2f_set_curve1d(r2f_ctx* ctx, const float* host_lut4xm, int m);
+R2F_API int r2f_set_curve1d(r2f_ctx* ctx, const float* host_lut4xm, int m);
 /* S8 (n, n, n, 3) output LUT = create_lut(..., linear_scaling=4) -- _ensure_lut_3d :378-409 */
-int r2f_set_lut3d(r2f_ctx* ctx, const float* host_lut, int n);
+R2F_API int r2f_set_lut3d(r2f_ctx* ctx, const float* host_lut, int n);
 /* S6c (4, m) grain LUT indexed by density                      -- _ensure_grain_lut :565-611 */
-int r2f_set_grain_lut(r2f_ctx* ctx, const float* host_lut4xm, int m);
+R2F_API int r2f_set_grain_lut(r2f_ctx* ctx, const float* host_lut4xm, int m);
 /* S2/S5/S6b stencil, (kh, kw, kc) row-major, kc in {1, 3}; correlation, anchor (kh/2, kw/2)
  *   -- _ensure_halation_kernel :498-545, _ensure_mtf_kernel :411-451, _ensure_grain_kernel :453-496 */
-int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int kw, int kc);
+R2F_API int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int kw, int kc);
 
 /* --- whole-frame render: CpuProcessor.process hot loop cpu_processor.py:363-407,
  *     GpuProcessor._execute_gpu_pipeline gpu_processor.py:1756-1877 ---
@@ -132,19 +140,19 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int kh, int 
  * frame block (the seed: the reference re-creates its uniform buffer `buffer_params_grain` per render, gpu_processor.py:585-597) plus one graph
  * launch on `stream`.  Any table / stencil / option change (r2f_generation) drops the graphs.  Results are the eager
  * launches', bit for bit.  r2f_set_option(ctx, "render_graph", 0) turns the replay off (A/B). */
-size_t r2f_workspace_bytes(const r2f_params* p, int H, int W);
-int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32_hwc,
+R2F_API size_t r2f_workspace_bytes(const r2f_params* p, int H, int W);
+R2F_API int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, float* out_f32_hwc,
                uint8_t* out_u8_hwc, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 /* Counters of r2f_render since r2f_create: out[0] frames replayed from a graph, out[1] graphs captured, out[2] frames launched
  * kernel by kernel, out[3] graphs dropped (context changes, evictions, failed captures). */
-int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
+R2F_API int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
 
 /* Introspection for the measurement harness (synchronises the device): what the front kernel of the last whole-frame render
  * recorded about the exposure planes the halation's FFT passes read, and what they made of it.  out4 = {min x, max |x|, bound,
  * floor}; *armed = 1 when that render's halation launches carried the rule (stencil_fft_scratch96_auto, 256-row windows, real
  * spectrum: r2f_render above), *packed = 1 when they then took the 12-byte scratch element (max <= bound x max(min, floor)).
  * Valid until the next write of the frame block (the next render).  Nothing upstream corresponds to it. */
-int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed);
+R2F_API int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed);
 
 /* The per-render uniform write: p->seed -> the context's device-side frame block, asynchronously on `stream`
  * (gpu_processor.py:585-597: the uniform buffer `buffer_params_grain` with a fresh random seed, made ahead of the dispatches;
@@ -154,7 +162,7 @@ int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed)
  * the write for frame B may land before frame A's grain kernels have read the seed, and both would share the scratch.  The
  * reference's processors are entered by one thread at a time for the same reason (mutable caches; gui.py:2119-2129); callers that
  * want frames in flight side by side use one context each (BatchSharder does). */
-int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream);
+R2F_API int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream);
 
 /* --- stage entry points (row-shard aware): one per compute pass of
  *     gpu_processor.py:1763-1862; used by the multi-GPU row tiler and by the parity tests.
@@ -170,7 +178,7 @@ int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream);
 
 /* S0+S1 (+S3+S4 (+S8)) pointwise.  `in` holds global rows [in_gy0, in_gy0+in_rows).
  * upto=EXPOSURE/DENSITY writes planes `dst`; upto=OUTPUT writes out_* (rows indexed from out_gy0). */
-int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
+R2F_API int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
                     int upto, const r2f_planes* dst, float* out_f32_hwc, uint8_t* out_u8_hwc, int out_gy0, int y0,
                     int y1, int W, int H_global, void* stream);
 /* r2f_stage_front(upto = EXPOSURE) for a frame that goes on to r2f_stage_halation, split by what the halation does to each
@@ -180,18 +188,18 @@ int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_la
  * the pointwise pass over it.  *finished_mask receives the channels handled that way (bit c); when it is non-zero call
  * r2f_stage_halation with R2F_F_IDENTITY_DONE.  Whole-frame use only: a row shard's neighbours need the exposure rows of
  * every channel.  Falls back to plain r2f_stage_front (mask 0) when no channel qualifies or the fast kernel does not apply. */
-int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
+R2F_API int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
                           const r2f_planes* exposure, const r2f_planes* density, int y0, int y1, int W, int H_global,
                           int* finished_mask, void* stream);
 /* S2 halation stencil on exposure + S3 log + S4 curve -> density planes. */
-int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,
+R2F_API int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,
                        int y0, int y1, int W, int H_global, void* stream);
 /* S5 MTF stencil on density -> density planes. */
-int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
+R2F_API int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
                   int y0, int y1, int W, int H_global, void* stream);
 /* [S6 grain + clip] + [S7 burn subtract + clip, when burn_map != NULL] + S8 3-D LUT (+ S9 uint8 truncation)
  * -> interleaved output.  With a burn map the grain (if any) must already have been applied by r2f_stage_grain. */
-int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const float* burn_map,
+R2F_API int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const float* burn_map,
                    float* out_f32_hwc, uint8_t* out_u8_hwc, int out_gy0, int y0, int y1, int W, int H_global,
                    void* stream);
 /* The grain in two halves, so that the first can run on another stream while the stencils run: r2f_stage_grain_field writes
@@ -199,44 +207,44 @@ int r2f_stage_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density,
  * coordinates only) for rows [y0, y1) to `field` planes; r2f_stage_tail_field is r2f_stage_tail with that field applied
  * pointwise (out = D + G * lut(D), clip, 3-D LUT) instead of being generated in the same kernel.  Same arithmetic, same
  * results as r2f_stage_tail.  Not combinable with a burn map (use r2f_stage_grain there). */
-int r2f_stage_grain_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* field, int y0, int y1, int W, int H_global,
+R2F_API int r2f_stage_grain_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* field, int y0, int y1, int W, int H_global,
                           void* stream);
-int r2f_stage_tail_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* field, float* out_f32,
+R2F_API int r2f_stage_tail_field(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, const r2f_planes* field, float* out_f32,
                          uint8_t* out_u8, int out_gy0, int y0, int y1, int W, int H_global, void* stream);
 
 /* S6 grain + clip alone, density planes -> density planes (the first half of the tail when S7 is on: the burn map
  * is a function of the WHOLE grained frame, so the frame has to exist before any pixel can be finished). */
-int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
+R2F_API int r2f_stage_grain(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density_in, const r2f_planes* density_out,
                     int y0, int y1, int W, int H_global, void* stream);
 /* S7 part 1: area-weighted (cv.resize INTER_AREA) partial sums of the green density over rows [y0, y1) into
  * cell_sums[(H_global / burn_cell) * (W / burn_cell)] (device).  Row shards add their arrays (all-reduce SUM). */
-int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* cell_sums, int y0, int y1,
+R2F_API int r2f_stage_burn_sums(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density, float* cell_sums, int y0, int y1,
                         int W, int H_global, void* stream);
 /* S7 part 2: clip(x - d_ref, 0) and gaussian_filter(sigma=3, truncate=2) on the low-res map (device -> device).
  * `scratch` holds 2 x the map size. */
-int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums, float* burn_map, float* scratch, int W,
+R2F_API int r2f_stage_burn_map(r2f_ctx* ctx, const r2f_params* p, const float* cell_sums, float* burn_map, float* scratch, int W,
                        int H_global, void* stream);
 /* Pre-path chroma noise reduction, effects.chroma_nr_filter (effects.py:547-561): XYZ -> xyY, a separable
  * (2*size+1)-tap Gaussian on the two chromaticity planes only (coordinates clamped to the frame), back to XYZ.
  * Pass 1 (rows independent): `in` -> planes {x blurred horizontally, y blurred horizontally, Y}.
  * Pass 2 (needs size rows above/below, clamped at the global edges): those planes -> XYZ planes, which
  * r2f_stage_front / r2f_render accept as R2F_LAYOUT_CHW input. */
-int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy0, int in_rows, const r2f_planes* dst,
+R2F_API int r2f_stage_chroma_nr_h(r2f_ctx* ctx, const void* in, int in_layout, int in_gy0, int in_rows, const r2f_planes* dst,
                           int size, int y0, int y1, int W, void* stream);
-int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes* dst, int size, int y0, int y1, int W,
+R2F_API int r2f_stage_chroma_nr_v(r2f_ctx* ctx, const r2f_planes* src, const r2f_planes* dst, int size, int y0, int y1, int W,
                           int H_global, void* stream);
 
 /* Pre-path down-scale to the preview / pipeline resolution: cv.resize(..., interpolation=cv.INTER_AREA) as
  * utils.resolution_scaling applies it when the target is smaller than the frame (utils.py:226-236, called at
  * cpu_processor.py:134).  `in` is a whole H x W frame (any in_layout); `dst` receives out_h x out_w planes. */
-int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
+R2F_API int r2f_resize_area(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
                     void* stream);
 
 /* Pre-path free rotation: cv.warpAffine(rgb, rot_mat, same size, flags=cv.INTER_LINEAR) of effects.rotate (effects.py:46-52;
  * constant border 0), restricted to the window [oy, oy + out_h) x [ox, ox + out_w) that rotate()'s centred crop keeps
  * (effects.py:54-74).  m_dst_to_src: the INVERSE of cv.getRotationMatrix2D(...), 2 x 3 row-major doubles (host memory).
  * `in` is a whole H x W frame (any in_layout); `dst` receives out_h x out_w planes. */
-int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const double* m_dst_to_src, const r2f_planes* dst,
+R2F_API int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const double* m_dst_to_src, const r2f_planes* dst,
                     int out_h, int out_w, int oy, int ox, void* stream);
 
 /* Post-path up-scale of the rendered uint8 frame: utils.resolution_scaling's cv.resize(image, dsize,
@@ -244,27 +252,27 @@ int r2f_warp_affine(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, c
  * requested one (cpu_processor.py:128-134, 411-412).  src/dst: uint8 (H, W, 3) / (out_h, out_w, 3) on the device.
  * r2f_lanczos4_table is the host-side table cv::resize derives per destination index (source index of tap 3, eight weights
  * in 11-bit fixed point); exported so the tests can pin it without a GPU. */
-int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
-int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef);
+R2F_API int r2f_resize_lanczos4_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
+R2F_API int r2f_lanczos4_table(int ssize, int dsize, int* ofs, short* coef);
 
 /* Pre-path up-scale to a preview LARGER than the frame: utils.resolution_scaling's cv.resize(float32 frame, dsize,
  * interpolation=cv.INTER_LANCZOS4) (utils.py:237-242, called at cpu_processor.py:134).  `in`: a whole H x W float32 frame (any
  * in_layout); `dst` receives out_h x out_w planes.  r2f_lanczos4_table_f32: the host-side per-destination tables (source index
  * of tap 3, eight float weights), exported for the tests. */
-int r2f_resize_lanczos4_f32(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
+R2F_API int r2f_resize_lanczos4_f32(r2f_ctx* ctx, const void* in, int in_layout, int H, int W, const r2f_planes* dst, int out_h, int out_w,
                             void* stream);
-int r2f_lanczos4_table_f32(int ssize, int dsize, int* ofs, float* coef);
+R2F_API int r2f_lanczos4_table_f32(int ssize, int dsize, int* ofs, float* coef);
 
 /* Caller-side RGB histogram of the rendered bitmap: the counting loop of utils.generate_histogram (utils.py:160-165; GPU twin
  * histogram.wgsl pass1_accumulate, dispatched at gpu_processor.py:1149).  image_hwc: uint8 (H, W, 3) on the device, 16-byte
  * aligned; counts: 3 x 256 uint32 on the device (R bins, G bins, B bins), overwritten.  The 768-value post-processing
  * (log1p, 3-bin smoothing, bar image) is host work: raw2film_amd/histogram.py. */
-int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint32_t* counts, void* stream);
+R2F_API int r2f_histogram_u8(r2f_ctx* ctx, const uint8_t* image_hwc, int H, int W, uint32_t* counts, void* stream);
 
 /* The CPU processor's last step (cpu_processor.py:411-412 -> utils.resolution_scaling, utils.py:226-236): cv.resize(uint8 frame,
  * INTER_AREA) when the rendered (and canvas-framed) frame is larger than the requested resolution.  src / dst: uint8
  * (H, W, 3) / (out_h, out_w, 3) on the device, out_h <= H, out_w <= W. */
-int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
+R2F_API int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int out_h, int out_w, void* stream);
 
 /* The hand-off from RAW decoding: the last two lines of raw_to_linear (raw_conversion.py:50-52) applied to LibRaw's 16-bit
  * output on the device, so that a decoded frame crosses PCIe as uint16 (6 bytes per pixel) instead of float32 (12 or 16):
@@ -272,7 +280,7 @@ int r2f_resize_area_u8(r2f_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8
  * color_processing.py:71-99 -- computed by the caller, raw2film_amd.decode.auto_exposure).  src: uint16 (H, W, channels) on
  * the device, channels 3 or 4 (a fourth is dropped); dst: float32 (H, W, 3), clamped at 65504 like every frame the GPU path
  * uploads (gpu_processor.py:275).  Bit-identical to the NumPy expressions. */
-int r2f_decode_u16(r2f_ctx* ctx, const uint16_t* src_hwc, int H, int W, int channels, float divisor, float factor, float* dst_f32_hwc3,
+R2F_API int r2f_decode_u16(r2f_ctx* ctx, const uint16_t* src_hwc, int H, int W, int channels, float divisor, float factor, float* dst_f32_hwc3,
                    void* stream);
 
 /* The GPU processor's preview blit, shaders/copy_to_int.wgsl as bound by gpu_processor.py:1416-1539: the display-referred float
@@ -285,22 +293,22 @@ typedef struct r2f_blit {
     float canvas_min_x, canvas_min_y, canvas_max_x, canvas_max_y;
     float canvas_color[3];     /* 0..1 */
 } r2f_blit;
-int r2f_blit_rgba8(r2f_ctx* ctx, const float* src_f32_hwc, int H, int W, uint8_t* dst_rgba, int dst_h, int dst_w, const r2f_blit* t,
+R2F_API int r2f_blit_rgba8(r2f_ctx* ctx, const float* src_f32_hwc, int H, int W, uint8_t* dst_rgba, int dst_h, int dst_w, const r2f_blit* t,
                    void* stream);
 
 /* shaders/histogram.wgsl pass2_process + pass3_render and shaders/scale_texture.wgsl (gpu_processor.py:1245-1285, 1883-1889) on
  * the counts of r2f_histogram_u8: log1p of the normalised counts, 3-bin smoothing, bar heights, the (height, 256, 4) RGBA bar
  * image coloured by mix_table_rgba (HOST, 8 x 4 bytes, index is_r * 4 + is_g * 2 + is_b) and, when target_rgba is given, its
  * nearest-neighbour copy into a (target_h, target_w, 4) widget texture.  counts / image / target are device pointers. */
-int r2f_histogram_render(r2f_ctx* ctx, const uint32_t* counts, const uint8_t* mix_table_rgba, int height, uint8_t* image_rgba,
+R2F_API int r2f_histogram_render(r2f_ctx* ctx, const uint32_t* counts, const uint8_t* mix_table_rgba, int height, uint8_t* image_rgba,
                          uint8_t* target_rgba, int target_h, int target_w, void* stream);
 
 /* Test entry for S6a: raw PCG3D hash (3 uint32 planes) and Gaussian field (3 fp32 planes) for
  * global rows [y0, y1); either output may be NULL.  noise.wgsl:14-62 / noise_bw.wgsl. */
-int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,
+R2F_API int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, float* noise_planes, int y0, int y1,
                     int W, void* stream);
 /* Test entry: plain per-channel stencil (no epilogue) with the kernel set for `which`. */
-int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W,
+R2F_API int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes* dst, int y0, int y1, int W,
                       int H_global, void* stream);
 
 /* Introspection for the measurement harness: what the device form of stencil `which` executes.  out: 3 channels x 8 ints
@@ -311,25 +319,25 @@ int r2f_stage_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_
  * above it = window rows * 4096 + window columns of its last launch (0 before the first); bit 30 = that launch multiplied by a REAL
  * kernel spectrum (taps centrally symmetric around an anchor at the centre of their box: option stencil_fft_real_spectrum).  One entry =
  * 32 packed FMAs per lane for 16 pixels (x2 taps when mirror-paired). */
-int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
+R2F_API int r2f_stencil_stats(r2f_ctx* ctx, int which, int* out);
 
 /* Per-launch device timing of the FFT stencil passes, for the roofline line of bench.py.  After r2f_set_option(ctx,
  * "kernel_timing", mask) every launch of a pass cls whose bit (1 << cls) is set (0 rows forward, 1 columns, 2 rows inverse) is bracketed by events on its own
  * stream; this call waits for them, returns their summed duration, the launch count and the summed algorithmic bytes
  * (scratch images and windows the pass has to move; the 1 MB kernel spectrum stays in L2), and resets the counters.
  * cls = pass (0..2) for launches on complex128 scratch (the halation), pass + 3 for launches on complex64 scratch (the MTF). */
-int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes);
+R2F_API int r2f_kernel_timing(r2f_ctx* ctx, int cls, double* total_ms, int* launches, double* bytes);
 
 /* Measurement aid for bench.py's `roofline.copy_ceiling` ("state the measured hipMemcpyDtoD / stream-triad
  * ceiling beside it"): a float4 streaming copy of `bytes` bytes from src to dst on the device -- 2 x bytes of HBM traffic and no
  * arithmetic.  Nothing upstream corresponds to it; bytes must be a multiple of 16 and both buffers 16-byte aligned. */
-int r2f_stream_copy(r2f_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream);
+R2F_API int r2f_stream_copy(r2f_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream);
 
 /* Change counter of everything a captured HIP graph of this context's launches freezes: bumped by every table / stencil /
  * matrix upload, every option change and every re-allocation of a context-owned buffer (LUTs, stencil forms, FFT scratch and
  * spectra).  The reference re-binds its resources per dispatch (gpu_processor.py:1756-1877) and has nothing to invalidate; a
  * caller that replays captured launches must re-capture when this value moves. */
-uint64_t r2f_generation(const r2f_ctx* ctx);
+R2F_API uint64_t r2f_generation(const r2f_ctx* ctx);
 
 /* Tuning knobs for A/B runs (every one of them bumps r2f_generation).  Round 5's, all defaulting to the faster form:
  *   stencil_fft_real_spectrum  1: centrally symmetric tap boxes (every halation disc / MTF kernel the reference builds) are laid
@@ -341,7 +349,7 @@ uint64_t r2f_generation(const r2f_ctx* ctx);
  *   stencil_fft_mixed_sign     1: channels with taps of both signs take the float64 FFT form whatever their size
  * (older ones: stencil_fft, stencil_fft_window[_rows|_max], stencil_fft_batch, stencil_fft_streams, stencil_fft_scratch32,
  *  stencil_fft_min_taps, stencil_fft_epilogue_lds, render_graph, front_fast, ... -- see r2f_set_option in r2f_api.hip) */
-int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
+R2F_API int r2f_set_option(r2f_ctx* ctx, const char* name, int value);
 
 /* --- plan-only entry points: the host-side planners of this library (raw2film_amd/csrc/r2f_plan.cpp), callable without a GPU and
  * without a context.  Nothing upstream corresponds to them (the reference leaves these decisions to OpenCV and wgpu:
@@ -360,16 +368,16 @@ typedef struct r2f_fft_plan {
  * window shape (the cheapest under the stencil_fft_window / _rows / _max options, 0 = not forced), tiling and batches
  * (batch_mib MiB of scratch in flight on `streams` internal streams).  scratch_elem_bytes: 16, 8 or 12.  R2F_EINVAL when no window
  * shape fits. */
-int r2f_plan_fft(int bh, int bw, int W, int rows, int nch, int scratch_elem_bytes, int window, int window_rows, int window_max,
+R2F_API int r2f_plan_fft(int bh, int bw, int W, int rows, int nch, int scratch_elem_bytes, int window, int window_rows, int window_max,
                  int batch_mib, int streams, r2f_fft_plan* out);
 /* The direct form's device entry list for channel `channel` of a (kh, kw, kc) stencil on a TW x TH tile with Q rows per lane and
  * an LDS budget (0 = one phase): out8 = {entries, row steps, LDS phases, mirrored taps paired, cropped rows, cropped (padded)
  * columns, LDS row stride, rows of the largest phase}.  The list is checked against the taps it was built from (every tap exactly
  * once, offsets inside the phase's LDS rows): R2F_EHIP would mean a planner bug.  R2F_ETOOLARGE: a row step does not fit. */
-int r2f_plan_stencil(const float* host_khwc, int kh, int kw, int kc, int channel, int Q, int TW, int TH, int lds_budget_bytes,
+R2F_API int r2f_plan_stencil(const float* host_khwc, int kh, int kw, int kc, int channel, int Q, int TW, int TH, int lds_budget_bytes,
                      int allow_sym, int* out8);
 /* Tile order of a gx x gy grid of stencil workgroups (a permutation of 0 .. gx gy - 1; band = 0: automatic band width). */
-int r2f_plan_tile_order(int gx, int gy, int band, int* order);
+R2F_API int r2f_plan_tile_order(int gx, int gy, int band, int* order);
 
 #ifdef __cplusplus
 }

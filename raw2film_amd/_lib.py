@@ -170,9 +170,24 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
-def load() -> C.CDLL:
-    """dlopen the in-tree library and bind every symbol of include/r2f.h; raises if absent."""
+def _bind(path: str) -> C.CDLL:
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """dlopen the in-tree library and bind every symbol of include/r2f.h; raises if absent.
+    path: ANOTHER build of the library (a development variant, tools/build_variant.py) bound beside the in-tree one -- the
+    library exports nothing but its C ABI, so two builds in one process do not interpose each other's internals."""
     global _lib
+    if path is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing")
+        return _bind(os.path.abspath(path))
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -180,10 +195,5 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m raw2film_amd.build` (hipcc, gfx950). "
             "raw2film_amd has no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH)
+    return _lib

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
 SOURCES = ["r2f_kernels.hip", "r2f_fft.hip", "r2f_front.hip", "r2f_post.hip", "r2f_api.hip", "r2f_plan.cpp"]
 HEADERS = ["r2f_device.h", "r2f_launch.h", "r2f_fft_math.h", "r2f_plan.h", os.path.join("..", "..", "include", "r2f.h")]
 ARCH = "gfx950"
+EXPORTS_MAP = os.path.join(CSRC, "r2f_exports.map")  # only the r2f_* entry points of include/r2f.h stay dynamic
 
 
 def _hipcc() -> str:
@@ -30,12 +31,15 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [EXPORTS_MAP]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _compile_one(hipcc: str, src: str, obj: str, defines: list[str]) -> tuple[str, int, str]:
-    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", "-o", obj, os.path.join(CSRC, src)] + defines
+    # -fvisibility=hidden: the library's dynamic symbols are the R2F_API entry points of include/r2f.h and nothing else (no r2f::
+    # launchers, planners or kernel stubs for a second copy of the library in the same process to interpose)
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function",
+           "-c", "-o", obj, os.path.join(CSRC, src)] + defines
     if src.endswith(".hip"):  # (r2f_plan.cpp is host-only C++: no device pass)
         cmd.insert(3, f"--offload-arch={ARCH}")
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -64,7 +68,7 @@ def build(force: bool = False, verbose: bool = False, defines: list[str] | None 
             print(cmd, flush=True)
         if rc != 0:
             raise RuntimeError(f"hipcc failed ({rc}): {cmd}\n{log}")
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target + ".tmp"] + objs
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS_MAP}", "-o", target + ".tmp"] + objs
     if verbose:
         print(" ".join(link), flush=True)
     res = subprocess.run(link, capture_output=True, text=True)

@@ -26,11 +26,13 @@ def _host_f32(a) -> np.ndarray:
 
 
 class HipContext:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, lib_path: str | None = None):
         import torch
 
         self._torch = torch
-        self._lib = _lib.load()  # raises ImportError if the HIP library is missing -- no fallback
+        # raises ImportError if the HIP library is missing -- no fallback.  lib_path: a development variant of the library bound
+        # beside the in-tree one (A/B of two builds in one process)
+        self._lib = _lib.load(lib_path)
         if not torch.cuda.is_available():
             raise R2FError("raw2film_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.device = torch.device("cuda", device)

@@ -49,11 +49,13 @@ class PendingFrame:
 class HipProcessor:
     """Drop-in for the hot path of CpuProcessor / GpuProcessor (gui.py:1584-1585)."""
 
-    def __init__(self, cameras=None, lenses=None, device: int = 0, payload_alpha: bool = True, result_buffers: int = 0):
+    def __init__(self, cameras=None, lenses=None, device: int = 0, payload_alpha: bool = True, result_buffers: int = 0,
+                 lib_path: str | None = None):
         """payload_alpha: extract_image_data_cpu appends the constant alpha plane like upstream (gpu_processor.py:765: its wgpu
         texture is rgba32float).  Nothing on this backend reads it -- the device path takes 3- and 4-channel frames alike -- and
         batch export is bound by the upload of the payload: with payload_alpha=False the frame crosses PCIe a quarter smaller.
-        result_buffers: see _download (pinned result buffers for interactive use)."""
+        result_buffers: see _download (pinned result buffers for interactive use).
+        lib_path: another build of libr2f_hip.so for this processor's context (development A/B; default: the in-tree library)."""
         import torch
 
         self._torch = torch
@@ -61,7 +63,7 @@ class HipProcessor:
         self.lenses = lenses
         self.payload_alpha = bool(payload_alpha)
         self.result_buffers = int(result_buffers)  # 0: process() returns a fresh array; n: views of n pinned buffers in turn (_download)
-        self.ctx = HipContext(device)
+        self.ctx = HipContext(device, lib_path=lib_path)
         self.device = self.ctx.device  # NB: a torch device, not a wgpu device (gui.py:1652 uses bitmap mode)
         # comparison dicts, same role as cpu_processor.py:41-45 / gpu_processor.py
         self.input_param_dict = None

@@ -28,6 +28,22 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.r2f_version()
 
 
+def test_dynamic_symbol_table_is_exactly_the_c_abi():
+    """Built with -fvisibility=hidden and csrc/r2f_exports.map: `nm -D --defined-only` lists the entry points of include/r2f.h
+    and nothing else -- no r2f:: launchers, planners or kernel stubs for a second copy of the library to interpose."""
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm")
+    if nm is None:
+        import pytest
+
+        pytest.skip("no nm")
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_functions()
+
+
 def test_struct_layouts_match_the_header():
     # r2f_params: 2 x u32, 2 x f32, 2 x i32, 2 x f32 ; r2f_planes: ptr, i64, 2 x i32
     assert ctypes.sizeof(_lib.Params) == 32

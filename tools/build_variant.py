@@ -52,7 +52,7 @@ def main():
         compile_all(d, sources, defines)
         objs = [obj_of(d if s in sources else BASE, s) for s in B.SOURCES]
         out = os.path.join(OUT, f"lib_{name}.so")
-        subprocess.run([B._hipcc(), f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", out] + objs, check=True)
+        subprocess.run([B._hipcc(), f"--offload-arch={B.ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={B.EXPORTS_MAP}", "-o", out] + objs, check=True)
         print(out, flush=True)
 
 
