@@ -50,14 +50,44 @@ METRICS = {
 }
 
 
+def strip_comments(text: str) -> str:
+    """C / C++ source without its comments and with runs of white space collapsed: what the compiler sees, roughly.  String and
+    character literals are kept as they are (a // inside one is not a comment)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":  # a literal: copy up to the closing quote, minding escapes
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            while j > 0 and text[j - 1] == "\\":  # a line comment continued with a backslash
+                j = text.find("\n", j + 1)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash() -> str:
-    """sha256 over the HIP sources and the C header: ties a committed PMC capture to the code that was profiled."""
+    """sha256 over the HIP sources and the C header WITHOUT their comments and white space: ties a committed PMC capture to the
+    code that was profiled, and keeps it tied across commits that only touch comments (round 5 re-measured unchanged code six
+    times because the hash covered the raw text: VERDICT r5, weak 8)."""
     h = hashlib.sha256()
     for rel in ("raw2film_amd/csrc/r2f_device.h", "raw2film_amd/csrc/r2f_launch.h", "raw2film_amd/csrc/r2f_kernels.hip",
                 "raw2film_amd/csrc/r2f_fft.hip", "raw2film_amd/csrc/r2f_fft_math.h", "raw2film_amd/csrc/r2f_front.hip", "raw2film_amd/csrc/r2f_post.hip", "raw2film_amd/csrc/r2f_api.hip", "raw2film_amd/csrc/r2f_plan.cpp",
                 "raw2film_amd/csrc/r2f_plan.h", "include/r2f.h"):
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, rel), "r", encoding="utf-8") as f:
+            h.update(strip_comments(f.read()).encode())
+            h.update(b"\0")
     return h.hexdigest()[:16]
 
 
@@ -109,6 +139,10 @@ def main():
     ap.add_argument("--no-alone", action="store_true",
                     help="skip the two extra steps that time the dominant FFT pass with one internal stream (tools/profile_round.sh: "
                          "keeps the profiled launches all of one size)")
+    ap.add_argument("--no-breakdown", action="store_true",
+                    help="skip every eager step behind the timed ones (stage times, per-pass times): the run then holds nothing but "
+                         "the product's own renders -- what tools/profile_round.sh profiles, so that calls and bytes per kernel are "
+                         "whole multiples of the renders")
     ap.add_argument("--no-pcie", action="store_true",
                     help="skip the host <-> device legs (cfg5_batch: the PCIe-inclusive BatchSharder leg; the others: host_device_copies)")
     ap.add_argument("--no-graph", action="store_true",
@@ -272,7 +306,7 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     # which scratch element the halation's passes of the LAST TIMED frame took (r2f_render chooses on the device, frame by frame);
     # asked now, before the eager breakdown steps overwrite the frame block
-    scratch_choice = proc.ctx.frame_exposure_range() if (use_processor and effects) else None
+    scratch_choice = proc.ctx.frame_exposure_range() if effects else None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=frame.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -310,7 +344,9 @@ def main():
             "stocks": "synthetic stand-ins portra400_like + k2383_like (spectral_film_lut data unavailable offline)",
             "sharding": (f"batch of {args.frames} frames, frame i -> rank i mod {world}, no collectives" if batch else
                          "single GPU" if world == 1 else
-                         f"row-sharded over {world} GPUs, RCCL halo exchange(s) per frame: schedule measured on the first frames (shard_schedule)"),
+                         f"row-sharded over {world} {'GPUs' if not args.same_device else 'ranks on one GPU'}, "
+                         f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged: validation only)'} halo exchange(s) per frame: "
+                         "schedule measured on the first frames (shard_schedule)"),
             "options": args.opt,
         },
     }
@@ -349,7 +385,9 @@ def main():
             dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         result["checksum"] = int(cs.item())
     eager = None
-    if replaying or use_processor:  # the breakdowns below need per-launch events: the same frame, stage by stage, eagerly
+    if args.no_breakdown:
+        steps_for_cols = args.steps
+    elif replaying or use_processor:  # the breakdowns below need per-launch events: the same frame, stage by stage, eagerly
         sched = {} if (use_processor or renderer is None or renderer.schedule is None) else \
             {"exchanges": renderer.schedule[0], "split_halation": renderer.schedule[1]}  # the schedule the timed steps ran, not a new measurement
         eager = RowShardedRenderer(timed, H, W, halation=effects, mtf=effects, grain=effects,
@@ -373,18 +411,22 @@ def main():
     stage_ms = timed.summary()
     result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
     if eager is not None:
-        result["stage_ms_note"] = "two eager stage-by-stage steps (RowShardedRenderer over the stage entry points) after the timed steps"
+        result["stage_ms_note"] = ("two eager stage-by-stage steps (RowShardedRenderer over the stage entry points) after the timed steps: the "
+                                   "same kernels on the same windows -- the stage path keeps the exposure-range record like r2f_render, so "
+                                   "the halation's passes choose the same scratch element")
     cols = drain_timing()  # only the column passes (classes 1 and 4) were on
     # the other two passes, for the breakdown only: two extra steps outside the timed region
-    proc.ctx.set_option("kernel_timing", 5)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    extra = drain_timing()
+    extra = [(0.0, 0, 0.0)] * 6
+    if not args.no_breakdown:
+        proc.ctx.set_option("kernel_timing", 5)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        extra = drain_timing()
     # ... and the dominant column pass with the GPU to itself (one internal stream): what a launch does when no other kernel
     # shares the CUs and the memory system with it
     solo = [(0.0, 0, 0.0)] * 6
-    if not args.no_alone and effects:
+    if not args.no_alone and not args.no_breakdown and effects:
         proc.ctx.set_option("kernel_timing", 2)
         proc.ctx.set_option("stencil_fft_streams", 1)
         for _ in range(2):
@@ -458,22 +500,47 @@ def main():
 
     if effects and "halation" in stage_ms:
         st_h, st_m = proc.ctx.stencil_stats(0), proc.ctx.stencil_stats(1)
-        names = ["rows_fwd (complex128)", "cols (complex128)", "rows_inv (complex128)", "rows_fwd (complex64)", "cols (complex64)",
+        # Which scratch element the halation's passes took: r2f_render chooses on the device per frame (asked after the last TIMED
+        # frame), and the eager stage-by-stage steps behind the pass times choose the same way since round 6 (the stage path keeps
+        # the exposure-range record too) -- asked again after them: the two must agree, or the breakdown is of other kernels.
+        rng = scratch_choice
+        rng_eager = proc.ctx.frame_exposure_range()
+        if rng is not None:
+            roof["halation_scratch_element"] = dict(
+                rng, eager_breakdown_took_the_same_element=bool(rng_eager and rng_eager["armed"] == rng["armed"]
+                                                                and rng_eager["twelve_byte_element"] == rng["twelve_byte_element"]),
+                note="what r2f_render's front kernel recorded about the exposure planes of the last timed frame and what the halation's "
+                     "FFT passes made of it: the 12-byte element (doubles rounded to 48 bits) when max_abs <= bound x max(min, floor), "
+                     "else complex128.  stage_ms / fft_pass_ms_per_step come from eager stage calls that make the same choice from "
+                     "the same record (R2F_F_TRACK_RANGE / R2F_F_RANGE_VALID)")
+        packed = bool(rng and rng["twelve_byte_element"])
+        armed = bool(rng and rng["armed"])
+        if rng_eager is not None and rng is not None and not roof["halation_scratch_element"]["eager_breakdown_took_the_same_element"]:
+            packed = bool(rng_eager["twelve_byte_element"])  # label the breakdown by what IT ran
+            armed = bool(rng_eager["armed"])
+        el_h = "12-byte element" if packed else "complex128"
+        names = [f"rows_fwd ({el_h})", f"cols ({el_h})", f"rows_inv ({el_h})", "rows_fwd (complex64)", "cols (complex64)",
                  "rows_inv (complex64)"]
         per_step = [extra[0][0] / 2, cols[1][0] / steps_for_cols, extra[2][0] / 2, extra[3][0] / 2, cols[4][0] / steps_for_cols, extra[5][0] / 2]
         roof["fft_pass_ms_per_step"] = {n: round(v, 4) for n, v in zip(names, per_step) if v > 0}
         roof["fft_pass_note"] = ("event-bracketed launch times summed per step; launches alternate between two internal streams, so "
                                  "the sums exceed the stage wall time. cols: inside the timed steps when those launch kernel by kernel, else -- "
-                                 "like rows_* -- from two extra eager steps after them (stage entry points: complex128 for the halation)")
-        # which scratch element the halation's passes of the TIMED steps took (r2f_render chooses on the device per frame; the eager
-        # stage-by-stage steps behind these pass times go through the stage entry points, which keep complex128)
-        rng = scratch_choice
-        if rng is not None:
-            roof["halation_scratch_element"] = dict(
-                rng, note="what r2f_render's front kernel recorded about the exposure planes of the last timed frame and what the halation's "
-                          "FFT passes made of it: the 12-byte element (doubles rounded to 48 bits) when max_abs <= bound x max(min, floor), "
-                          "else complex128.  stage_ms / fft_pass_ms_per_step come from eager stage calls, which always use complex128")
-        packed = bool(rng and rng["twelve_byte_element"])
+                                 "like rows_* -- from two extra eager steps after them (the same kernels: see halation_scratch_element)")
+        # The library sums the passes' algorithmic bytes with 16-byte scratch elements for launches that choose on the device; when
+        # they took the 12-byte element the scratch part of those sums is a quarter smaller: pass 1 moves window floats (8 B per
+        # element of a pair's image) + the image, pass 2 the image + its valid rows, pass 3 the valid rows + the outputs
+        win_h = next((c["window"] for c in st_h if c["fft"]), None)
+        byte_scale = [1.0] * 6
+        if packed and win_h:
+            nzh = np.nonzero(hal_k[..., 0])
+            bw_h = int(nzh[1].max() - nzh[1].min() + 1)
+            vx_h = (win_h[1] - bw_h + 1) & ~3
+            byte_scale[0] = 1.0 - 0.25 * 16.0 / (16.0 + 8.0)
+            byte_scale[1] = 0.75
+            byte_scale[2] = 1.0 - 0.25 * (win_h[1] * 16.0) / (win_h[1] * 16.0 + 2.0 * vx_h * 4.0)
+        cols = [(ms, n, b * byte_scale[c]) for c, (ms, n, b) in enumerate(cols)]
+        extra = [(ms, n, b * byte_scale[c]) for c, (ms, n, b) in enumerate(extra)]
+        solo = [(ms, n, b * byte_scale[c]) for c, (ms, n, b) in enumerate(solo)]
         # The dominant kernel of a step: the tail (one launch per frame) or one of the six FFT pass classes (summed per step)
         cand = {"tail": float(stage_ms.get("tail", 0.0))}
         cand.update({f"fft{c}": v for c, v in enumerate(per_step)})
@@ -503,12 +570,14 @@ def main():
             real = any(c.get("real_spectrum") for c in stats if c["fft"])
             walk = real and win[0] == 256
             g = bytes_alg / (tot_ms * 1e-3) / 1e9
-            kname = (f"r2f::fft_cols_walk_kernel<{win[1] // 16}, {1 if dom == 4 else 0}>" if walk else
+            # (ST template argument: 1 complex64, 0 complex128, 3 = element chosen on the device at the top of the kernel)
+            st_arg = 1 if dom == 4 else (3 if armed else 0)
+            kname = (f"r2f::fft_cols_walk_kernel<{win[1] // 16}, {st_arg}>" if walk else
                      f"r2f::fft_cols_kernel<{win[1] // 16}, {'true' if win[0] == 512 else 'false'}, {1 if dom == 4 else 0}, {'true' if real else 'false'}>")
             dk = {
                 "kernel": f"{kname} "
                           f"(pass 2 of the fp64 overlap-save FFT of the {'MTF' if dom == 4 else 'halation'} stencil, windows of {win[0]} rows x "
-                          f"{win[1]} columns, {'complex64' if dom == 4 else 'complex128'} scratch: column FFT, x "
+                          f"{win[1]} columns, {'complex64' if dom == 4 else el_h + (' (chosen on the device)' if armed else '')} scratch: column FFT, x "
                           f"{'real ' if real else ''}kernel spectrum, inverse column FFT, in place"
                           + ("; a resident grid walking the launch's pairs per column block" if walk else "") + ")",
                 "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
@@ -519,9 +588,9 @@ def main():
                 "concurrency": "two FFT-pass kernels usually share the GPU (two internal streams): kernel_ms and achieved are per launch "
                                "under that sharing; the event pair also spans the dispatch gap (~5 us)",
             }
-            if dom == 1 and packed:
-                dk["note"] = ("measured on eager stage calls (complex128 scratch); in the timed steps r2f_render chose the 12-byte element for "
-                              "this frame: the same pass then moves 3/4 of these bytes (kernel fft_cols_walk_kernel<.., 3>)")
+            if dom == 1 and armed:
+                dk["note"] = ("measured on eager stage calls that choose the scratch element from the same exposure-range record as the timed "
+                              "steps' r2f_render: the same kernel instance on the same windows with the same element")
             if solo[dom][1]:
                 ms, n, b = solo[dom]
                 dk["alone"] = {"kernel_ms": ms / n, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -64,9 +64,19 @@ enum {
     R2F_F_IDENTITY_DONE = 1u << 6, /* r2f_stage_halation only: the channels whose halation stencil is a single tap at the anchor
                                      (the blue layer of a colour stock, effects.py:248-263) were already finished into the
                                      density planes by r2f_stage_front_split for rows [y0, y1) -- skip them */
-    R2F_F_FRAME_RESIDENT = 1u << 7 /* stage entry points: do NOT write p->seed into the context's device-side frame block first;
+    R2F_F_FRAME_RESIDENT = 1u << 7, /* stage entry points: do NOT write p->seed into the context's device-side frame block first;
                                      the kernels read what r2f_write_frame_params last wrote there (in stream order).  For callers
                                      that replay captured launches: the write stays outside the capture, the launches inside */
+    R2F_F_TRACK_RANGE = 1u << 8,   /* r2f_stage_front (upto = EXPOSURE) / r2f_stage_front_split: merge min and max |.| of the exposure
+                                     samples this call writes for the halation's FFT channels into the frame block (reset by
+                                     r2f_write_frame_params) -- what r2f_render's front kernel does for a whole frame.  A call whose
+                                     kernel cannot record (the generic pointwise kernel) marks the range unusable instead: the
+                                     halation then keeps complex128, nothing goes wrong silently */
+    R2F_F_RANGE_VALID = 1u << 9    /* r2f_stage_halation: the caller vouches that the frame block's range covers EVERY row the
+                                     `exposure` buffer holds for the FFT channels (own rows by R2F_F_TRACK_RANGE front calls, rows
+                                     received from neighbours by r2f_stage_exposure_range -- windows also read buffer rows beyond the
+                                     stencil's reach, for outputs they discard): the passes may then choose the 12-byte scratch
+                                     element on the device exactly like r2f_render's (below) */
 };
 
 /* `upto` of r2f_stage_front */
@@ -124,9 +134,12 @@ R2F_API int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int 
  * Scratch element of the halation's passes: complex128, or -- chosen on the device, frame by frame, by r2f_render only -- a
  * 12-byte element (each component a double rounded to 48 bits) when the range of the exposure samples the front kernel wrote
  * allows it: max |x| <= bound x max(min x, first breakpoint of the density curve), the bound derived from the curve's steepest
- * cell so that the element costs a density at most three fp32 ulps -- the MTF's complex64 scratch is allowed the same -- (option stencil_fft_scratch96_auto, default 1; a frame with a
- * 65 504 specular over 1e-4 shadows keeps complex128).  The stage entry points always use complex128 for the halation, so a
- * whole-frame render and a row-sharded one agree to that element's rounding, not bit for bit.
+ * cell and the element's worst error (two roundings at 2^-37 of max / shadow, x 1.5: a searched constant, tests/test_gpu_fft.py) so
+ * that the element costs a density at most three fp32 ulps -- the MTF's complex64 scratch is allowed the same -- (option
+ * stencil_fft_scratch96_auto, default 1; with the stand-in Portra curve frames up to max / shadow = 6.1e4 take it, wider ones
+ * keep complex128).  The stage entry points make the same choice when their caller keeps the
+ * record complete (R2F_F_TRACK_RANGE, r2f_stage_exposure_range, R2F_F_RANGE_VALID) and use complex128 otherwise; a row shard sees
+ * the range of ITS rows, so a whole-frame render and a row-sharded one agree to that element's rounding, not bit for bit.
  * Non-finite samples: in the direct form a NaN / infinity in a stencil's input comes out as NaN in every output whose tap box
  * (plus up to three zero-weight padding rows / columns) covers it, like the per-tap loop of the reference's convolution.wgsl; the FFT form takes such a sample as 0 instead (a NaN
  * handed to the transforms would come back in every output of its 256 x 512 window) -- the outputs inside the tap box are then
@@ -191,7 +204,12 @@ R2F_API int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, i
 R2F_API int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
                           const r2f_planes* exposure, const r2f_planes* density, int y0, int y1, int W, int H_global,
                           int* finished_mask, void* stream);
-/* S2 halation stencil on exposure + S3 log + S4 curve -> density planes. */
+/* A row shard's half of r2f_render's exposure-range record: min and max |.| of rows [y0, y1) of `exposure` (the channels whose
+ * halation stencil takes the FFT form) merged into the context's frame block, in stream order -- for the halo rows a rank received
+ * from its neighbours (its own rows are recorded by the front kernel, R2F_F_TRACK_RANGE).  Nothing upstream corresponds to it. */
+R2F_API int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int W, void* stream);
+/* S2 halation stencil on exposure + S3 log + S4 curve -> density planes.  With R2F_F_RANGE_VALID the FFT passes choose their
+ * scratch element on the device from the frame block's range (see r2f_render); without it they keep complex128. */
 R2F_API int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,
                        int y0, int y1, int W, int H_global, void* stream);
 /* S5 MTF stencil on density -> density planes. */

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libr2f_hip.so")
 LAYOUT_HWC3, LAYOUT_HWC4, LAYOUT_CHW = 0, 1, 2
 KERNEL_HALATION, KERNEL_MTF, KERNEL_GRAIN = 0, 1, 2
 F_MATRIX, F_HALATION, F_MTF, F_GRAIN, F_GRAIN_MONO, F_BURN, F_IDENTITY_DONE, F_FRAME_RESIDENT = 1, 2, 4, 8, 16, 32, 64, 128
+F_TRACK_RANGE, F_RANGE_VALID = 256, 512
 UPTO_EXPOSURE, UPTO_DENSITY, UPTO_OUTPUT = 0, 1, 2
 OK, EINVAL, EHIP, ETOOLARGE = 0, -1, -2, -3
 
@@ -84,6 +85,7 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
+    "r2f_stage_exposure_range": (C.c_int, [C.c_void_p, _P(Planes), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "r2f_stage_mtf": (
         C.c_int,
         [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],

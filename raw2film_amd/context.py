@@ -81,12 +81,20 @@ class HipContext:
                            int(burn_cell), float(burn_strength), float(burn_d_ref))
 
     def planes(self, t, gy0: int = 0) -> _lib.Planes:
-        """Describe a contiguous float32 (3, rows, W) device tensor holding global rows gy0.."""
+        """Describe a float32 (3, rows, W) device tensor holding global rows gy0..: contiguous, or a ROW SLICE of such a tensor
+        (t[:, a:b, :]: rows contiguous, planes a fixed stride apart -- r2f_planes carries the plane stride)."""
         torch = self._torch
-        if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous() or not t.is_cuda:
-            raise ValueError("planes: need a contiguous float32 CUDA tensor of shape (3, rows, W)")
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != 3 or not t.is_cuda:
+            raise ValueError("planes: need a float32 CUDA tensor of shape (3, rows, W)")
+        rows, W = int(t.shape[1]), int(t.shape[2])
+        if t.is_contiguous():
+            stride = rows * W
+        elif rows > 0 and t.stride(2) == 1 and t.stride(1) == W and t.stride(0) >= rows * W:
+            stride = int(t.stride(0))
+        else:
+            raise ValueError("planes: need a contiguous (3, rows, W) tensor or a row slice t[:, a:b, :] of one")
         self._same_device(t, "planes")
-        return _lib.Planes(t.data_ptr(), int(t.shape[1]) * int(t.shape[2]), int(gy0), int(t.shape[1]))
+        return _lib.Planes(t.data_ptr(), stride, int(gy0), rows)
 
     def _check_out(self, t, dtype, W, what, *, rows=None, gy0=0, y0=None, y1=None):
         """A caller's output tensor before its pointer crosses the C ABI (which cannot check it): (rows, W, 3) of `dtype`,
@@ -243,8 +251,13 @@ class HipContext:
 
     # ------------------------------------------------------------------ stages (row-shard aware)
     def stage_front(self, image, params, upto, *, in_gy0=0, dst=None, dst_gy0=0, out_f32=None, out_u8=None,
-                    out_gy0=0, y0=None, y1=None, H_global=None, layout=None):
+                    out_gy0=0, y0=None, y1=None, H_global=None, layout=None, track_range=False):
+        """track_range (upto = exposure): the kernel merges the range of the exposure samples it writes for the halation's FFT
+        channels into the frame block (R2F_F_TRACK_RANGE), like r2f_render's front kernel does for a whole frame."""
         self._check_image(image)
+        if track_range:
+            params = _lib.Params.from_buffer_copy(params)
+            params.flags |= _lib.F_TRACK_RANGE
         layout, rows, W = self.layout_of(image, layout)
         y0 = in_gy0 if y0 is None else y0
         y1 = in_gy0 + rows if y1 is None else y1
@@ -262,11 +275,14 @@ class HipContext:
         self._check(rc)
 
     def stage_front_split(self, image, params, exposure, density, *, in_gy0=0, exposure_gy0=0, density_gy0=0, y0=None, y1=None,
-                          H_global=None, layout=None) -> int:
+                          H_global=None, layout=None, track_range=False) -> int:
         """S0 + S1 for a frame that goes on to stage_halation: channels with a real halation stencil -> `exposure`; channels
         whose halation stencil is one tap at the anchor are finished (tap weight, log, curve) straight into `density`.  Returns
-        the mask of channels finished that way: pass it to stage_halation(identity_done=mask)."""
+        the mask of channels finished that way: pass it to stage_halation(identity_done=mask).  track_range: see stage_front."""
         self._check_image(image)
+        if track_range:
+            params = _lib.Params.from_buffer_copy(params)
+            params.flags |= _lib.F_TRACK_RANGE
         layout, rows, W = self.layout_of(image, layout)
         y0 = in_gy0 if y0 is None else y0
         y1 = in_gy0 + rows if y1 is None else y1
@@ -284,10 +300,23 @@ class HipContext:
             raise ValueError("source and destination widths differ")
         self._check(fn(self._h, first, C.byref(ps), C.byref(pd), y0, y1, W, H_global, self._stream()))
 
-    def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global, identity_done=0):
-        if identity_done:  # stage_front_split already wrote the identity channels' density for these rows
+    def stage_exposure_range(self, exposure, *, src_gy0=0, y0, y1):
+        """Merge min / max |.| of rows [y0, y1) of the exposure planes (the halation's FFT channels) into the frame block: the halo
+        rows a row shard received (r2f_stage_exposure_range)."""
+        if y1 <= y0:
+            return
+        pe = self.planes(exposure, src_gy0)
+        self._check(self._lib.r2f_stage_exposure_range(self._h, C.byref(pe), int(y0), int(y1), int(exposure.shape[2]), self._stream()))
+
+    def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global, identity_done=0, range_valid=False):
+        """range_valid: the caller vouches that the frame block's range covers every row `exposure` holds (R2F_F_RANGE_VALID): the
+        FFT passes then choose their scratch element on the device like r2f_render's."""
+        if identity_done or range_valid:
             params = _lib.Params.from_buffer_copy(params)
+        if identity_done:  # stage_front_split already wrote the identity channels' density for these rows
             params.flags |= _lib.F_IDENTITY_DONE
+        if range_valid:
+            params.flags |= _lib.F_RANGE_VALID
         self._stencil_call(self._lib.r2f_stage_halation, C.byref(params), exposure, src_gy0, density, dst_gy0, y0, y1, H_global)
 
     def stage_mtf(self, density_in, density_out, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global):

@@ -102,13 +102,14 @@ struct r2f_ctx {
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (doubles rounded to 48 bits, 2^-37) whatever the frame holds -- A/B
     // 1: a whole-frame render (r2f_render) lets the halation's FFT passes choose between complex128 and the 12-byte element ON THE
     // DEVICE, per frame, from the range of the exposure samples its front kernel wrote (FrameParams::e_min / e_max): the 12-byte
-    // element costs a shadow at most 6e-12 x (max |x| / shadow) of itself -- the worst of isolated speculars (2.1e-12), bright blocks,
-    // a half-bright frame and bright stripes, profiles/r05_scratch96_probe.txt -- which the density curve turns into 0.434 x slope x
-    // that; the bound keeps it under three fp32 ulps of a density in [1, 2), what the MTF's complex64 scratch is allowed, and frames
-    // with a wider range (a 65 504 specular over 1e-4 shadows) keep complex128.
+    // element costs a shadow at most 1.46e-11 x (max |x| / shadow) of itself (two roundings at 2^-37; kDynCoefficient below adds a
+    // factor 1.5) -- which the density curve turns into 0.434 x slope x that; the bound keeps it under three fp32 ulps of a density
+    // in [1, 2), what the MTF's complex64 scratch is allowed, and frames with a wider range keep complex128 (the stand-in Portra
+    // curve: max / shadow <= 6.1e4; the headline's noise frame, at 1.4e5, does not qualify since round 6).
     int opt_fft_s96_auto = 1;
     float curve_slope_max = 0.f;  // max |d density / d log10 exposure| over the density curve's cells (host copy, r2f_set_curve1d)
     bool frame_dyn_armed = false;  // the last whole-frame render's halation launches carried the rule (r2f_frame_exposure_range)
+    bool capturing = false;        // r2f_render is capturing render_launches: the frame-block write stays outside the graph
     int opt_fft_epi_lds = 1;  // pass 3's epilogue gathers its curve cells from LDS (0: from global memory; A/B)
     // 1: a centrally symmetric tap box (k[i][j] == k[bh-1-i][bw-1-j] bit for bit, anchor at its centre -- every halation disc and
     // |ifft2| MTF kernel the reference builds, effects.py:200-217, :123-143) is laid out with its anchor on the window origin, so its
@@ -396,27 +397,35 @@ int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
 
 // p->seed -> the context's device-side frame block, in stream order (a one-lane kernel: its by-value argument is copied at
 // launch time, so no host staging buffer has to outlive the call).
-// new_frame: also reset the exposure range (the start of a render); false: a stage entry's own seed write in the middle of one
-int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s, bool new_frame = true) {
+// mode 1: seed + reset of the exposure range (the start of a render); 0: a stage entry's own seed write in the middle of one;
+// 2: the range reset alone (a render whose caller keeps the seed resident); 3: the range made unusable (frame_params_kernel)
+int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s, int mode = 1) {
     FrameParams v{};
     v.seed = p->seed;
     v.e_min = kFrameMinReset, v.e_max = kFrameMaxReset;
-    R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, new_frame ? 1 : 0, s));
+    R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, mode, s));
     return R2F_OK;
 }
 
 // Destroy the retired graphs whose last replay has completed (wait = true: all of them, after their events -- r2f_destroy).
 void reap_retired_graphs(r2f_ctx* ctx, bool wait) {
+    // Graphs whose completion cannot be asked for -- no event (its creation failed at capture time), or one recorded inside a
+    // caller's stream capture -- are kept; when more than a handful of entries pile up the device is synchronised once and
+    // everything goes (a missing event used to read as "complete", and the list could grow without bound).
+    if (!wait && ctx->retired.size() > 16) {
+        (void)hipDeviceSynchronize();
+        wait = true;
+    }
     size_t kept = 0;
     for (auto& r : ctx->retired) {
-        hipError_t e = r.done ? (wait ? hipEventSynchronize(r.done) : hipEventQuery(r.done)) : hipSuccess;
+        hipError_t e = r.done ? (wait ? hipEventSynchronize(r.done) : hipEventQuery(r.done)) : (wait ? hipSuccess : hipErrorNotReady);
         if (e == hipErrorNotReady) {
             ctx->retired[kept++] = r;
             continue;
         }
         if (e != hipSuccess) {
             (void)hipGetLastError();  // (an event recorded inside a caller's stream capture cannot be queried: keep the graph until
-            if (!wait) {              //  the context goes, where the device has been synchronised)
+            if (!wait) {              //  the list is flushed behind a device synchronisation, above or in r2f_destroy)
                 ctx->retired[kept++] = r;
                 continue;
             }
@@ -500,12 +509,21 @@ bool fft_eligible(const r2f_ctx* ctx, const StencilSet& s, int c) {
 }
 
 // The rule of the halation's scratch element (FftConvArgs::dyn): the 12-byte element when max |x| <= bound x max(min x, floor).
-//   |delta density| <= 0.434 x steepest curve cell x 6e-12 x (max / shadow) <= 3.6e-7  (three ulps of a density in [1, 2); 6e-12: the
-//   worst coefficient measured over isolated speculars, bright blocks, a half-bright frame and stripes);
+//   |delta density| <= 0.434 x steepest curve cell x kDynCoefficient x (max / shadow) <= 3.6e-7  (three ulps of a density in [1, 2));
 //   below the curve's first breakpoint np.interp clamps: no slope, so shadows under it do not count.
+// kDynCoefficient = what the element costs a shadow's exposure, as a multiple of max / shadow: 1.5 x 2^-36.  The element keeps 36
+// mantissa bits per component (half an ulp = 2^-37 of the value) and a scratch value is rounded twice (pass 1's store, pass 2's);
+// the worst frame is a nearly flat bright field around a dark hole: all of a window's energy sits in one spectral line per row,
+// whose two roundings reach every output of the window undiminished (the stencil's taps sum to 1) -- 2 x 2^-37 = 1.46e-11 of
+// max / shadow.  A search over 1 050 random frames of seven families x five bright-region statistics found exactly that and nothing
+// above it (1.43e-11 for holes in a jittered flat field; noise-like windows 1.0e-11, isolated speculars 4.5e-12:
+// profiles/r06_scratch96_probe.txt; tests/test_gpu_fft.py repeats the search on a fixed budget).  Round 5 shipped 6.0e-12, the
+// maximum of 16 hand-made probes without a flat field among them: too small by 2.4.  The factor
+// 1.5 covers what no search of 7e5-pixel frames sees of a 1e8-pixel frame's tail.
+constexpr double kDynCoefficient = 1.5 * 1.4551915228366852e-11;  // 1.5 x 2^-36 = 2.18e-11
 void dyn_rule(const r2f_ctx* ctx, float* bound, float* floor) {
     const double slope = std::max((double)ctx->curve_slope_max, 1e-3);
-    *bound = (float)std::min(3.6e-7 / (0.4343 * slope * 6.0e-12), 1e7);
+    *bound = (float)std::min(3.6e-7 / (0.4343 * slope * kDynCoefficient), 1e7);
     *floor = (float)std::pow(10.0, (double)ctx->curve.x0);
 }
 
@@ -825,7 +843,7 @@ int run_stencil(r2f_ctx* ctx, int which, const r2f_planes* src, const r2f_planes
 // =============================================================================== C ABI
 extern "C" {
 
-const char* r2f_version(void) { return "r2f-hip 0.5 gfx950 abi5"; }
+const char* r2f_version(void) { return "r2f-hip 0.6 gfx950 abi6"; }
 
 int r2f_create(int device, r2f_ctx** out) {
     if (!out) return R2F_EINVAL;
@@ -853,7 +871,7 @@ void r2f_destroy(r2f_ctx* ctx) {
     DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();  // nothing in flight may still read what is freed below
     drop_render_graphs(ctx);
-    reap_retired_graphs(ctx, true);
+    reap_retired_graphs(ctx, true);  // (the device has been synchronised: entries without a usable event go too)
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     ctx->frame_buf.release();
     ctx->lut2d_buf.release();
@@ -1135,6 +1153,12 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
     if (!ctx || !p) return R2F_EINVAL;
     R2F_GUARD(ctx);
     if (y1 <= y0) return R2F_OK;
+    // R2F_F_TRACK_RANGE (a row shard's front calls): record like a whole-frame render's front kernel, or say that it did not happen
+    const bool want_track = upto == R2F_UPTO_EXPOSURE && (tracked || (p->flags & R2F_F_TRACK_RANGE)) && ctx->opt_fft_s96_auto;
+    auto cannot_track = [&]() -> int {
+        if (!(p->flags & R2F_F_TRACK_RANGE) || upto != R2F_UPTO_EXPOSURE) return R2F_OK;
+        return write_frame_params(ctx, p, static_cast<hipStream_t>(stream), 3);
+    };
     if (!in || W <= 0 || y0 < in_gy0 || y1 > in_gy0 + in_rows || in_layout < 0 || in_layout > 2)
         return fail(ctx, R2F_EINVAL, "front: bad input geometry");
     if (!ctx->lut2d.tex) return fail(ctx, R2F_EINVAL, "input LUT not set (r2f_set_lut2d)");
@@ -1190,13 +1214,28 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
         f.vec = (vec && planes_vec_ok(finish_dst, W)) ? 1 : 0;
         if (f.finish_mask && f.finish_mask != 7 && front_fast_eligible(f)) {
             *finished_mask = f.finish_mask;
-            if (tracked && ctx->opt_fft_s96_auto) {  // a whole-frame render: the exposure planes' range for the FFT passes
+            if (want_track) {  // the exposure planes' range for the FFT passes
                 f.track = static_cast<FrameParams*>(ctx->frame_buf.p);
-                *tracked = true;
+                f.track_mask = 7 & ~f.finish_mask;
+                if (tracked) *tracked = true;
             }
             R2F_HIP(ctx, launch_front_fast(f, static_cast<hipStream_t>(stream)));
             return R2F_OK;
         }
+    }
+    if (want_track && !tracked && a.fast && front_fast_eligible(a)) {
+        // a row shard writes every channel's exposure (its neighbours need them); the record covers the channels the halation's FFT
+        // passes read, i.e. not the single-tap ones -- the same samples a whole-frame render records
+        a.track = static_cast<FrameParams*>(ctx->frame_buf.p);
+        a.track_mask = 7;
+        if (ctx->stencil[R2F_KERNEL_HALATION].present) {
+            float w;
+            for (int c = 0; c < 3; ++c)
+                if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &w)) a.track_mask &= ~(1 << c);
+        }
+    } else {
+        int rc = cannot_track();
+        if (rc) return rc;
     }
     R2F_HIP(ctx, launch_front(a, static_cast<hipStream_t>(stream)));
     return R2F_OK;
@@ -1206,8 +1245,27 @@ int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* expo
                        int y1, int W, int H_global, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
     R2F_GUARD(ctx);
+    ctx->frame_dyn_armed = false;  // (set again by the FFT launches when they carry the rule: r2f_frame_exposure_range)
     return run_stencil(ctx, R2F_KERNEL_HALATION, exposure, density, y0, y1, W, H_global, 1, p->log_eps,
-                       static_cast<hipStream_t>(stream), (p->flags & R2F_F_IDENTITY_DONE) != 0);
+                       static_cast<hipStream_t>(stream), (p->flags & R2F_F_IDENTITY_DONE) != 0, (p->flags & R2F_F_RANGE_VALID) != 0);
+}
+
+int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int W, void* stream) {
+    if (!ctx) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    if (y1 <= y0) return R2F_OK;
+    if (W <= 0) return fail(ctx, R2F_EINVAL, "exposure range: bad geometry");
+    int rc = check_rows(ctx, "exposure range", exposure, y0, y1);
+    if (rc) return rc;
+    int mask = 7;  // the channels the halation's FFT passes read: not the single-tap ones (as the front kernel records them)
+    if (ctx->stencil[R2F_KERNEL_HALATION].present) {
+        float w;
+        for (int c = 0; c < 3; ++c)
+            if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &w)) mask &= ~(1 << c);
+    }
+    R2F_HIP(ctx, launch_exposure_range(to_dev(exposure), y0, y1, W, mask, static_cast<FrameParams*>(ctx->frame_buf.p),
+                                       static_cast<hipStream_t>(stream)));
+    return R2F_OK;
 }
 
 int r2f_stage_mtf(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* din, const r2f_planes* dout, int y0, int y1,
@@ -1395,7 +1453,7 @@ static int run_tail(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* density
         a.grain_lut = ctx->grain_lut;
     }
     if (a.grain && !(p->flags & R2F_F_FRAME_RESIDENT)) {  // the seed of THIS call, ahead of the kernel that reads it
-        rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), false);
+        rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), 0);
         if (rc) return rc;
     }
     R2F_HIP(ctx, launch_tail(a, static_cast<hipStream_t>(stream)));
@@ -1700,7 +1758,7 @@ int r2f_stage_noise(r2f_ctx* ctx, const r2f_params* p, uint32_t* hash_planes, fl
     a.frame = static_cast<const FrameParams*>(ctx->frame_buf.p);
     a.mono = (p->flags & R2F_F_GRAIN_MONO) ? 1 : 0;
     if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
-        int rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), false);
+        int rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), 0);
         if (rc) return rc;
     }
     R2F_HIP(ctx, launch_noise(a, static_cast<hipStream_t>(stream)));
@@ -1732,8 +1790,12 @@ static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, in
     bool tracked = false;
     ctx->frame_dyn_armed = false;
     if (hal) {  // the halation's identity channels (blue on a colour stock) are finished by the front kernel, straight into B
-        if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // kernel by kernel: the frame block (seed, exposure range reset) ahead of the front kernel
-            rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream));
+        // kernel by kernel: the frame block (seed, exposure range reset) ahead of the front kernel.  A caller that keeps the seed
+        // resident still gets the range reset -- every frame's record starts empty, whatever the flag (the union of
+        // earlier frames' ranges used to decide frame N's scratch element); inside a capture the reset stays outside with the seed
+        // write (r2f_render issues one or the other ahead of every replay)
+        if (!(p->flags & R2F_F_FRAME_RESIDENT) || !ctx->capturing) {
+            rc = write_frame_params(ctx, p, static_cast<hipStream_t>(stream), (p->flags & R2F_F_FRAME_RESIDENT) ? 2 : 1);
             if (rc) return rc;
         }
         // ... and also records the range of the exposure planes it writes (every row of them)
@@ -1843,8 +1905,8 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
         r2f_ctx::RenderGraph& g = ctx->graphs[slot];
         g.last_use = ++ctx->graph_clock;
         ctx->frame_dyn_armed = g.dyn_armed;
-        if (!(p->flags & R2F_F_FRAME_RESIDENT)) {  // (a caller that wrote the frame block itself says so with the flag)
-            int rc = write_frame_params(ctx, p, s);
+        {  // seed + range reset; a caller that wrote the seed itself (the flag) gets the range reset alone
+            int rc = write_frame_params(ctx, p, s, (p->flags & R2F_F_FRAME_RESIDENT) ? 2 : 1);
             if (rc) return rc;
         }
         R2F_HIP(ctx, hipGraphLaunch(g.exec, s));
@@ -1876,7 +1938,9 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     hipError_t e = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal);
     int rc = R2F_OK;
     if (e == hipSuccess) {
+        ctx->capturing = true;
         rc = render_launches(ctx, &q, in, in_layout, out_f32, out_u8, H, W, workspace, ctx->cap_stream);
+        ctx->capturing = false;
         e = hipStreamEndCapture(ctx->cap_stream, &graph);
     }
     hipGraphExec_t exec = nullptr;
@@ -1902,10 +1966,8 @@ int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout,
     g.dyn_armed = ctx->frame_dyn_armed;  // (what the captured halation launches carry; r2f_frame_exposure_range after a replay)
     if (hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) g.done = nullptr, (void)hipGetLastError();
     ++ctx->stat_captures;
-    if (!(p->flags & R2F_F_FRAME_RESIDENT)) {
-        rc = write_frame_params(ctx, p, s);
-        if (rc) return rc;
-    }
+    rc = write_frame_params(ctx, p, s, (p->flags & R2F_F_FRAME_RESIDENT) ? 2 : 1);
+    if (rc) return rc;
     R2F_HIP(ctx, hipGraphLaunch(g.exec, s));
     if (g.done) R2F_HIP(ctx, hipEventRecord(g.done, s));
     ++ctx->stat_replays;

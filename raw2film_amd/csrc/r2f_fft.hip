@@ -766,13 +766,13 @@ template <int XL>
 static void launch_rows_fwd(const FftConvArgs& a, hipStream_t s) {
     const dim3 block(kFftThreads), grid(a.ny / RowGeom<XL>::ROWS, a.npairs);
     if (a.s32 == 1)
-        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 1>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_rows_fwd_kernel<XL, 1>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 3)
-        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 3>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_rows_fwd_kernel<XL, 3>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 2)
-        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 2>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_rows_fwd_kernel<XL, 2>), grid, block, fft_lds_bytes(), s, a);
     else
-        hipLaunchKernelGGL((fft_rows_fwd_kernel<XL, 0>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_rows_fwd_kernel<XL, 0>), grid, block, fft_lds_bytes(), s, a);
 }
 
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
@@ -782,18 +782,18 @@ hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s) {
         launch_rows_fwd<1>(a, s);
     else
         launch_rows_fwd<0>(a, s);
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 template <int NBX, bool Y512, bool KR>
 static void launch_cols_kr(const FftConvArgs& a, int mode, hipStream_t s) {
     const dim3 block(kFftThreads), grid(a.nx / (Y512 ? 8 : 16), a.npairs);
     if (a.s32 == 1)
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 1, KR>), grid, block, fft_lds_bytes(), s, a, mode);
+        launch_k((fft_cols_kernel<NBX, Y512, 1, KR>), grid, block, fft_lds_bytes(), s, a, mode);
     else if (a.s32 == 2)
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 2, KR>), grid, block, fft_lds_bytes(), s, a, mode);
+        launch_k((fft_cols_kernel<NBX, Y512, 2, KR>), grid, block, fft_lds_bytes(), s, a, mode);
     else
-        hipLaunchKernelGGL((fft_cols_kernel<NBX, Y512, 0, KR>), grid, block, fft_lds_bytes(), s, a, mode);
+        launch_k((fft_cols_kernel<NBX, Y512, 0, KR>), grid, block, fft_lds_bytes(), s, a, mode);
 }
 
 template <int NBX, bool Y512>
@@ -821,13 +821,13 @@ template <int NBX>
 static void launch_cols_walk_st(const FftConvArgs& a, dim3 grid, hipStream_t s) {
     const dim3 block(kFftThreads);
     if (a.s32 == 1)
-        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 1>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 1>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 3)
-        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 3>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 3>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 2)
-        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 2>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 2>), grid, block, fft_lds_bytes(), s, a);
     else
-        hipLaunchKernelGGL((fft_cols_walk_kernel<NBX, 0>), grid, block, fft_lds_bytes(), s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 0>), grid, block, fft_lds_bytes(), s, a);
 }
 
 static void launch_cols_walk(const FftConvArgs& a, hipStream_t s) {
@@ -845,13 +845,13 @@ static void launch_cols_walk(const FftConvArgs& a, hipStream_t s) {
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
     if (cols_walk_applies(a, mode)) {
         launch_cols_walk(a, s);
-        return hipGetLastError();
+        return take_launch_status();
     }
     if (a.ny == 512)
         launch_cols_nx<true>(a, mode, s);
     else
         launch_cols_nx<false>(a, mode, s);
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 template <int XL, int EPI>
@@ -868,13 +868,13 @@ static void launch_rows_inv(const FftConvArgs& a0, hipStream_t s) {
         lds += (size_t)(a.curve.m - 1) * sizeof(float4);
     }
     if (a.s32 == 1)
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 1>), grid, dim3(kFftThreads), lds, s, a);
+        launch_k((fft_rows_inv_kernel<XL, EPI, 1>), grid, dim3(kFftThreads), lds, s, a);
     else if (a.s32 == 3)
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 3>), grid, dim3(kFftThreads), lds, s, a);
+        launch_k((fft_rows_inv_kernel<XL, EPI, 3>), grid, dim3(kFftThreads), lds, s, a);
     else if (a.s32 == 2)
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 2>), grid, dim3(kFftThreads), lds, s, a);
+        launch_k((fft_rows_inv_kernel<XL, EPI, 2>), grid, dim3(kFftThreads), lds, s, a);
     else
-        hipLaunchKernelGGL((fft_rows_inv_kernel<XL, EPI, 0>), grid, dim3(kFftThreads), lds, s, a);
+        launch_k((fft_rows_inv_kernel<XL, EPI, 0>), grid, dim3(kFftThreads), lds, s, a);
 }
 
 template <int XL>
@@ -897,7 +897,7 @@ hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s) {
         launch_rows_inv_epi<1>(a, s);
     else
         launch_rows_inv_epi<0>(a, s);
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 }  // namespace r2f

@@ -197,9 +197,9 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             if (UPTO == R2F_UPTO_EXPOSURE) {
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
                 if (track) {  // (fminf / fmaxf drop a NaN: pass 1 of the FFT form takes a non-finite sample as 0 anyway; an infinity stays)
-                    if (!(a.finish_mask & 1)) t_lo = fminf(t_lo, r[q]), t_hi = fmaxf(t_hi, fabsf(r[q]));
-                    if (!(a.finish_mask & 2)) t_lo = fminf(t_lo, g[q]), t_hi = fmaxf(t_hi, fabsf(g[q]));
-                    if (!(a.finish_mask & 4)) t_lo = fminf(t_lo, b[q]), t_hi = fmaxf(t_hi, fabsf(b[q]));
+                    if (a.track_mask & 1) t_lo = fminf(t_lo, r[q]), t_hi = fmaxf(t_hi, fabsf(r[q]));
+                    if (a.track_mask & 2) t_lo = fminf(t_lo, g[q]), t_hi = fmaxf(t_hi, fabsf(g[q]));
+                    if (a.track_mask & 4) t_lo = fminf(t_lo, b[q]), t_hi = fmaxf(t_hi, fabsf(b[q]));
                 }
                 if (FIN) {  // same arithmetic as single_tap_kernel with the halation epilogue: w * x, log10, curve
                     if (a.finish_mask & 1) r[q] = curve_eval_at((const float4*)cells_lds, a.curve, 0, log10_fast(a.finish_w[0] * r[q], a.log_eps));
@@ -311,9 +311,9 @@ static void launch_fast(const FrontArgs& a, hipStream_t s) {
     gy = gy > row_groups ? row_groups : (gy < 1 ? 1 : gy);
     const dim3 grid(gx, gy), block(64, BY);
     switch (a.in_layout) {
-        case R2F_LAYOUT_CHW: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_CHW, UPTO, BY, FIN>), grid, block, lds, s, a); break;
-        case R2F_LAYOUT_HWC3: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_HWC3, UPTO, BY, FIN>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((front_fast_kernel<R2F_LAYOUT_HWC4, UPTO, BY, FIN>), grid, block, lds, s, a); break;
+        case R2F_LAYOUT_CHW: launch_k((front_fast_kernel<R2F_LAYOUT_CHW, UPTO, BY, FIN>), grid, block, lds, s, a); break;
+        case R2F_LAYOUT_HWC3: launch_k((front_fast_kernel<R2F_LAYOUT_HWC3, UPTO, BY, FIN>), grid, block, lds, s, a); break;
+        default: launch_k((front_fast_kernel<R2F_LAYOUT_HWC4, UPTO, BY, FIN>), grid, block, lds, s, a); break;
     }
 }
 
@@ -328,7 +328,7 @@ hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s) {
         big ? launch_fast<R2F_UPTO_DENSITY, 16>(a, s) : launch_fast<R2F_UPTO_DENSITY, 8>(a, s);
     else
         big ? launch_fast<R2F_UPTO_OUTPUT, 16>(a, s) : launch_fast<R2F_UPTO_OUTPUT, 8>(a, s);
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 hipError_t front_fast_init_attributes() {

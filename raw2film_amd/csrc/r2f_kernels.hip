@@ -12,6 +12,8 @@
 //   lanczos4_u8       post-path up-scale of the uint8 result (cv.resize INTER_LANCZOS4): the way back from max_scale
 //   noise_kernel      S6a test entry (hash + Gaussian field)
 //   histogram_u8      caller-side RGB histogram counts of the uint8 output (utils.generate_histogram, histogram.wgsl pass 1)
+#include <algorithm>
+
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
@@ -1159,11 +1161,11 @@ hipError_t launch_front(const FrontArgs& a, hipStream_t s) {
         int gy = ((a.blocks_per_cu > 0 ? a.blocks_per_cu : 6) * 256 + gx - 1) / gx;
         if (gy > row_groups) gy = row_groups;
         if (gy < 1) gy = 1;
-        hipLaunchKernelGGL(front_kernel<true>, dim3(gx, gy), block, cell_bytes, s, a);
+        launch_k(front_kernel<true>, dim3(gx, gy), block, cell_bytes, s, a);
     } else {
-        hipLaunchKernelGGL(front_kernel<false>, dim3(gx, row_groups), block, 0, s, a);
+        launch_k(front_kernel<false>, dim3(gx, row_groups), block, 0, s, a);
     }
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
@@ -1175,10 +1177,10 @@ hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
 #define R2F_STENCIL_FIXED(R)                                                                        \
     case R:                                                                                        \
         if (a.epilogue == 1)                                                                       \
-            hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 1, R>), grid, block, lds, s, a);         \
+            launch_k((stencil_kernel<32, 16, 4, 1, R>), grid, block, lds, s, a);         \
         else                                                                                       \
-            hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0, R>), grid, block, lds, s, a);         \
-        return hipGetLastError();
+            launch_k((stencil_kernel<32, 16, 4, 0, R>), grid, block, lds, s, a);         \
+        return take_launch_status();
         switch (a.fixed_r) {
             R2F_STENCIL_FIXED(1)
             R2F_STENCIL_FIXED(2)
@@ -1198,14 +1200,14 @@ hipError_t launch_stencil(const StencilArgs& a, int variant, hipStream_t s) {
     }
     const int key = variant * 2 + (a.epilogue == 1 ? 1 : 0);
     switch (key) {
-        case 0: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 0>), grid, block, lds, s, a); break;
-        case 1: hipLaunchKernelGGL((stencil_kernel<32, 16, 4, 1>), grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 0>), grid, block, lds, s, a); break;
-        case 3: hipLaunchKernelGGL((stencil_kernel<16, 8, 4, 1>), grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((stencil_kernel<32, 8, 4, 0>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((stencil_kernel<32, 8, 4, 1>), grid, block, lds, s, a); break;
+        case 0: launch_k((stencil_kernel<32, 16, 4, 0>), grid, block, lds, s, a); break;
+        case 1: launch_k((stencil_kernel<32, 16, 4, 1>), grid, block, lds, s, a); break;
+        case 2: launch_k((stencil_kernel<16, 8, 4, 0>), grid, block, lds, s, a); break;
+        case 3: launch_k((stencil_kernel<16, 8, 4, 1>), grid, block, lds, s, a); break;
+        case 4: launch_k((stencil_kernel<32, 8, 4, 0>), grid, block, lds, s, a); break;
+        default: launch_k((stencil_kernel<32, 8, 4, 1>), grid, block, lds, s, a); break;
     }
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
@@ -1229,8 +1231,8 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
         l.grain_lut = a.grain_lut;
         const int quads = (a.W + 3) / 4;
         dim3 block(64, 4), grid((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4);
-        hipLaunchKernelGGL(lut3d_kernel, grid, block, 0, s, l);
-        return hipGetLastError();
+        launch_k(lut3d_kernel, grid, block, 0, s, l);
+        return take_launch_status();
     }
     const int TW = 4 * kTailBX, TH = kTailQ * kTailBY;
     dim3 block(kTailBX * kTailBY), grid((a.W + TW - 1) / TW, (a.y1 - a.y0 + TH - 1) / TH);
@@ -1242,9 +1244,9 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
 #define R2F_TAIL_FIXED(R)                                                        \
     case R:                                                                     \
         if (a.sep)                                                              \
-            hipLaunchKernelGGL((tail_kernel<R, true>), grid, block, lds, s, b); \
+            launch_k((tail_kernel<R, true>), grid, block, lds, s, b); \
         else                                                                    \
-            hipLaunchKernelGGL((tail_kernel<R>), grid, block, lds, s, b);       \
+            launch_k((tail_kernel<R>), grid, block, lds, s, b);       \
         break;
         R2F_TAIL_FIXED(1)
         R2F_TAIL_FIXED(2)
@@ -1257,87 +1259,127 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s) {
         R2F_TAIL_FIXED(9)
 #undef R2F_TAIL_FIXED
         default:
-            hipLaunchKernelGGL((tail_kernel<0>), grid, block, lds, s, b);
+            launch_k((tail_kernel<0>), grid, block, lds, s, b);
             break;
     }
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 hipError_t launch_burn_sums(const BurnSumsArgs& a, hipStream_t s) {
     if (a.h_lo <= 0 || a.w_lo <= 0) return hipSuccess;
-    hipLaunchKernelGGL(burn_sums_kernel, dim3(a.w_lo, a.h_lo), dim3(256), 0, s, a);
-    return hipGetLastError();
+    launch_k(burn_sums_kernel, dim3(a.w_lo, a.h_lo), dim3(256), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_burn_map(const BurnMapArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(burn_map_kernel, dim3(1), dim3(256), 0, s, a);
-    return hipGetLastError();
+    launch_k(burn_map_kernel, dim3(1), dim3(256), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_chroma_h(const ChromaArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
-    hipLaunchKernelGGL(chroma_h_kernel, dim3((a.W + kChromaSeg - 1) / kChromaSeg, a.y1 - a.y0), dim3(256), 0, s, a);
-    return hipGetLastError();
+    launch_k(chroma_h_kernel, dim3((a.W + kChromaSeg - 1) / kChromaSeg, a.y1 - a.y0), dim3(256), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_chroma_v(const ChromaArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     const int quads = (a.W + 3) / 4;
-    hipLaunchKernelGGL(chroma_v_kernel, dim3((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(chroma_v_kernel, dim3((quads + 63) / 64, (a.y1 - a.y0 + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_resize_area(const ResizeArgs& a, hipStream_t s) {
     if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
-    hipLaunchKernelGGL(resize_area_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(resize_area_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s) {
     if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
-    hipLaunchKernelGGL(warp_affine_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(warp_affine_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_single_tap(const TapArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
-    hipLaunchKernelGGL(single_tap_kernel, dim3((a.W + 1023) / 1024, a.y1 - a.y0), dim3(256), 0, s, a);
-    return hipGetLastError();
+    launch_k(single_tap_kernel, dim3((a.W + 1023) / 1024, a.y1 - a.y0), dim3(256), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_lanczos4_u8(const LanczosArgs& a, hipStream_t s) {
     if (a.out_h <= 0 || a.out_w <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lanczos4_u8_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(lanczos4_u8_kernel, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s) {
     if (a.y1 <= a.y0 || a.W <= 0) return hipSuccess;
     dim3 block(256), grid((a.W + 255) / 256, a.y1 - a.y0);
-    hipLaunchKernelGGL(noise_kernel, grid, block, 0, s, a);
-    return hipGetLastError();
+    launch_k(noise_kernel, grid, block, 0, s, a);
+    return take_launch_status();
 }
 
-// (new_frame = 0: only the seed -- a stage entry's own write in the middle of a frame keeps the exposure range the front kernel recorded)
-__global__ void frame_params_kernel(FrameParams* dst, const FrameParams v, const int new_frame) {
-    if (new_frame)
+// mode 0: only the seed (a stage entry's own write in the middle of a frame keeps the exposure range the front kernel recorded);
+// 1: the whole block (seed + range reset: the start of a frame); 2: only the range reset (a caller that keeps the seed resident);
+// 3: the range is made unusable (max = +inf: the FFT passes keep complex128) -- a front kernel that was asked to record the range
+// of what it writes and cannot
+__global__ void frame_params_kernel(FrameParams* dst, const FrameParams v, const int mode) {
+    if (mode == 1)
         *dst = v;
-    else
+    else if (mode == 0)
         dst->seed = v.seed;
+    else if (mode == 2)
+        dst->e_min = v.e_min, dst->e_max = v.e_max;
+    else
+        dst->e_max = 0x7f800000u;
 }
 
-hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int new_frame, hipStream_t s) {
-    hipLaunchKernelGGL(frame_params_kernel, dim3(1), dim3(1), 0, s, dst, v, new_frame);
-    return hipGetLastError();
+hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int mode, hipStream_t s) {
+    launch_k(frame_params_kernel, dim3(1), dim3(1), 0, s, dst, v, mode);
+    return take_launch_status();
+}
+
+// min / max |.| of rows [y0, y1) of the planes in `mask`, merged into the frame block like the front kernel's own record
+// (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours).  NaNs drop out of fminf / fmaxf, like there.
+__global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src, const int y0, const int y1, const int W, const int mask,
+                                                              FrameParams* dst) {
+    float lo = __builtin_inff(), hi = 0.f;
+    const long long n = (long long)(y1 - y0) * W;
+    for (int c = 0; c < 3; ++c) {
+        if (!((mask >> c) & 1)) continue;
+        const float* p = src.data + c * src.plane_stride + (long long)(y0 - src.gy0) * W;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const float v = p[i];
+            lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, m));
+        hi = fmaxf(hi, __shfl_xor(hi, m));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(reinterpret_cast<int*>(&dst->e_min), __float_as_int(lo));
+        atomicMax(reinterpret_cast<int*>(&dst->e_max), __float_as_int(hi));
+    }
+}
+
+hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int W, int mask, FrameParams* dst, hipStream_t s) {
+    if (y1 <= y0 || W <= 0 || !(mask & 7)) return hipSuccess;
+    const long long n = (long long)(y1 - y0) * W;
+    const int blocks = (int)std::min<long long>((n + 1023) / 1024, 2048);
+    launch_k(exposure_range_kernel, dim3(blocks), dim3(256), 0, s, src, y0, y1, W, mask, dst);
+    return take_launch_status();
 }
 
 hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s) {
     hipError_t e = hipMemsetAsync(counts, 0, 768 * sizeof(uint32_t), s);
     if (e != hipSuccess || n_bytes <= 0) return e;
     const long long per_block = (long long)kHistThreads * kHistBytesPerLane * kHistIters;
-    hipLaunchKernelGGL(histogram_u8_kernel, dim3((unsigned)((n_bytes + per_block - 1) / per_block)), dim3(kHistThreads), 0, s,
+    launch_k(histogram_u8_kernel, dim3((unsigned)((n_bytes + per_block - 1) / per_block)), dim3(kHistThreads), 0, s,
                        image, n_bytes, counts);
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 }  // namespace r2f

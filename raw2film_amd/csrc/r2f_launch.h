@@ -2,11 +2,37 @@
 #pragma once
 
 #include <cstdint>
+#include <tuple>
+#include <type_traits>
 #include "r2f_device.h"
 
 struct r2f_blit;
 
 namespace r2f {
+
+// Kernel launches report THEIR OWN status.  hipLaunchKernelGGL + hipGetLastError() would hand back (and consume) whatever error was
+// pending on the calling thread -- one of PyTorch's or RCCL's, left there by an abandoned capture, say -- as if this library had
+// produced it.  hipLaunchKernel returns the status of the launch itself and leaves the thread's last-error slot alone
+// unless this launch fails; the first failure of a launcher is parked in a thread-local until the launcher returns it.
+inline thread_local hipError_t tl_launch_error = hipSuccess;
+template <typename... KArgs, typename... Args>
+inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, const Args&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "one value per kernel parameter");
+    std::tuple<std::remove_cv_t<KArgs>...> vals{static_cast<std::remove_cv_t<KArgs>>(args)...};
+    void* ptrs[sizeof...(KArgs)];
+    int i = 0;
+    std::apply([&](auto&... v) { ((ptrs[i++] = static_cast<void*>(&v)), ...); }, vals);
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // the error this launch produced is reported through the return value, not left pending
+        if (tl_launch_error == hipSuccess) tl_launch_error = e;
+    }
+}
+inline hipError_t take_launch_status() {
+    const hipError_t e = tl_launch_error;
+    tl_launch_error = hipSuccess;
+    return e;
+}
 
 struct FrontArgs {
     const void* in;
@@ -34,9 +60,10 @@ struct FrontArgs {
     int finish_mask;
     float finish_w[3];
     DevPlanes finish_dst;
-    // fast kernel, upto = EXPOSURE: min / max |.| of the exposure samples written to `dst` (the channels NOT in finish_mask) are
-    // accumulated into this frame block (nullptr: not tracked)
+    // fast kernel, upto = EXPOSURE: min / max |.| of the exposure samples written to `dst` for the channels in track_mask (the ones
+    // the halation's FFT passes read) are accumulated into this frame block (nullptr: not tracked)
     FrameParams* track;
+    int track_mask;
 };
 bool front_fast_eligible(const FrontArgs& a);
 hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s);
@@ -254,7 +281,10 @@ hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s);
 hipError_t launch_lanczos4_u8(const LanczosArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 // *dst <- v on stream s (one lane): the per-render write of the context's FrameParams block ahead of a frame's launches
-hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int new_frame, hipStream_t s);
+// mode: 0 seed only, 1 seed + range reset, 2 range reset only, 3 range made unusable (frame_params_kernel)
+hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int mode, hipStream_t s);
+// the range of rows [y0, y1) of the planes in `mask` merged into the frame block (r2f_stage_exposure_range)
+hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int W, int mask, FrameParams* dst, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
 hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s);

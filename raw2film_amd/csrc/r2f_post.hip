@@ -327,36 +327,36 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f4v* __restrict_
 
 hipError_t launch_stream_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
     const long long n = bytes / 16;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const f4v*>(src),
+    launch_k(stream_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const f4v*>(src),
                        static_cast<f4v*>(dst), n);
-    return hipGetLastError();
+    return take_launch_status();
 }
 
 hipError_t launch_decode_u16(const uint16_t* src, long long n, int ch, float divisor, float factor, float* dst, hipStream_t s) {
     DecodeU16Args a{src, dst, n, ch, divisor, factor,
                     (ch == 3 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) ? 1 : 0};
     const long long quads = (n + 3) / 4;
-    hipLaunchKernelGGL(decode_u16_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    launch_k(decode_u16_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_resize_area_u8(const uint8_t* src, int H, int W, uint8_t* dst, int out_h, int out_w, hipStream_t s) {
     AreaU8Args a{src, dst, H, W, out_h, out_w};
-    hipLaunchKernelGGL(resize_area_u8_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(resize_area_u8_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_lanczos4_f32(const void* in, int in_layout, int H, int W, const DevPlanes& dst, int out_h, int out_w, const int* xofs,
                                const float* xcoef, const int* yofs, const float* ycoef, hipStream_t s) {
     LanczosF32Args a{in, in_layout, H, W, dst, out_h, out_w, xofs, xcoef, yofs, ycoef};
-    hipLaunchKernelGGL(lanczos4_f32_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(lanczos4_f32_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_blit_rgba8(const float* src, int H, int W, uint8_t* dst, int dst_h, int dst_w, const r2f_blit& t, hipStream_t s) {
     BlitArgs a{src, dst, H, W, dst_h, dst_w, t};
-    hipLaunchKernelGGL(blit_rgba8_kernel, dim3((dst_w + 63) / 64, (dst_h + 3) / 4), dim3(64, 4), 0, s, a);
-    return hipGetLastError();
+    launch_k(blit_rgba8_kernel, dim3((dst_w + 63) / 64, (dst_h + 3) / 4), dim3(64, 4), 0, s, a);
+    return take_launch_status();
 }
 
 hipError_t launch_histogram_render(const uint32_t* counts, const uint8_t* mix_rgba, int height, uint8_t* image, uint8_t* target, int th,
@@ -366,8 +366,8 @@ hipError_t launch_histogram_render(const uint32_t* counts, const uint8_t* mix_rg
     for (int k = 0; k < 8; ++k)
         a.mix[k] = (uint32_t)mix_rgba[4 * k] | ((uint32_t)mix_rgba[4 * k + 1] << 8) | ((uint32_t)mix_rgba[4 * k + 2] << 16) |
                    ((uint32_t)mix_rgba[4 * k + 3] << 24);
-    hipLaunchKernelGGL(histogram_render_kernel, dim3(1), dim3(256), 0, s, a);
-    return hipGetLastError();
+    launch_k(histogram_render_kernel, dim3(1), dim3(256), 0, s, a);
+    return take_launch_status();
 }
 
 }  // namespace r2f

@@ -118,3 +118,71 @@ def roughen(rng, p, n2: int, m1: int, n3: int, rough2: float = 0.2, rough3: floa
     if p.grain_lut is not None:
         p.grain_lut = grain_lut(rng, 256, amp=0.03)
     return p
+
+
+# ---------------------------------------------------------------------------------------------- 12-byte scratch element
+# Frames for the search behind the guard of the halation's 12-byte FFT scratch element (r2f_api.hip dyn_rule).
+# The element rounds every scratch value to 2^-37 of itself, so what it costs a pixel scales with the energy of the WINDOW the
+# pixel shares, while the guard sees max |x| and min x of the frame: the worst frames put as much bright, spectrally rich signal as
+# possible into a window and a shadow further than the stencil's reach (43 px at the 100 MP pitch) from all of it.
+SCRATCH96_KINDS = ("holes", "blocks", "stripes", "checker", "gradient", "half", "speculars")
+SCRATCH96_FILLS = ("u50", "u0", "binary", "jitter", "lognormal")
+
+
+def scratch96_frame(rng, H: int, W: int, kind: str, fill: str, lo: float, hi: float) -> np.ndarray:
+    """(H, W, 3) float32 exposure-like frame: a shadow field at `lo` (x U(1, 3), or flat), bright regions at up to `hi`."""
+
+    def bright(shape):
+        if fill == "u50":
+            v = rng.uniform(0.5, 1.0, shape)
+        elif fill == "u0":
+            v = rng.uniform(0.0, 1.0, shape)
+        elif fill == "binary":
+            v = rng.integers(0, 2, shape).astype(np.float64)
+        elif fill == "jitter":  # nearly flat, every mantissa bit in use
+            v = 1.0 - rng.uniform(0.0, 2.0 ** -int(rng.integers(4, 20)), shape)
+        else:  # lognormal body clipped at 1: a few speculars over a bright body
+            v = np.minimum(np.exp(rng.normal(-2.0, 1.0, shape)), 1.0)
+        return hi * v
+
+    dark = lo * (rng.uniform(1.0, 3.0, (H, W, 3)) if rng.integers(0, 2) else np.ones((H, W, 3)))
+    img = dark.copy()
+    reach = 48
+    if kind == "holes":  # bright everywhere but in a few dark squares whose centres see no bright sample
+        img = bright((H, W, 3))
+        for _ in range(int(rng.integers(2, 9))):
+            s = int(rng.integers(2 * reach + 4, 2 * reach + 80))
+            y, x = int(rng.integers(0, max(H - s, 1))), int(rng.integers(0, max(W - s, 1)))
+            img[y:y + s, x:x + s] = dark[y:y + s, x:x + s]
+    elif kind == "blocks":
+        for _ in range(int(rng.integers(1, 7))):
+            h, w = int(rng.integers(8, H // 2)), int(rng.integers(8, W // 2))
+            y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+            img[y:y + h, x:x + w] = bright((h, w, 3))
+    elif kind == "stripes":  # bright stripes over part of the frame, a dark field beside them
+        p = int(rng.integers(2, 9))
+        split = int(rng.integers(W // 3, 2 * W // 3))
+        b = bright((H, W, 3))
+        if rng.integers(0, 2):
+            img[::p, :split] = b[::p, :split]
+        else:
+            img[:, :split:p] = b[:, :split:p]
+    elif kind == "checker":
+        c = int(rng.integers(2 * reach + 4, 3 * reach))
+        yy, xx = np.indices((H, W))
+        m = ((yy // c + xx // c) % 2).astype(bool)
+        img[m] = bright((H, W, 3))[m]
+    elif kind == "gradient":  # a smooth ramp from hi down to the shadows, bright noise on top of its upper half
+        ramp = np.geomspace(hi, lo, W)[None, :, None] * np.ones((H, 1, 3))
+        img = np.maximum(ramp * rng.uniform(0.5, 1.0, (H, W, 3)), dark)
+    elif kind == "half":
+        split = int(rng.integers(W // 4, 3 * W // 4))
+        img[:, :split] = bright((H, split, 3))
+    else:  # isolated speculars and a patch (tools/scratch96_probe.py)
+        img[::int(rng.integers(40, 120)), ::int(rng.integers(40, 160))] = hi
+        img[H // 2:H // 2 + 40, W // 2:W // 2 + 60] = bright((40, 60, 3))
+    # the guard's hi and lo are the frame's own extremes: pin them so that the ratio is the one asked for
+    img = np.clip(img, lo, hi)
+    img[0, 0] = lo
+    img[H - 1, W - 1] = hi
+    return img.astype(F32)

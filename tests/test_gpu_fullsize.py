@@ -54,36 +54,58 @@ def test_windows_of_the_100mp_render_match_the_oracle(full, y0, x0):
     assert err <= 1e-5, err
 
 
-@pytest.mark.parametrize("fft", [0, 1])
-def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
+@pytest.mark.parametrize("mode", ["direct", "fft", "fft_dyn"])
+def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, mode):
     """Direct stencils: bit for bit (every pixel sums its taps in the same order whatever the tile or shard).  FFT stencils:
     the windows are anchored at the shard's first row, so a pixel's 256 x 256 window differs between the two renders and
-    with it the fp64 rounding noise (~1e-13): after the one rounding to fp32 a handful of pixels may differ by an ulp."""
+    with it the fp64 rounding noise (~1e-13): after the one rounding to fp32 a handful of pixels may differ by an ulp.
+    fft_dyn (round 6): the shards keep the exposure-range record like r2f_render does (R2F_F_TRACK_RANGE on the front call,
+    R2F_F_RANGE_VALID on the halation) and are compared with the DEFAULT whole-frame render: both choose the 12-byte element on
+    this frame, each from its own rows' range; the element rounds per window, so the two tilings agree to ITS rounding."""
     ctx, params, p, frame, out = full
-    ctx.set_option("stencil_fft", fft)
+    fft, dyn = mode != "direct", mode == "fft_dyn"
+    ctx.set_option("stencil_fft", int(fft))
     if not fft:
         out, _ = ctx.render(frame, params)
-    else:
-        # like for like: the stage entry points keep complex128 scratch for the halation, the whole-frame render chooses its
-        # element from the frame's range (round 5: the 12-byte one on this frame).  The fixture's default render must agree with
-        # the complex128 one to the element's own rounding (at most three ulps of a density, a few 1e-7 of the output).
+    elif not dyn:
+        # like for like: stage calls without the record keep complex128 scratch for the halation, and so does the whole-frame
+        # render of THIS frame -- its range (max / shadow = 1.4e5) is beyond the 12-byte element's guard since round 6, and kernels
+        # that choose on the device and choose complex128 compute what the complex128 kernels compute, bit for bit
+        rng = ctx.frame_exposure_range()
         ctx.set_option("stencil_fft_scratch96_auto", 0)
         exact, _ = ctx.render(frame, params)
         ctx.set_option("stencil_fft_scratch96_auto", 1)
+        assert torch.equal(exact, out)
+        del exact
+    else:
+        # a frame the guard accepts: the same one with its deepest shadows and brightest speculars clamped (max / shadow ~ 1e4)
+        frame = frame.clamp(4e-3, 48.0)
+        ctx.set_option("stencil_fft_scratch96_auto", 0)
+        exact, _ = ctx.render(frame, params)
+        exact = exact.clone()
+        ctx.set_option("stencil_fft_scratch96_auto", 1)
+        out, _ = ctx.render(frame, params)
+        rng = ctx.frame_exposure_range()
+        assert rng["armed"] and rng["twelve_byte_element"], rng
         d = (exact - out).abs()
         assert float((d / exact.abs().clamp_min(1e-3)).max()) <= 2e-6
         assert 0 < float((d > 0).float().mean()) <= 5e-3  # (it IS the other element: a few pixels in ten thousand differ)
-        out = exact
-        del d
+        del d, exact
     rh, rm = p.halation_kernel.shape[0] // 2, p.mtf_kernel.shape[0] // 2
     bounds = [0, 1000, 4096, 5121, H_FULL]  # uneven shards, each at least a halo tall
+    worst = 0.0
     for a, b in zip(bounds[:-1], bounds[1:]):
         d_lo, d_hi = max(a - rm, 0), min(b + rm, H_FULL)
         e_lo, e_hi = max(d_lo - rh, 0), min(d_hi + rh, H_FULL)
         E = torch.empty((3, e_hi - e_lo, W_FULL), dtype=torch.float32, device="cuda")
-        ctx.stage_front(frame[e_lo:e_hi], params, 0, in_gy0=e_lo, dst=E, dst_gy0=e_lo, H_global=H_FULL)
+        if dyn:
+            ctx.write_frame_params(params)  # the start of a frame: the record is reset
+        ctx.stage_front(frame[e_lo:e_hi], params, 0, in_gy0=e_lo, dst=E, dst_gy0=e_lo, H_global=H_FULL, track_range=dyn)
         D = torch.empty((3, d_hi - d_lo, W_FULL), dtype=torch.float32, device="cuda")
-        ctx.stage_halation(E, D, params, src_gy0=e_lo, dst_gy0=d_lo, y0=d_lo, y1=d_hi, H_global=H_FULL)
+        ctx.stage_halation(E, D, params, src_gy0=e_lo, dst_gy0=d_lo, y0=d_lo, y1=d_hi, H_global=H_FULL, range_valid=dyn)
+        if dyn:
+            rng = ctx.frame_exposure_range()
+            assert rng["armed"] and rng["twelve_byte_element"], rng
         D2 = torch.empty((3, b - a, W_FULL), dtype=torch.float32, device="cuda")
         ctx.stage_mtf(D, D2, params, src_gy0=d_lo, dst_gy0=a, y0=a, y1=b, H_global=H_FULL)
         part = torch.empty((b - a, W_FULL, 3), dtype=torch.float32, device="cuda")
@@ -91,11 +113,15 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, fft):
         if fft:
             ref = out[a:b]
             diff = (part - ref).abs()
-            assert float((diff / ref.abs().clamp_min(1e-3)).max()) <= 5e-7, (a, b)
-            assert float((diff > 0).float().mean()) <= 1e-3, (a, b)
+            worst = max(worst, float((diff / ref.abs().clamp_min(1e-3)).max()))
+            # complex128 on both sides: fp64 rounding noise, an fp32 ulp on a handful of pixels.  The 12-byte element on both
+            # sides: each side within 1e-6 of the complex128 frame (asserted above for the whole frame: <= 2e-6), windows differ
+            assert worst <= (2e-6 if dyn else 5e-7), (a, b, worst)
+            assert float((diff > 0).float().mean()) <= (1e-2 if dyn else 1e-3), (a, b)
         else:
             assert torch.equal(part, out[a:b]), (a, b)
         del E, D, D2, part
+    print(f"row shards vs whole frame ({mode}): worst relative difference at the 1e-3 floor {worst:.2e}")
     ctx.set_option("stencil_fft", 1)
 
 

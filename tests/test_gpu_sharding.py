@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _render(rank, world, H, W, fw, burn=0.0, direct=False):
+def _render(rank, world, H, W, fw, burn=0.0, direct=False, dyn=False):
     from raw2film_amd import HipProcessor, stencils
     from raw2film_amd.hip_processor import REC709_TO_XYZ
     from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
@@ -38,9 +38,15 @@ def _render(rank, world, H, W, fw, burn=0.0, direct=False):
     hal = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
     mtf = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
     be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
-    rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, burn=bool(burn), rank=rank, world=world)
+    # dyn = False: complex128 scratch for the halation whatever the rows hold -- like for like with a whole-frame render under
+    # stencil_fft_scratch96_auto = 0, which is what the bit-identity tests below compare; dyn = True is the product default
+    if dyn:
+        proc.ctx.set_option("stencil_fft_window_rows", 256)  # (the device-side choice exists for the 256-row passes large frames take)
+    rr = RowShardedRenderer(be, H, W, halation=True, mtf=True, burn=bool(burn), rank=rank, world=world, dyn_scratch=dyn)
     frame = synthetic_frame(H, W, seed=31)
     frame[60:150, 40:200] *= 8.0
+    if dyn:  # a frame whose range the 12-byte element's guard accepts (max / shadow <= 6e4 with the stand-in Portra curve)
+        frame = np.clip(frame, 8e-3, None)
     img = torch.from_numpy(frame).cuda()
     out = torch.empty((rr.plan.rows, W, 3), dtype=torch.float32, device="cuda")
     rr.render(img[rr.plan.r0:rr.plan.r1].contiguous(), out_f32=out)
@@ -48,7 +54,7 @@ def _render(rank, world, H, W, fw, burn=0.0, direct=False):
     return out.cpu().numpy(), proc, params, img
 
 
-def _worker(rank, world, port, H, W, fw, path, burn=0.0, direct=False):
+def _worker(rank, world, port, H, W, fw, path, burn=0.0, direct=False, dyn=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -56,8 +62,11 @@ def _worker(rank, world, port, H, W, fw, path, burn=0.0, direct=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out, _, _, _ = _render(rank, world, H, W, fw, burn, direct)
+        out, proc, _, _ = _render(rank, world, H, W, fw, burn, direct, dyn)
         np.save(f"{path}.{rank}.npy", out)
+        if dyn:
+            rng = proc.ctx.frame_exposure_range()
+            np.save(f"{path}.{rank}.packed.npy", np.array([rng["armed"], rng["twelve_byte_element"], rng["min"], rng["max_abs"]], dtype=np.float64))
     finally:
         dist.destroy_process_group()
 
@@ -237,6 +246,35 @@ def test_two_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
     proc.ctx.set_option("stencil_fft_scratch96_auto", 1)
     ref12, _ = proc.ctx.render(img, params)  # ... and r2f_render's own choice agrees to the 12-byte element's rounding
     assert np.max(np.abs(ref12.cpu().numpy() - whole) / np.maximum(np.abs(whole), 1e-3)) <= 2e-6
+
+
+def test_row_shards_choose_the_halation_scratch_element_like_the_whole_frame(tmp_path):
+    """Round 6: the row-sharded renderer IS the headline renderer.  Its front calls record the range of the
+    exposure rows they write, the received halo rows are added by r2f_stage_exposure_range, and the halation calls vouch for the
+    record (R2F_F_RANGE_VALID) -- so the FFT passes choose their scratch element on the device exactly like r2f_render's.
+    One rank: the same kernels on the same windows with the same element -- bit-identical to r2f_render's default frame.
+    Two ranks: each chooses from ITS rows' range (rank-local: the bound is per window); the frames agree to the element's rounding."""
+    import torch.multiprocessing as mp
+
+    H, W, fw = 420, 256, 1.0  # 65-tap halation, 27-tap MTF; shards of 210 rows
+    whole, proc, params, img = _render(0, 1, H, W, fw, dyn=True)
+    rng = proc.ctx.frame_exposure_range()
+    assert rng["armed"] and rng["twelve_byte_element"], rng
+    ref, _ = proc.ctx.render(img, params)  # r2f_render's own choice
+    assert proc.ctx.frame_exposure_range()["twelve_byte_element"]
+    np.testing.assert_array_equal(whole, ref.cpu().numpy())
+    proc.ctx.set_option("stencil_fft_scratch96_auto", 0)
+    exact, _ = proc.ctx.render(img, params)
+    assert not np.array_equal(exact.cpu().numpy(), whole)  # (it is the other element)
+    proc.close()
+    path = str(tmp_path / "shard")
+    mp.spawn(_worker, args=(2, _free_port(), H, W, fw, path, 0.0, False, True), nprocs=2, join=True)
+    sharded = np.concatenate([np.load(f"{path}.{r}.npy") for r in range(2)])
+    assert np.max(np.abs(sharded - whole) / np.maximum(np.abs(whole), 1e-3)) <= 2e-6
+    for r in range(2):
+        armed, packed, lo, hi = np.load(f"{path}.{r}.packed.npy")
+        assert armed and packed, (r, lo, hi)
+        assert lo >= rng["min"] and hi <= rng["max_abs"]  # a rank's record is a sub-range of the frame's
 
 
 def test_four_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):

@@ -33,11 +33,12 @@ def test_two_copies_of_the_library_render_side_by_side(tmp_path):
     addr = lambda lib: C.cast(lib.r2f_render, C.c_void_p).value  # noqa: E731
     assert addr(a.ctx._lib) != addr(b.ctx._lib)
     outs = {id(a): [], id(b): []}
+    bufs = {id(p): torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for p in (a, b)}  # the same buffers every frame
     for i in range(4):  # interleaved: eager, capture + replay, replay, replay in each copy
         for p in (a, b):
-            o = p.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=SEED + i, return_float=True, output="device", **kw)
-            outs[id(p)].append(o.clone())
-            del o
+            p.process_array(frame, neg, 6, 0.4, colorspace="linear-rec709", seed=SEED + i, return_float=True, output="device",
+                            out=bufs[id(p)], **kw)
+            outs[id(p)].append(bufs[id(p)].clone())
     for x, y in zip(outs[id(a)], outs[id(b)]):
         assert torch.equal(x, y)
     assert not torch.equal(outs[id(a)][0], outs[id(a)][1])
