@@ -161,7 +161,13 @@ def main():
                     help="nccl = RCCL (the measured configuration); gloo + --same-device validates the N > 1 code path on one GPU")
     ap.add_argument("--same-device", action="store_true", help="validation only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parse-only", action="store_true",
+                    help="print the parsed arguments as JSON and exit without touching torch or the GPU (tests/test_bench_host.py checks "
+                         "the command lines of tools/first_multi_gpu.sh with it)")
     args = ap.parse_args()
+    if args.parse_only:
+        print(json.dumps(vars(args)))
+        return
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before HIP initialises
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -728,8 +734,19 @@ def main():
             t0 = time.perf_counter()
             res = proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + 10 + i, lens_correction=False, **settings)
             e2e.append((time.perf_counter() - t0) * 1e3)
-        proc.result_buffers = 0
         copies["process_end_to_end_pinned_result_ms"] = min(e2e)
+        # where that call's time goes: one more call with a device synchronisation behind every stage
+        # (HipProcessor.profile_stages -- a measuring mode: its total is a little above the un-profiled call's)
+        proc.profile_stages = True
+        proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + 20, lens_correction=False, **settings)
+        proc.profile_stages = False
+        copies["process_stage_ms"] = {k: round(float(v), 3) for k, v in proc.last_stage_ms.items()}
+        copies["process_stage_note"] = ("HipProcessor.process(host ndarray, cache=False, result_buffers=2) with a synchronisation behind each stage: "
+                                        "host_phase = extract_image_data_cpu (views and index arithmetic; cache=False skips the 32-row checksum "
+                                        "that cost ~4 ms in round 5), upload_and_device_prepath = the fp32 frame over PCIe + the clamp of "
+                                        "gpu_processor.py:275 on the device, prepare_and_render = table checks + r2f_render, download = uint8 "
+                                        "result into a pinned buffer; load_and_upload = the first two together")
+        proc.result_buffers = 0
         gb = H * W * 3 / 1e9
         copies["GB_per_s"] = {"h2d_f32": 4 * gb / (copies["h2d_f32_ms"] * 1e-3), "h2d_u16": 2 * gb / (copies["h2d_u16_ms"] * 1e-3),
                               "d2h_u8": gb / (copies["d2h_u8_ms"] * 1e-3)}

@@ -89,6 +89,16 @@ struct FrameParams {
 };
 constexpr uint32_t kFrameMinReset = 0x7f800000u, kFrameMaxReset = 0u;
 
+// One wave's (lo, hi) merged into the block's exposure range.  Thousands of waves end here, and atomics on ONE address serialise in
+// the L2 (a 59-row front call of a row shard spent 0.1 ms of its ~5 us in them: 3 072 waves x 2): a wave looks first and only
+// sends the atomic that can still move the extreme -- after the first few waves almost none can.  The look may be stale; the record
+// only ever moves one way (min down, max up), so a stale value can cost an atomic that was not needed, never lose one that was.
+__device__ __forceinline__ void merge_range(FrameParams* blk, float lo, float hi) {
+    const int ilo = __float_as_int(lo), ihi = __float_as_int(hi);
+    if (ilo < __atomic_load_n(reinterpret_cast<int*>(&blk->e_min), __ATOMIC_RELAXED)) atomicMin(reinterpret_cast<int*>(&blk->e_min), ilo);
+    if (ihi > __atomic_load_n(reinterpret_cast<int*>(&blk->e_max), __ATOMIC_RELAXED)) atomicMax(reinterpret_cast<int*>(&blk->e_max), ihi);
+}
+
 // ---------------------------------------------------------------------------- streaming accesses
 // Non-temporal 16-byte accesses for frame-sized buffers that are written once and read back a stage later (1.2 GB per plane set
 // at 100 MP, far beyond the 256 MB Infinity Cache).  On MI355X a float4 copy runs 6.57 TB/s that way against 6.23 with plain loads

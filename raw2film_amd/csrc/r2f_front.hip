@@ -270,16 +270,13 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             o32[2] = u8_of(b[2]) | (u8_of(r[3]) << 8) | (u8_of(g[3]) << 16) | (u8_of(b[3]) << 24);
         }
     }
-    if (track) {  // one pair of atomics per wave (a persistent grid: a few thousand per frame)
+    if (track) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             t_lo = fminf(t_lo, __shfl_xor(t_lo, m));
             t_hi = fmaxf(t_hi, __shfl_xor(t_hi, m));
         }
-        if (threadIdx.x == 0) {
-            atomicMin(reinterpret_cast<int*>(&a.track->e_min), __float_as_int(t_lo));
-            atomicMax(reinterpret_cast<int*>(&a.track->e_max), __float_as_int(t_hi));
-        }
+        if (threadIdx.x == 0) merge_range(a.track, t_lo, t_hi);
     }
 }
 

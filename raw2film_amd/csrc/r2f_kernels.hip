@@ -1359,10 +1359,7 @@ __global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src
         lo = fminf(lo, __shfl_xor(lo, m));
         hi = fmaxf(hi, __shfl_xor(hi, m));
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(reinterpret_cast<int*>(&dst->e_min), __float_as_int(lo));
-        atomicMax(reinterpret_cast<int*>(&dst->e_max), __float_as_int(hi));
-    }
+    if ((threadIdx.x & 63) == 0) merge_range(dst, lo, hi);
 }
 
 hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int W, int mask, FrameParams* dst, hipStream_t s) {

@@ -350,6 +350,14 @@ class HipProcessor:
             self._check_texture(dst_texture, "dst_texture")
         if histogram_texture is not None:
             self._check_texture(histogram_texture, "histogram_texture")
+        # profile_stages (bench.py's host_device_copies): wall clock per stage of this call, with a device synchronisation behind
+        # each -- a measuring mode (the syncs serialise what otherwise overlaps), off by default
+        prof = getattr(self, "profile_stages", False)
+        if prof:
+            import time
+
+            self._torch.cuda.synchronize(self.device)
+            t_start = time.perf_counter()
         # GpuProcessor.load_image_texture (gpu_processor.py:655-719): the pre-processed frame stays on the device while the
         # load parameters do not change -- a re-render with other film settings neither prepares nor uploads it again
         self.load_image_texture(
@@ -358,6 +366,9 @@ class HipProcessor:
             src_version=src_version,
         )
         image, layout, payload = self._texture
+        if prof:
+            self._torch.cuda.synchronize(self.device)
+            t_loaded = time.perf_counter()
         out_u8 = self._render_prepared(
             image, layout, payload, negative_film, grain_size, grain_sigma, dst_texture, histogram_texture, "cpu",
             print_film=print_film, exp_comp=exp_comp,
@@ -371,7 +382,17 @@ class HipProcessor:
             highlight_burn=highlight_burn, burn_scale=burn_scale, color_masking=color_masking, seed=seed,
             canvas_mode=canvas_mode, canvas_scale=canvas_scale, canvas_ratio=canvas_ratio,
         )
-        return None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
+        if prof:
+            self._torch.cuda.synchronize(self.device)
+            t_rendered = time.perf_counter()
+        res = None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
+        if prof:
+            t_end = time.perf_counter()
+            self.last_stage_ms = {"load_and_upload": (t_loaded - t_start) * 1e3, "prepare_and_render": (t_rendered - t_loaded) * 1e3,
+                                  "download": (t_end - t_rendered) * 1e3, "total": (t_end - t_start) * 1e3,
+                                  **{k: v for k, v in (getattr(self, "_load_stage_ms", None) or {}).items()}}
+            self._load_stage_ms = None
+        return res
 
     def load_image_texture(self, src, cam=None, lens=None, lens_correction=True, frame_width=36, frame_height=24, rotation=0.0,
                            zoom=1.0, rotate_times=0, flip=False, resolution=None, half_size=True, cache=True, chroma_nr=0,
@@ -388,6 +409,11 @@ class HipProcessor:
             src_key = src
         elif src_version is not None:
             src_key = (getattr(src, "shape", None), str(getattr(src, "dtype", "")), "version", src_version)
+        elif not cache:
+            # cache=False uploads whatever the fingerprint says: its pass over 32 rows (4.7 MB of a 100 MP frame, ~4 ms of crc32 --
+            # the unexplained part of process(host array)'s 35 ms in round 5) is skipped, and nothing is recorded that a later
+            # cache=True call could take for "the same frame"
+            src_key = None
         else:
             src_key = self._array_fingerprint(src)
         new_param_dict = {
@@ -402,15 +428,25 @@ class HipProcessor:
         same_src = isinstance(src, str) or (held is not None and held() is src)
         if cache and same_src and getattr(self, "_texture", None) is not None and new_param_dict == getattr(self, "image_param_dict", None):
             return
+        prof = getattr(self, "profile_stages", False)
+        if prof:
+            import time
+
+            t0 = time.perf_counter()
         cpu_payload = self.extract_image_data_cpu(
             src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
             half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
             _internal=True,
         )
+        if prof:
+            t1 = time.perf_counter()
         self.prepare_gpu_textures(cpu_payload)
-        self.image_param_dict = new_param_dict
+        if prof:
+            self._torch.cuda.synchronize(self.device)
+            self._load_stage_ms = {"host_phase": (t1 - t0) * 1e3, "upload_and_device_prepath": (time.perf_counter() - t1) * 1e3}
+        self.image_param_dict = new_param_dict if (src_key is not None or isinstance(src, str)) else None
         self._texture_src = None
-        if not isinstance(src, str):
+        if not isinstance(src, str) and src_key is not None:
             import weakref
 
             try:

@@ -341,6 +341,21 @@ class RowShardedRenderer:
         # render() (device backends only).  Tests of the tuning protocol itself inject a clock of their own (CPU backends, gloo).
         self._frame_timer = frame_timer
         can_measure = frame_timer is not None or (getattr(backend, "device", None) is not None and torch.cuda.is_available())
+        if self.tune_frames < 0:
+            raise ValueError("tune_frames must be >= 0 (0: no measuring, the first candidate runs)")
+        # The ranks walk the candidate list in lockstep (one all-reduce per decision, and the two-exchange form needs both
+        # neighbours to play along): a list that differs between ranks would deadlock in a collective much later -- compare a hash
+        # of it once, here, and fail on every rank at once
+        if cands and world > 1 and dist.is_available() and dist.is_initialized() and type(self)._exchange is RowShardedRenderer._exchange:
+            import hashlib
+
+            h = float(int.from_bytes(hashlib.sha256(repr((cands, H, W, world)).encode()).digest()[:6], "big"))  # 48 bits: exact in fp64
+            dev = backend.device if (getattr(backend, "device", None) is not None and dist.get_backend(group) != "gloo") else "cpu"
+            both_ends = torch.tensor([h, -h], dtype=torch.float64, device=dev)
+            dist.all_reduce(both_ends, op=dist.ReduceOp.MAX, group=group)
+            if float(both_ends[0]) != -float(both_ends[1]):
+                raise RuntimeError(f"rank {rank}: the ranks derived different candidate schedules {cands} for this frame "
+                                   "(different stencils, options or library builds across the ranks?)")
         if len(cands) > 1 and can_measure and self.tune_frames > 0:
             self._tune = {"i": 0, "n": -1, "ms": [[] for _ in cands]}
             self._set_schedule(cands[0])
@@ -371,7 +386,10 @@ class RowShardedRenderer:
         """One frame of the measuring phase: rendered kernel by kernel under the current candidate, timed between two events on the
         launch stream (exchange included); moves on to the next candidate / to the decision when this one has its frames."""
         torch, t = self.torch, self._tune
-        if t["n"] < 0:  # the very first frame builds tables, spectra and scratch: not timed
+        if t["n"] < 0:
+            # the first frame of EVERY candidate is not timed: the very first builds tables, spectra and scratch, and a later
+            # candidate's first frame may still meet a window shape of its own (a spectrum upload, a larger scratch -- both
+            # synchronise), which would bias the choice towards candidate 0 whenever tune_frames is 1 (ADVICE r5)
             t["n"] = 0
             return self._render_eager(image_rows, out_f32, out_u8)
         if self._frame_timer is not None:
@@ -379,16 +397,18 @@ class RowShardedRenderer:
             ms = self._frame_timer(self._candidates[t["i"]], lambda: box.append(self._render_eager(image_rows, out_f32, out_u8)))
             res = box[0]
         else:
+            # on the stream the launches go to: the backend's device's current stream (torch's current DEVICE may be another one)
+            stream = torch.cuda.current_stream(self.backend.device)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            a.record(stream)
             res = self._render_eager(image_rows, out_f32, out_u8)
-            b.record()
+            b.record(stream)
             b.synchronize()
             ms = a.elapsed_time(b)
         t["ms"][t["i"]].append(float(ms))
         t["n"] += 1
         if t["n"] >= self.tune_frames:
-            t["i"], t["n"] = t["i"] + 1, 0
+            t["i"], t["n"] = t["i"] + 1, -1
             if t["i"] < len(self._candidates):
                 self._set_schedule(self._candidates[t["i"]])
             else:
@@ -538,7 +558,6 @@ class RowShardedRenderer:
                 if whole:
                     def everything():
                         self._exchange_finish(self._front_and_start_exchange(image_rows))
-                        self._halo_range()
                         self._halation_interior()
                         self._after_exchange(out_f32, out_u8, None)
                     graphs["a"] = capture(everything)
@@ -567,7 +586,6 @@ class RowShardedRenderer:
             graphs["pre"].replay()
         self._note("exchange_finish")
         self._exchange_finish(pending)
-        self._halo_range()
         if mid_exchange:
             if graphs["a"] is not None:
                 self._note("replay:density")
@@ -587,7 +605,6 @@ class RowShardedRenderer:
             pending = self._front_and_start_exchange(image_rows)
         self._halation_interior()
         self._exchange_finish(pending)
-        self._halo_range()
         return self._after_exchange(out_f32, out_u8, None)
 
     def _note(self, what):
@@ -628,7 +645,6 @@ class RowShardedRenderer:
         self._halation_interior()
         self._note("exchange_finish")
         self._exchange_finish(pending)
-        self._halo_range()
         return self._after_exchange(out_f32, out_u8, field_ready)
 
     def _front_and_start_exchange(self, image_rows):
@@ -722,6 +738,9 @@ class RowShardedRenderer:
         H = p.H
         if not self.halation:
             return
+        # the halo rows that have just arrived join the exposure-range record, ahead of the launches that choose from it (part of
+        # the captured graph: two small launches whose issue would otherwise sit between the exchange and the replay)
+        self._halo_range()
         kw = {"identity_done": self._identity_done} if self._identity_done else {}
         if self._dyn:  # the frame block's range covers every row of the buffer handed over (_e_rows, _halo_range)
             kw["range_valid"] = True

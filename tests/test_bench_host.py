@@ -47,3 +47,32 @@ def test_self_launch_command_line(monkeypatch):
     assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+
+
+def test_the_command_lines_of_the_first_multi_gpu_script_parse():
+    """tools/first_multi_gpu.sh is written for a machine nobody has had yet (more than one MI355X): every bench.py command line in
+    it must at least be one bench.py's argument parser accepts (bench.py --parse-only: no torch, no GPU), for every N it loops
+    over, and the script must be valid bash."""
+    import json
+    import re
+    import shutil
+
+    script = os.path.join(ROOT, "tools", "first_multi_gpu.sh")
+    text = open(script).read()
+    bash = shutil.which("bash")
+    if bash:
+        assert subprocess.run([bash, "-n", script], capture_output=True, text=True).returncode == 0
+    lines = [ln.strip() for ln in text.splitlines() if re.match(r"\s*python bench\.py ", ln)]
+    assert len(lines) == 2
+    seen = set()
+    for ln in lines:
+        cmd = ln.split(" 2>")[0].split()[2:]  # the arguments, without the redirections
+        for n in (1, 2, 4, 8):
+            argv = [a.replace("$N", str(n)) for a in cmd] + ["--parse-only"]
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=60, cwd=ROOT)
+            assert res.returncode == 0, (argv, res.stderr[-500:])
+            parsed = json.loads(res.stdout)
+            assert parsed["gpus"] == n and parsed["config"] == "cfg4_100mp" and parsed["backend"] == "nccl" and parsed["no_cpu_baseline"]
+            seen.add((n, parsed["checksum"]))
+    assert seen == {(n, c) for n in (1, 2, 4, 8) for c in (True, False)}
+    assert "tests/test_gpu_multi.py" in text and "measured_ms_max_over_ranks" in text and "rccl_ranks" in text

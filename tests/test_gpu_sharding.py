@@ -107,6 +107,8 @@ def _worker_graph(rank, world, port, H, W, fw, path):
             graphed.render(img, out_f32=out_g, seed=seed)
             assert torch.equal(out_g, out_e), (rank, k)
             if k >= 1:  # captured on the second frame, replayed from then on -- a new seed costs no graph
+                # (the received halo rows join the exposure-range record INSIDE the graph downstream of the exchange, ahead of the
+                # halation launches that choose their scratch element from it)
                 assert graphed.trace == ["exchange_start", "replay:halation_interior", "exchange_finish", "replay:after_exchange"] or \
                     graphed.trace[:1] == ["exchange_start"] and graphed.trace[-3:] == ["replay:halation_interior", "exchange_finish", "replay:after_exchange"], graphed.trace
             frames.append(out_g.cpu().numpy().copy())
@@ -192,7 +194,7 @@ def _worker_schedules(rank, world, port, H, W, fw, path):
             frames += 1
             assert float(((out_g - out_e.new_tensor(np.load(f"{path}.two.{rank}.npy"))).abs()
                           / out_e.new_tensor(np.load(f"{path}.two.{rank}.npy")).abs().clamp_min(1e-3)).max()) <= 2e-6, frames
-        assert frames == 1 + auto.tune_frames * len(auto._candidates)
+        assert frames == (1 + auto.tune_frames) * len(auto._candidates)  # (one untimed frame ahead of every candidate's timed ones)
         assert auto.schedule[0] in (1, 2) and len(auto.tuned_ms) == len(auto._candidates) and all(t > 0 for t in auto.tuned_ms)
         chosen = torch.tensor([auto.schedule[0] * 2 + int(auto.schedule[1])])
         both = [torch.zeros_like(chosen) for _ in range(world)]

@@ -412,7 +412,8 @@ def _tuning_worker(rank, world, port, H, W, scale, result_path):
             rr.render(torch.from_numpy(img[r0:r1].copy()), out_f32=out)
             frames += 1
             np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=2e-6)
-        assert frames == 1 + 2 * 3 and seen == [(1, False)] * 2 + [(1, True)] * 2 + [(2, False)] * 2, (frames, seen)
+        # (one untimed frame ahead of every candidate's two timed ones: its first frame may still build a spectrum or grow the scratch)
+        assert frames == 3 * (1 + 2) and seen == [(1, False)] * 2 + [(1, True)] * 2 + [(2, False)] * 2, (frames, seen)
         assert rr.schedule == (2, False) and not rr.single_exchange, rr.schedule
         assert [round(t, 2) for t in rr.tuned_ms] == [5.01, 6.03, 4.55], rr.tuned_ms  # the MAX over the ranks of each rank's best frame
         rr.trace = []

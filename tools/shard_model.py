@@ -54,7 +54,9 @@ SCHEDULES = (("1 exchange, halation in one call", dict(exchanges=1, split_halati
 
 
 def run(n, rank, graph, kw):
-    rr = NoTransport(be, H, W, halation=True, mtf=True, rank=rank, world=n, graph=graph, **kw)
+    # (R2F_SHARD_DYN=0: A/B without the exposure-range record -- the halation keeps complex128 scratch whatever the rows hold)
+    rr = NoTransport(be, H, W, halation=True, mtf=True, rank=rank, world=n, graph=graph,
+                     dyn_scratch=os.environ.get("R2F_SHARD_DYN", "1") != "0", **kw)
     rows = rr.plan.rows
     frame = synthetic_frame_device(rows, W, seed=n)
     out = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
