@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="cfg5_batch: frames per step, dealt round-robin to the ranks")
     ap.add_argument("--frame", default="noise", choices=["noise", "smooth"],
                     help="synthetic frame statistics: independent pixels (headline; worst case for the LUT gathers) or photograph-like")
+    ap.add_argument("--clamp", default="",
+                    help="lo,hi: clamp the synthetic frame's samples (NOT the headline input: a frame whose exposure range the guard of "
+                         "the halation's 12-byte FFT scratch element accepts, e.g. 0.004,48 -- the labelled second capture of tools/profile_round.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone", action="store_true",
                     help="skip the two extra steps that time the dominant FFT pass with one internal stream (tools/profile_round.sh: "
@@ -249,6 +252,9 @@ def main():
         del whole_frame
     else:
         frame = synthetic_frame_device(r1 - r0, W, seed=1234 + rank, device=f"cuda:{local_rank}", kind=args.frame)
+    if args.clamp:
+        c_lo, c_hi = (float(v) for v in args.clamp.split(","))
+        frame.clamp_(c_lo, c_hi)
     out_u8 = args.output == "u8"
     if out_u8 and not use_processor:
         raise SystemExit("--output u8 is measured through HipProcessor.process_array: one GPU, a frame configuration")
@@ -341,7 +347,8 @@ def main():
         "vs_baseline": None,
         "dtype": ("f32" if args.direct_stencils or not effects else
                   "f32 (pointwise stages, grain) + f64 (FFT stencils; the MTF's scratch images are complex64)"),
-        "data": "synthetic" if args.frame == "noise" else "synthetic (smooth, photograph-like frame: not the headline input)",
+        "data": ("synthetic" if args.frame == "noise" else "synthetic (smooth, photograph-like frame: not the headline input)")
+                + (f" (samples clamped to [{args.clamp}]: not the headline input)" if args.clamp else ""),
         "config": {
             "workload": f"{args.config}: " + (f"{args.frames} x " if batch else "") + f"{W}x{H} ({H * W / 1e6:.1f} MP) decoded linear-Rec.709 "
                         "frame, 36x24 mm, " + (f"full pipeline S0-S8: {full}" if effects else "LUTs only (S0+S1+S3+S4+S8), effects off")
@@ -491,7 +498,7 @@ def main():
     traffic_rec = None
     captures = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{args.config}_hbm_traffic.json")))  # latest round last
     tfile = captures[-1] if captures else ""
-    if tfile and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain and not out_u8:
+    if tfile and world == 1 and not args.opt and not args.direct_stencils and not args.side_grain and not out_u8 and not args.clamp:
         rec = json.load(open(tfile))
         meta = rec.get("_meta", {})
         match = meta.get("source_hash") == source_hash() and meta.get("config") == args.config and meta.get("frame") == args.frame

@@ -204,10 +204,11 @@ R2F_API int r2f_stage_front(r2f_ctx* ctx, const r2f_params* p, const void* in, i
 R2F_API int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void* in, int in_layout, int in_gy0, int in_rows,
                           const r2f_planes* exposure, const r2f_planes* density, int y0, int y1, int W, int H_global,
                           int* finished_mask, void* stream);
-/* A row shard's half of r2f_render's exposure-range record: min and max |.| of rows [y0, y1) of `exposure` (the channels whose
- * halation stencil takes the FFT form) merged into the context's frame block, in stream order -- for the halo rows a rank received
- * from its neighbours (its own rows are recorded by the front kernel, R2F_F_TRACK_RANGE).  Nothing upstream corresponds to it. */
-R2F_API int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int W, void* stream);
+/* A row shard's half of r2f_render's exposure-range record: min and max |.| of rows [y0, y1) and [y2, y3) of `exposure` (the
+ * channels whose halation stencil takes the FFT form) merged into the context's frame block, in stream order -- for the halo rows a
+ * rank received from its neighbours above and below, in one launch (an empty range is skipped; its own rows are recorded by the
+ * front kernel, R2F_F_TRACK_RANGE).  Nothing upstream corresponds to it. */
+R2F_API int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int y2, int y3, int W, void* stream);
 /* S2 halation stencil on exposure + S3 log + S4 curve -> density planes.  With R2F_F_RANGE_VALID the FFT passes choose their
  * scratch element on the device from the frame block's range (see r2f_render); without it they keep complex128. */
 R2F_API int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,

@@ -85,7 +85,7 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
-    "r2f_stage_exposure_range": (C.c_int, [C.c_void_p, _P(Planes), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "r2f_stage_exposure_range": (C.c_int, [C.c_void_p, _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "r2f_stage_mtf": (
         C.c_int,
         [C.c_void_p, _P(Params), _P(Planes), _P(Planes), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],

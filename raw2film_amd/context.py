@@ -300,13 +300,14 @@ class HipContext:
             raise ValueError("source and destination widths differ")
         self._check(fn(self._h, first, C.byref(ps), C.byref(pd), y0, y1, W, H_global, self._stream()))
 
-    def stage_exposure_range(self, exposure, *, src_gy0=0, y0, y1):
-        """Merge min / max |.| of rows [y0, y1) of the exposure planes (the halation's FFT channels) into the frame block: the halo
-        rows a row shard received (r2f_stage_exposure_range)."""
-        if y1 <= y0:
+    def stage_exposure_range(self, exposure, *, src_gy0=0, y0, y1, y2=0, y3=0):
+        """Merge min / max |.| of rows [y0, y1) and [y2, y3) of the exposure planes (the halation's FFT channels) into the frame block:
+        the halo rows a row shard received from above and below, one launch (r2f_stage_exposure_range)."""
+        if y1 <= y0 and y3 <= y2:
             return
         pe = self.planes(exposure, src_gy0)
-        self._check(self._lib.r2f_stage_exposure_range(self._h, C.byref(pe), int(y0), int(y1), int(exposure.shape[2]), self._stream()))
+        self._check(self._lib.r2f_stage_exposure_range(self._h, C.byref(pe), int(y0), int(y1), int(y2), int(y3), int(exposure.shape[2]),
+                                                       self._stream()))
 
     def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global, identity_done=0, range_valid=False):
         """range_valid: the caller vouches that the frame block's range covers every row `exposure` holds (R2F_F_RANGE_VALID): the

@@ -1250,12 +1250,14 @@ int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* expo
                        static_cast<hipStream_t>(stream), (p->flags & R2F_F_IDENTITY_DONE) != 0, (p->flags & R2F_F_RANGE_VALID) != 0);
 }
 
-int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int W, void* stream) {
+int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int y2, int y3, int W, void* stream) {
     if (!ctx) return R2F_EINVAL;
     R2F_GUARD(ctx);
-    if (y1 <= y0) return R2F_OK;
+    if (y1 <= y0 && y3 <= y2) return R2F_OK;
     if (W <= 0) return fail(ctx, R2F_EINVAL, "exposure range: bad geometry");
-    int rc = check_rows(ctx, "exposure range", exposure, y0, y1);
+    int rc = y1 > y0 ? check_rows(ctx, "exposure range", exposure, y0, y1) : R2F_OK;
+    if (rc) return rc;
+    rc = y3 > y2 ? check_rows(ctx, "exposure range", exposure, y2, y3) : R2F_OK;
     if (rc) return rc;
     int mask = 7;  // the channels the halation's FFT passes read: not the single-tap ones (as the front kernel records them)
     if (ctx->stencil[R2F_KERNEL_HALATION].present) {
@@ -1263,7 +1265,7 @@ int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, i
         for (int c = 0; c < 3; ++c)
             if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &w)) mask &= ~(1 << c);
     }
-    R2F_HIP(ctx, launch_exposure_range(to_dev(exposure), y0, y1, W, mask, static_cast<FrameParams*>(ctx->frame_buf.p),
+    R2F_HIP(ctx, launch_exposure_range(to_dev(exposure), y0, y1, y2, y3, W, mask, static_cast<FrameParams*>(ctx->frame_buf.p),
                                        static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }

@@ -216,6 +216,12 @@ __device__ __forceinline__ void curve_eval_batch(CellPtr cells_base, const DevCu
     }
 }
 
+#ifndef R2F_FFT_EPI2
+// Round 6, the exact part of a leaner pass-3 epilogue (r2f_fft.hip): the transforms' 1 / (ny nx) lives in the
+// kernel spectrum (one multiply per spectrum element at build time instead of one fp64 multiply per OUTPUT: 32 per lane and line),
+// and the cell index is clamped with one v_med3_i32 below.  Bit-identical results.  0 = round 5's form (A/B).
+#define R2F_FFT_EPI2 1
+#endif
 // curve_eval_batch for ONE channel of a `near` curve whose cells sit in LDS (the epilogue of FFT pass 3: 32 evaluations per lane
 // next to a transform of ~950 instructions, so every instruction here counts).  Same arithmetic, same results; leaner control: the
 // common case tests only "x outside its guessed cell" (2 compares), the neighbour logic runs when some lane of the wave needs it.
@@ -227,7 +233,13 @@ __device__ __forceinline__ void curve_eval_near_lds(const float4* cells, const D
     float4 c[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
+#if R2F_FFT_EPI2
+        // clamp to [0, last] in one instruction (last >= 0; the compiler cannot know and builds clampi from a compare, a select and a min)
+        const int raw = (int)((x[k] - cv.x0) * cv.inv_step);
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(idx[k]) : "v"(raw), "v"(last));
+#else
         idx[k] = clampi((int)((x[k] - cv.x0) * cv.inv_step), 0, last);
+#endif
         c[k] = cells[idx[k]];
     }
     bool off = false;

@@ -82,81 +82,6 @@ __device__ __forceinline__ void fft256(cplx (&v)[16], const cplx w1, double* tbu
     dft16<INV>(v);
 }
 
-// fft256 for the column walk (pass 2), the same arithmetic in the same order -- bit-identical results -- around ONE LDS round trip
-// instead of two, with the round trip under the butterflies (a hand-placed schedule for the one pass that is
-// not at its bytes).  fft256 sends the real parts through a wave-private tile, waits, reads them back, then the imaginary parts
-// through the same tile: four exposed LDS latencies per transform with nothing else for the wave to issue, at two waves per SIMD.
-// Here the tile holds complex values (double2, 17-pitch: conflict-free for 16-byte accesses both ways; twice the LDS, which pass 2's
-// two workgroups per CU can afford: 2 x 69.6 KB) and the transform is cut where its data flow allows:
-//   * the first DFT-16's second stage yields its outputs four at a time (k = r, r + 4, r + 8, r + 12 from group r): each group is
-//     twiddled and WRITTEN while the next group's butterflies issue (a sched_barrier per group keeps the compiler from collecting
-//     the writes at the end);
-//   * the reads come back in the order the second DFT-16's first stage consumes them (j = c, c + 4, c + 8, c + 12), so its first
-//     butterflies start when 4 of the 16 reads have landed (LDS returns in order; the waits are counted).
-// The twiddle powers are the same products as twiddle_powers' (same tree, same roundings), taken in the order the groups need them.
-#ifndef R2F_FFT_PIPE
-#define R2F_FFT_PIPE 1
-#endif
-constexpr int kTLineC = 16 * kTPitch;  // 272 double2 per line of the complex tile
-template <bool INV>
-__device__ __forceinline__ void fft256_pipe(cplx (&v)[16], const cplx w1, cplx* tbuf, int lane) {
-    constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
-    const int l = lane & 15;
-    cplx* t = tbuf + (lane >> 4) * kTLineC;
-    // ---- first DFT-16, stage 1 and its internal twiddles (dft16 of r2f_fft_math.h, verbatim)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4<INV>(v[c], v[c + 4], v[c + 8], v[c + 12]);
-    v[1 + 4] = ctw<INV>(v[1 + 4], make_double2(c1, -s1));
-    v[1 + 8] = ctw<INV>(v[1 + 8], make_double2(h, -h));
-    v[1 + 12] = ctw<INV>(v[1 + 12], make_double2(s1, -c1));
-    v[2 + 4] = ctw<INV>(v[2 + 4], make_double2(h, -h));
-    v[2 + 8] = ctw<INV>(v[2 + 8], make_double2(0.0, -1.0));
-    v[2 + 12] = ctw<INV>(v[2 + 12], make_double2(-h, -h));
-    v[3 + 4] = ctw<INV>(v[3 + 4], make_double2(s1, -c1));
-    v[3 + 8] = ctw<INV>(v[3 + 8], make_double2(-h, -h));
-    v[3 + 12] = ctw<INV>(v[3 + 12], make_double2(-c1, s1));
-    // ---- the powers of w1 (twiddle_powers' tree), the ones groups 0 and 1 need first
-    const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3),
-               w8 = cmul(w4, w4);
-    // ---- stage 2 group by group: dft4 over v[4 r .. 4 r + 3] leaves out[r + 4 s] in v[4 r + s]; row k of the tile takes out[k] w1^k
-    dft4<INV>(v[0], v[1], v[2], v[3]);
-    t[0 * kTPitch + l] = v[0];
-    t[4 * kTPitch + l] = ctw<INV>(v[1], w4);
-    t[8 * kTPitch + l] = ctw<INV>(v[2], w8);
-    t[12 * kTPitch + l] = ctw<INV>(v[3], cmul(w6, w6));
-    __builtin_amdgcn_sched_barrier(0);
-    dft4<INV>(v[4], v[5], v[6], v[7]);
-    t[1 * kTPitch + l] = ctw<INV>(v[4], w1);
-    t[5 * kTPitch + l] = ctw<INV>(v[5], w5);
-    t[9 * kTPitch + l] = ctw<INV>(v[6], cmul(w8, w1));
-    t[13 * kTPitch + l] = ctw<INV>(v[7], cmul(w8, w5));
-    __builtin_amdgcn_sched_barrier(0);
-    dft4<INV>(v[8], v[9], v[10], v[11]);
-    t[2 * kTPitch + l] = ctw<INV>(v[8], w2);
-    t[6 * kTPitch + l] = ctw<INV>(v[9], w6);
-    t[10 * kTPitch + l] = ctw<INV>(v[10], cmul(w5, w5));
-    t[14 * kTPitch + l] = ctw<INV>(v[11], cmul(w7, w7));
-    __builtin_amdgcn_sched_barrier(0);
-    dft4<INV>(v[12], v[13], v[14], v[15]);
-    t[3 * kTPitch + l] = ctw<INV>(v[12], w3);
-    t[7 * kTPitch + l] = ctw<INV>(v[13], w7);
-    t[11 * kTPitch + l] = ctw<INV>(v[14], cmul(w8, w3));
-    t[15 * kTPitch + l] = ctw<INV>(v[15], cmul(w8, w7));
-    __builtin_amdgcn_wave_barrier();
-    // ---- the transposed values, in the order the second DFT-16's first stage takes them
-    const cplx* rd = t + l * kTPitch;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        v[c] = rd[c];
-        v[c + 4] = rd[c + 4];
-        v[c + 8] = rd[c + 8];
-        v[c + 12] = rd[c + 12];
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (all sixteen reads are out before the first butterfly; the waits on them are counted)
-    __builtin_amdgcn_wave_barrier();
-    dft16<INV>(v);
-}
-
 // A lane's double moved to / from its neighbour lane ^ 1 (DPP quad_perm [1, 0, 3, 2], no LDS).
 __device__ __forceinline__ double swap_lane1(double x) {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);
@@ -562,12 +487,14 @@ __device__ __forceinline__ void fft_cols_body(const FftConvArgs& a, const int mo
     double* tbuf = wave_tbuf(fsm);
     fft256<false>(v, w1, tbuf, lane);
     if (mode == 1) {
+        // the spectrum carries the transforms' 1 / (ny nx) (a power of two: exact), so pass 3 rounds what it reads (R2F_FFT_EPI2)
+        const double sc = R2F_FFT_EPI2 ? 1.0 / ((double)kN * (NBX * 16)) : 1.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (KR)
-                rat(a.kf_out, sidx(l + 16 * q, k, NBX)) = v[q].x;  // (the imaginary part of a centred symmetric kernel's spectrum is rounding noise)
+                rat(a.kf_out, sidx(l + 16 * q, k, NBX)) = v[q].x * sc;  // (the imaginary part of a centred symmetric kernel's spectrum is rounding noise)
             else
-                at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+                at(a.kf_out, sidx(l + 16 * q, k, NBX)) = make_double2(v[q].x * sc, -v[q].y * sc);
         }
         return;
     }
@@ -612,12 +539,13 @@ __device__ __forceinline__ void fft_cols_y512_body(const FftConvArgs& a, const i
     const cplx* kf = a.kfs[(a.pair0 + pair) / a.ppc];
     const int f0 = 256 * (l & 1) + (l >> 1);  // spectrum row of register q: f0 + 16 q
     if (mode == 1) {
+        const double sc = R2F_FFT_EPI2 ? 1.0 / (512.0 * (NBX * 16)) : 1.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (KR)
-                rat(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = v[q].x;
+                rat(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = v[q].x * sc;
             else
-                at(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = make_double2(v[q].x, -v[q].y);
+                at(a.kf_out, sidx(f0 + 16 * q, k, NBX)) = make_double2(v[q].x * sc, -v[q].y * sc);
         }
         return;
     }
@@ -659,17 +587,18 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F
 // into a wave-private LDS tile by LDS-DMA (global_load_lds_dwordx4, counted vmcnt waits; complex64 only, 8 KB per wave) while the
 // current one is transformed measured the same as this one (0.59-0.60 against 0.61 alone, 4.84 against 4.82 in the frame): what
 // the pass does not hide is not the latency of its loads (round 3 found the same with a register prefetch); removed again.
+// Round 6: fft256 re-cut around ONE LDS round trip with the round trip under the butterflies (a complex tile, the first DFT-16's
+// outputs written group by group while the next group's butterflies issue, the reads back in the order the second DFT-16 takes
+// them; the ISA came out as placed, results bit-identical) measured 0.623 against 0.628 ms alone on complex64, 0.894 against 0.885 on
+// complex128, and the frame +0.02 ... +0.04 ms (interleaved, two builds in one process: profiles/r06_fft_levers_ab.txt): the LDS
+// round trips are not what this pass fails to hide either; removed again (commit "Column walk: fft256 around one LDS round trip").
 // Loop-invariant values the compiler would otherwise keep in VGPRs from pair to pair (the fifteen twiddle powers: 60 VGPRs; sixteen
 // store offsets) are made opaque per iteration -- recomputing them is what the one-shot kernel does too: 207-209 VGPRs, no spill.
 template <int NBX, int ST>
 __device__ __forceinline__ void fft_cols_walk_body(const FftConvArgs& a, double* fsm) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
-#if R2F_FFT_PIPE
-    cplx* tbuf = reinterpret_cast<cplx*>(fsm) + (threadIdx.x >> 6) * 4 * kTLineC;  // this wave's complex tile: 4 lines x 272 double2
-#else
     double* tbuf = wave_tbuf(fsm);
-#endif
     const long long img = (long long)kN * (NBX * 16);
     const int G = gridDim.y;
     const cplx w1 = a.tw[l];
@@ -690,19 +619,11 @@ __device__ __forceinline__ void fft_cols_walk_body(const FftConvArgs& a, double*
         cplx v[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sbase + m * (NBX * 256));
-#if R2F_FFT_PIPE
-        fft256_pipe<false>(v, w, tbuf, lane);
-#else
         fft256<false>(v, w, tbuf, lane);
-#endif
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = make_double2(v[q].x * kr[q], v[q].y * kr[q]);
         asm volatile("" : "+v"(w.x), "+v"(w.y));
-#if R2F_FFT_PIPE
-        fft256_pipe<true>(v, w, tbuf, lane);
-#else
         fft256<true>(v, w, tbuf, lane);
-#endif
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<ST>(s1, sbase + q * (NBX * 256), v[q]);
@@ -771,7 +692,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     }
     const int gp = a.pair0 + pair, ci = gp / a.ppc, pc = gp - ci * a.ppc, ch = a.chan[ci];
     float* dplane = a.dst.data + (long long)ch * a.dst.plane_stride;
-    const double scale = 1.0 / ((double)NX * a.ny);  // a power of two
+    const double scale = R2F_FFT_EPI2 ? 1.0 : 1.0 / ((double)NX * a.ny);  // a power of two; carried by the kernel spectrum (pass 2, mode 1)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         int wy, wx;
@@ -782,7 +703,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
         // the 16 outputs of this lane first, then the curve on all of them at once (independent gathers), then the stores
         float o[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) o[q] = (float)((half ? v[q].y : v[q].x) * scale);
+        for (int q = 0; q < 16; ++q) o[q] = R2F_FFT_EPI2 ? (float)(half ? v[q].y : v[q].x) : (float)((half ? v[q].y : v[q].x) * scale);
         if (EPI) {
             constexpr int CB = R2F_FFT_CURVE_BATCH;
 #pragma unroll
@@ -847,7 +768,6 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI
 // ---------------------------------------------------------------------------------------------------- launchers
 static size_t fft_lds_bytes() { return (size_t)(kFftThreads / 64) * 4 * kTLine * sizeof(double); }
 
-hipError_t fft_init_attributes();  // (below the kernels it names)
 
 template <int XL>
 static void launch_rows_fwd(const FftConvArgs& a, hipStream_t s) {
@@ -907,15 +827,14 @@ static bool cols_walk_applies(const FftConvArgs& a, int mode) { return a.cols_wa
 template <int NBX>
 static void launch_cols_walk_st(const FftConvArgs& a, dim3 grid, hipStream_t s) {
     const dim3 block(kFftThreads);
-    const size_t walk_lds = fft_lds_bytes() * (R2F_FFT_PIPE ? 2 : 1);  // the pipelined transform's tile holds complex values
     if (a.s32 == 1)
-        launch_k((fft_cols_walk_kernel<NBX, 1>), grid, block, walk_lds, s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 1>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 3)
-        launch_k((fft_cols_walk_kernel<NBX, 3>), grid, block, walk_lds, s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 3>), grid, block, fft_lds_bytes(), s, a);
     else if (a.s32 == 2)
-        launch_k((fft_cols_walk_kernel<NBX, 2>), grid, block, walk_lds, s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 2>), grid, block, fft_lds_bytes(), s, a);
     else
-        launch_k((fft_cols_walk_kernel<NBX, 0>), grid, block, walk_lds, s, a);
+        launch_k((fft_cols_walk_kernel<NBX, 0>), grid, block, fft_lds_bytes(), s, a);
 }
 
 static void launch_cols_walk(const FftConvArgs& a, hipStream_t s) {
@@ -930,24 +849,7 @@ static void launch_cols_walk(const FftConvArgs& a, hipStream_t s) {
         launch_cols_walk_st<16>(a, grid, s);
 }
 
-// The column walk's complex transpose tile takes 69.6 KB of dynamic LDS per workgroup: beyond the 64 KB a kernel gets unasked.
-hipError_t fft_init_attributes() {
-#if R2F_FFT_PIPE
-#define R2F_WALK_ATTR(NBX, ST)                                                                                         \
-    {                                                                                                                 \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_walk_kernel<NBX, ST>),              \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * fft_lds_bytes()));   \
-        if (e != hipSuccess) return e;                                                                                \
-    }
-#define R2F_WALK_ATTR4(NBX) R2F_WALK_ATTR(NBX, 0) R2F_WALK_ATTR(NBX, 1) R2F_WALK_ATTR(NBX, 2) R2F_WALK_ATTR(NBX, 3)
-    R2F_WALK_ATTR4(16)
-    R2F_WALK_ATTR4(32)
-    R2F_WALK_ATTR4(64)
-#undef R2F_WALK_ATTR4
-#undef R2F_WALK_ATTR
-#endif
-    return hipSuccess;
-}
+hipError_t fft_init_attributes() { return hipSuccess; }
 
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
     if (cols_walk_applies(a, mode)) {

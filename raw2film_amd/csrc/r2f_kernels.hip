@@ -1340,17 +1340,19 @@ hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int mode,
     return take_launch_status();
 }
 
-// min / max |.| of rows [y0, y1) of the planes in `mask`, merged into the frame block like the front kernel's own record
-// (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours).  NaNs drop out of fminf / fmaxf, like there.
-__global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src, const int y0, const int y1, const int W, const int mask,
-                                                              FrameParams* dst) {
+// min / max |.| of rows [y0, y1) and [y2, y3) of the planes in `mask`, merged into the frame block like the front kernel's own record
+// (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours above and below, one launch for both bands).
+// NaNs drop out of fminf / fmaxf, like there.
+__global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src, const int y0, const int y1, const int y2, const int y3,
+                                                              const int W, const int mask, FrameParams* dst) {
     float lo = __builtin_inff(), hi = 0.f;
-    const long long n = (long long)(y1 - y0) * W;
+    const long long n0 = (long long)(y1 - y0) * W, n = n0 + (long long)(y3 - y2) * W;
     for (int c = 0; c < 3; ++c) {
         if (!((mask >> c) & 1)) continue;
-        const float* p = src.data + c * src.plane_stride + (long long)(y0 - src.gy0) * W;
+        const float* p0 = src.data + c * src.plane_stride + (long long)(y0 - src.gy0) * W;
+        const float* p1 = src.data + c * src.plane_stride + (long long)(y2 - src.gy0) * W - n0;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-            const float v = p[i];
+            const float v = i < n0 ? p0[i] : p1[i];
             lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
         }
     }
@@ -1362,11 +1364,13 @@ __global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src
     if ((threadIdx.x & 63) == 0) merge_range(dst, lo, hi);
 }
 
-hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int W, int mask, FrameParams* dst, hipStream_t s) {
-    if (y1 <= y0 || W <= 0 || !(mask & 7)) return hipSuccess;
-    const long long n = (long long)(y1 - y0) * W;
+hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, FrameParams* dst, hipStream_t s) {
+    if (y1 < y0) y1 = y0;
+    if (y3 < y2) y3 = y2;
+    const long long n = (long long)(y1 - y0 + y3 - y2) * W;
+    if (n <= 0 || W <= 0 || !(mask & 7)) return hipSuccess;
     const int blocks = (int)std::min<long long>((n + 1023) / 1024, 2048);
-    launch_k(exposure_range_kernel, dim3(blocks), dim3(256), 0, s, src, y0, y1, W, mask, dst);
+    launch_k(exposure_range_kernel, dim3(blocks), dim3(256), 0, s, src, y0, y1, y2, y3, W, mask, dst);
     return take_launch_status();
 }
 

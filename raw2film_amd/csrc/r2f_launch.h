@@ -283,8 +283,8 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 // *dst <- v on stream s (one lane): the per-render write of the context's FrameParams block ahead of a frame's launches
 // mode: 0 seed only, 1 seed + range reset, 2 range reset only, 3 range made unusable (frame_params_kernel)
 hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int mode, hipStream_t s);
-// the range of rows [y0, y1) of the planes in `mask` merged into the frame block (r2f_stage_exposure_range)
-hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int W, int mask, FrameParams* dst, hipStream_t s);
+// the range of rows [y0, y1) and [y2, y3) of the planes in `mask` merged into the frame block (r2f_stage_exposure_range)
+hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, FrameParams* dst, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
 hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s);

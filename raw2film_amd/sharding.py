@@ -162,8 +162,8 @@ class HipStageBackend:
         return self.ctx.stage_front_split(image_rows, self.params, E, D, in_gy0=in_gy0, exposure_gy0=e_gy0, density_gy0=d_gy0,
                                           y0=y0, y1=y1, H_global=H, track_range=track)
 
-    def exposure_range(self, E, e_gy0, y0, y1):
-        self.ctx.stage_exposure_range(E, src_gy0=e_gy0, y0=y0, y1=y1)
+    def exposure_range(self, E, e_gy0, y0, y1, y2=0, y3=0):
+        self.ctx.stage_exposure_range(E, src_gy0=e_gy0, y0=y0, y1=y1, y2=y2, y3=y3)
 
     def halation(self, E, e_gy0, D, d_gy0, y0, y1, H, identity_done=0, range_valid=False):
         self.ctx.stage_halation(E, D, self.params, src_gy0=e_gy0, dst_gy0=d_gy0, y0=y0, y1=y1, H_global=H,
@@ -706,10 +706,8 @@ class RowShardedRenderer:
         E, lo = self._e_rows()
         hi = lo + int(E.shape[1])
         self._note("halo_range")
-        if lo < p.r0:
-            be.exposure_range(E, lo, lo, p.r0)
-        if hi > p.r1:
-            be.exposure_range(E, lo, p.r1, hi)
+        if lo < p.r0 or hi > p.r1:  # the band above and the band below in one launch
+            be.exposure_range(E, lo, lo, p.r0, p.r1, hi)
 
     def _halation_interior(self):
         """The halation of the rows whose stencil reads this rank's own exposure rows only: issued before the halo exchange is

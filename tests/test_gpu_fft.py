@@ -389,10 +389,11 @@ def test_the_halation_scratch_element_is_chosen_per_frame_on_the_device():
             c.set_option("stencil_fft_scratch96", 0)
             # a row shard's sequence: reset, own rows recorded by the front kernel in two calls, the "halo" rows by the range kernel
             c.write_frame_params(params)
-            c.stage_front(dev[:300], params, 0, dst=E, y0=0, y1=300, H_global=H, track_range=True)
+            c.stage_front(dev[100:300], params, 0, in_gy0=100, dst=E, y0=100, y1=300, H_global=H, track_range=True)
             c.stage_front(dev[300:620], params, 0, in_gy0=300, dst=E, y0=300, y1=620, H_global=H, track_range=True)
-            c.stage_front(dev[620:], params, 0, in_gy0=620, dst=E, y0=620, y1=H, H_global=H)  # ... rows that "arrive": not recorded,
-            c.stage_exposure_range(E, y0=620, y1=H)                                               # then added
+            c.stage_front(dev[:100], params, 0, dst=E, y0=0, y1=100, H_global=H)               # ... rows that "arrive" from above
+            c.stage_front(dev[620:], params, 0, in_gy0=620, dst=E, y0=620, y1=H, H_global=H)  # and below: not recorded by the front,
+            c.stage_exposure_range(E, y0=0, y1=100, y2=620, y3=H)                              # then added, both bands in one launch
             c.stage_halation(E, Dv, params, y0=0, y1=H, H_global=H, range_valid=True)
             rng = c.frame_exposure_range()
             assert rng["armed"] and rng["twelve_byte_element"] == want_packed, rng

@@ -496,7 +496,9 @@ def test_bench_runs_two_ranks_on_one_gpu_and_reproduces_the_single_rank_frame(tm
     l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert l2["n_gpus"] == ranks and l2["scaling"] == "strong" and l1["n_gpus"] == 1
     assert l2["metric"] == l1["metric"] and l2["unit"] == "MP/s" and l2["value"] > 0
-    assert f"row-sharded over {ranks} GPUs" in l2["config"]["sharding"]
+    # (the label says what carried the halos: RCCL only with --backend nccl; here gloo, host-staged, ranks sharing one GPU)
+    assert f"row-sharded over {ranks} ranks on one GPU" in l2["config"]["sharding"] and "gloo" in l2["config"]["sharding"]
+    assert "RCCL" not in l2["config"]["sharding"]
     assert l2["checksum"] == l1["checksum"]
     assert l2["roofline"]["peak"] == ranks * l1["roofline"]["peak"]
     assert l2["gloo_ranks"] == ranks and "rccl_ranks" not in l2  # (RCCL's count appears with --backend nccl: tests/test_gpu_multi.py)
