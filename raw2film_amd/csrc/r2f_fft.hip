@@ -405,27 +405,45 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(__builtin_isfinite(fa[m]) ? (double)fa[m] : 0.0, __builtin_isfinite(fb[m]) ? (double)fb[m] : 0.0);
     }
+    // ST = 3 (element chosen per frame on the device): the choice is needed at the stores only, so the frame block is read HERE --
+    // behind the issue of the window loads, its round trip under the loads and the transform -- instead of at the top of the kernel,
+    // where every workgroup's first global load waited for it (+2.2 us per launch of 1 536 short workgroups, measured with rocprofv3)
+    bool packed = false;
+    if (ST == 3) packed = dyn_packed(a);
     if (!(R2F_FFT_EXP & 4)) {
         G::template fft<false>(v, a, l, wave_tbuf(fsm), lane);
-    }
-    char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
-    if (R2F_FFT_EXP & 2) {
-        if (v[3].x == 1.2345e300) sst<ST>(s1, 0, v[5]);  // keep the transform alive without storing
-        return;
     }
     // register q sits 16 q columns on: the next 16 x 16 block of the layout, 256 elements further
     unsigned tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // the row index again (see the top)
     const int rs = blockIdx.x * G::ROWS + tid / LPL;
     const unsigned sb = sidx(rs, G::out_col(l, 0), G::NBX);
+    if (ST == 3) {
+        if (packed) {
+            char* s1 = simg<2>(a.s1, pair, (long long)a.ny * NX);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) sst<ST>(s1, sb + q * 256, v[q]);
+            for (int q = 0; q < 16; ++q) sst<2>(s1, sb + q * 256, v[q]);
+        } else {
+            char* s1 = simg<0>(a.s1, pair, (long long)a.ny * NX);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sst<0>(s1, sb + q * 256, v[q]);
+        }
+        return;
+    }
+    constexpr int STS = ST == 3 ? 0 : ST;
+    char* s1 = simg<STS>(a.s1, pair, (long long)a.ny * NX);
+    if (R2F_FFT_EXP & 2) {
+        if (v[3].x == 1.2345e300) sst<STS>(s1, 0, v[5]);  // keep the transform alive without storing
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sst<STS>(s1, sb + q * 256, v[q]);
     if (R2F_FFT_EXP & 8) {  // ... and this workgroup's rows below the valid outputs are the first rows of the window row below
         const int below = pair + (a.gx + 1) / 2;
         if (r >= a.vy && below < a.npairs && (a.pair0 + below) / a.ppc == ci && !a.raw) {
-            char* s2 = simg<ST>(a.s1, below, (long long)a.ny * NX);
+            char* s2 = simg<STS>(a.s1, below, (long long)a.ny * NX);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sst<ST>(s2, sidx(r - a.vy, G::out_col(l, q), G::NBX), v[q]);
+            for (int q = 0; q < 16; ++q) sst<STS>(s2, sidx(r - a.vy, G::out_col(l, q), G::NBX), v[q]);
         }
     }
 }
@@ -436,14 +454,7 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
 template <int XL, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(R2F_FFT_WPE1, 8))) void fft_rows_fwd_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    if (ST == 3) {  // element chosen per frame on the device
-        if (dyn_packed(a))
-            fft_rows_fwd_body<XL, 2>(a, fsm);
-        else
-            fft_rows_fwd_body<XL, 0>(a, fsm);
-    } else {
-        fft_rows_fwd_body<XL, ST>(a, fsm);
-    }
+    fft_rows_fwd_body<XL, ST>(a, fsm);  // (ST = 3: the body reads the choice where it needs it, at its stores)
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 2
@@ -662,7 +673,9 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     // and 128-byte lines as they do for oy = 0 (an odd first row had cost the MTF's pass 0.10 of 0.44 ms).  ro: output row.
     const int pair = blockIdx.y, r = (a.oy & ~(G::ROWS - 1)) + blockIdx.x * G::ROWS + threadIdx.x / LPL, ro = r - a.oy;
     const bool live = (unsigned)ro < (unsigned)a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    const char* s1 = simg<ST>(a.s1, pair, (long long)a.ny * NX);
+    // ST = 3: the frame block is read here, ahead of the copy of the curve cells, so that its round trip is over when the loads need it
+    bool packed = false;
+    if (ST == 3) packed = dyn_packed(a);
     // The epilogue's curve cells: 32 divergent 16-byte gathers per lane.  From global memory they go through the texture path at
     // 0.9 lanes per clock and CU (profiles/r02_gather_rate.txt) -- more of its cycles than all of the pass's coalesced scratch
     // loads and stores; from LDS at 4.3.  The workgroup's channel has (m - 1) cells of 16 bytes: copied behind the transpose
@@ -678,9 +691,21 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     if (R2F_FFT_EXP3 & 1) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
-    } else {
+    } else if (ST == 3) {
+        if (packed) {
+            const char* s1 = simg<2>(a.s1, pair, (long long)a.ny * NX);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
+            for (int m = 0; m < 16; ++m) v[m] = sld<2>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
+        } else {
+            const char* s1 = simg<0>(a.s1, pair, (long long)a.ny * NX);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = sld<0>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
+        }
+    } else {
+        constexpr int STL = ST == 3 ? 0 : ST;
+        const char* s1 = simg<STL>(a.s1, pair, (long long)a.ny * NX);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = sld<STL>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
     }
     if (!(R2F_FFT_EXP3 & 4)) {
         G::template fft<true>(v, a, l, wave_tbuf(fsm), lane);
@@ -755,14 +780,7 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 template <int XL, int EPI, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(EPI ? R2F_FFT_WPE3 : (XL ? 3 : 4), 8))) void fft_rows_inv_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    if (ST == 3) {
-        if (dyn_packed(a))
-            fft_rows_inv_body<XL, EPI, 2>(a, fsm);
-        else
-            fft_rows_inv_body<XL, EPI, 0>(a, fsm);
-    } else {
-        fft_rows_inv_body<XL, EPI, ST>(a, fsm);
-    }
+    fft_rows_inv_body<XL, EPI, ST>(a, fsm);  // (ST = 3: the body reads the choice ahead of its loads)
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers

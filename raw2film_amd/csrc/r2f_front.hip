@@ -22,6 +22,8 @@
 // Results are bit-identical to the generic kernel's (tests/test_gpu_parity.py::test_fused_pointwise_fast_path_matches_generic).
 // Workgroups are persistent: 1 024 threads and up to 112 KB of LDS (one per CU) when the curve is needed, 512 threads and the
 // 64 KB LUT alone (two per CU) for upto = EXPOSURE; each copies its tables once and walks the frame.
+#include <type_traits>
+
 #include "r2f_launch.h"
 
 #include "../../include/r2f.h"
@@ -165,6 +167,12 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
     const float s3 = a.lut3d_scale * (float)(a.lut3d.n - 1);
     const long long plane = (long long)a.in_rows * W;
     const Mat3Pairs mat = pairs_of(a.mat);
+    // The row loop exists once per tracking mode (TRK: 0 none, 1 red + green -- a colour stock, one v_min3 + one v_max3 per pixel --,
+    // 2 any mask): a wave-uniform test of a.track inside the pixel loop is a scalar branch per pixel, i.e. four basic-block borders in
+    // what the scheduler otherwise treats as one block with the LUT gathers of four pixels in flight together (+21 us per 100 MP
+    // frame with the test inside, rocprofv3).  Only the EXPOSURE instances can track; the others compile the loop once.
+    auto row_loop = [&](auto trk_tag) {
+    constexpr int TRK = decltype(trk_tag)::value;
     for (int gy = a.y0 + blockIdx.y * BY + threadIdx.y; gy < a.y1 && x < W; gy += gridDim.y * BY) {
         const long long irow = gy - a.in_gy0;
         float r[4], g[4], b[4];
@@ -196,7 +204,11 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             p = lut2d(lut_lds, a.lut2d.n, p);
             if (UPTO == R2F_UPTO_EXPOSURE) {
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
-                if (track) {  // (fminf / fmaxf drop a NaN: pass 1 of the FFT form takes a non-finite sample as 0 anyway; an infinity stays)
+                // (fminf / fmaxf drop a NaN: pass 1 of the FFT form takes a non-finite sample as 0 anyway; an infinity stays)
+                if (TRK == 1) {
+                    t_lo = fminf(fminf(t_lo, r[q]), g[q]);
+                    t_hi = fmaxf(fmaxf(t_hi, fabsf(r[q])), fabsf(g[q]));
+                } else if (TRK == 2) {
                     if (a.track_mask & 1) t_lo = fminf(t_lo, r[q]), t_hi = fmaxf(t_hi, fabsf(r[q]));
                     if (a.track_mask & 2) t_lo = fminf(t_lo, g[q]), t_hi = fmaxf(t_hi, fabsf(g[q]));
                     if (a.track_mask & 4) t_lo = fminf(t_lo, b[q]), t_hi = fmaxf(t_hi, fabsf(b[q]));
@@ -270,6 +282,13 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             o32[2] = u8_of(b[2]) | (u8_of(r[3]) << 8) | (u8_of(g[3]) << 16) | (u8_of(b[3]) << 24);
         }
     }
+    };
+    if (!track)
+        row_loop(std::integral_constant<int, 0>{});
+    else if (a.track_mask == 3)
+        row_loop(std::integral_constant<int, 1>{});
+    else
+        row_loop(std::integral_constant<int, 2>{});
     if (track) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {

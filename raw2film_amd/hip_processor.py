@@ -471,7 +471,31 @@ class HipProcessor:
     def prepare_gpu_textures(self, cpu_payload):
         """PHASE 2's stateful half (gpu_processor.py:785-790): upload the payload's frame and run the device pre-path on it
         (uint16 conversion, free rotation, chroma NR, preview scaling); the result is the frame the pipeline reads."""
-        image = self._payload_tensor(cpu_payload).to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
+        host = self._payload_tensor(cpu_payload)
+        if cpu_payload.get("clip_on_device") and not host.is_cuda and host.dim() == 3 and host.numel() >= (1 << 24):
+            # A large float frame of this object's own making (process(host array)): the clamp of gpu_processor.py:275 rides on the
+            # upload -- the frame goes up in row chunks on a copy stream and every chunk is clamped on the launch stream while the
+            # next one travels, so that of its 2.4 GB pass (0.5 ms at 100 MP) only the last chunk's share is left behind the copy
+            torch = self._torch
+            if getattr(self, "_up_stream", None) is None:
+                self._up_stream = torch.cuda.Stream(device=self.device)
+                self._down_stream = torch.cuda.Stream(device=self.device)
+            compute = torch.cuda.current_stream(self.device)
+            image = torch.empty(host.shape, dtype=host.dtype, device=self.device)
+            self._up_stream.wait_stream(compute)  # (the block may have been another frame's a moment ago)
+            rows = int(host.shape[0])
+            step = -(-rows // 8)
+            for a0 in range(0, rows, step):
+                a1 = min(a0 + step, rows)
+                with torch.cuda.stream(self._up_stream):
+                    image[a0:a1].copy_(host[a0:a1], non_blocking=True)
+                    arrived = self._up_stream.record_event()
+                compute.wait_event(arrived)
+                image[a0:a1].clamp_(0.0, 65504.0)
+            image.record_stream(self._up_stream)
+            cpu_payload = dict(cpu_payload, clip_on_device=False)
+        else:
+            image = host.to(self.device, non_blocking=True)  # HOST -> DEVICE, the reference's write_texture
         image, layout = self._prepare_device_frame(image, cpu_payload)
         # (what is kept next to the device frame is the payload's geometry, not its host frame: the processor must not keep a
         # 1.2 GB decode buffer alive)

@@ -483,6 +483,36 @@ def test_process_clamps_the_frame_like_the_reference_load():
     proc.close()
 
 
+def test_a_large_host_frame_is_clamped_on_its_way_up_in_chunks():
+    """Round 6: a host frame of >= 16.7 M samples goes up in eight row chunks on a copy stream, each clamped on the launch stream
+    while the next one travels (the clamp of gpu_processor.py:275 no longer costs a pass of its own behind the upload).  Same
+    result as clamping on the host first -- out-of-range samples in the first, a middle and the last chunk, an odd row count;
+    pageable and pinned sources; and again when the array is edited and handed in a second time (no stale chunk, no stale frame)."""
+    from raw2film_amd import HipProcessor, filmstock
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    rng = np.random.default_rng(8)
+    H, W = 2403, 2400
+    img = rng.uniform(0.0, 1.0, (H, W, 3)).astype(np.float32)
+    img[0, 0] = (1e6, -2.0, 70000.0)
+    img[H // 2 + 7, 33] = (-1e-3, 0.5, -5.0)
+    img[H - 1, W - 1] = (80000.0, 65504.0, -0.0)
+    proc = HipProcessor(device=0)
+    kw = dict(print_film=prt, lens_correction=False, seed=2, grain=0, halation=False, sharpness=False)
+    want = proc.process(np.clip(img, 0, 65504), neg, 6, 0.4, cache=False, **kw)
+    got = proc.process(img, neg, 6, 0.4, cache=False, **kw)
+    np.testing.assert_array_equal(got, want)
+    pinned = torch.from_numpy(img).pin_memory().numpy()
+    np.testing.assert_array_equal(proc.process(pinned, neg, 6, 0.4, cache=False, **kw), want)
+    img[100:200] *= 0.5  # the same buffer, other content
+    want2 = proc.process(np.clip(img, 0, 65504), neg, 6, 0.4, cache=False, **kw)
+    got2 = proc.process(img, neg, 6, 0.4, cache=False, **kw)
+    np.testing.assert_array_equal(got2, want2)
+    assert not np.array_equal(got2, want)
+    proc.close()
+
+
 def test_pinned_result_buffers_return_views_in_turn():
     from raw2film_amd import HipProcessor, filmstock
 
