@@ -736,12 +736,15 @@ def main():
         # instead of a fresh pageable array like upstream's: the download then runs at the link's rate
         proc.result_buffers = 2
         e2e = []
-        for i in range(3):
+        for i in range(8):  # (the uploaded frame alternates between two device blocks -- the previous one is still held while the
+            #                   next arrives --, and r2f_render captures a buffer set the second time it comes by: steady state from
+            #                   the fifth call on)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res = proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + 10 + i, lens_correction=False, **settings)
             e2e.append((time.perf_counter() - t0) * 1e3)
         copies["process_end_to_end_pinned_result_ms"] = min(e2e)
+        copies["process_end_to_end_pinned_result_all_ms"] = [round(x, 3) for x in e2e]
         # where that call's time goes: one more call with a device synchronisation behind every stage
         # (HipProcessor.profile_stages -- a measuring mode: its total is a little above the un-profiled call's)
         proc.profile_stages = True
