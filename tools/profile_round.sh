@@ -84,4 +84,4 @@ summary["_meta"] = {
 json.dump(summary, open(f"{out}/summary/{tag}_{name}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(summary["_meta"], indent=1))
 PY
-tail -1 $OUT/bench_under_rocprof.log | cut -c1-600
+grep "^{" $OUT/bench_under_rocprof.log | tail -1 | cut -c1-600
