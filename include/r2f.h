@@ -160,8 +160,9 @@ R2F_API int r2f_render(r2f_ctx* ctx, const r2f_params* p, const void* in, int in
  * kernel by kernel, out[3] graphs dropped (context changes, evictions, failed captures). */
 R2F_API int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
 
-/* Introspection for the measurement harness (synchronises the device): what the front kernel of the last whole-frame render
- * recorded about the exposure planes the halation's FFT passes read, and what they made of it.  out4 = {min x, max |x|, bound,
+/* Introspection for the measurement harness (synchronises the device): what the front kernel of the last whole-frame render (or
+ * the front / range calls of a row shard's last frame: R2F_F_TRACK_RANGE, r2f_stage_exposure_range) recorded about the exposure
+ * planes the halation's FFT passes read, and what they made of it.  out4 = {min x, max |x|, bound,
  * floor}; *armed = 1 when that render's halation launches carried the rule (stencil_fft_scratch96_auto, 256-row windows, real
  * spectrum: r2f_render above), *packed = 1 when they then took the 12-byte scratch element (max <= bound x max(min, floor)).
  * Valid until the next write of the frame block (the next render).  Nothing upstream corresponds to it. */

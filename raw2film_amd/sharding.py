@@ -209,6 +209,9 @@ class RowShardedRenderer:
 
     backend:   object with empty/front/halation/mtf/tail/front_to_output (see HipStageBackend)
     halation / mtf / grain: which stages are enabled (the stage gates of cpu_processor.py:368,382,387)
+    dyn_scratch: with a backend that keeps the exposure-range record (HipStageBackend.tracks_range) the halation's FFT passes
+               choose their scratch element on the device per frame like a whole-frame r2f_render's (default); False: complex128
+               whatever the rows hold (bit-for-bit comparisons with a render under stencil_fft_scratch96_auto = 0, A/B)
     """
 
     def __init__(self, backend, H: int, W: int, *, halation: bool, mtf: bool, grain: bool = True, burn: bool = False,

@@ -314,3 +314,89 @@ def test_wrong_output_tensors_raise_before_anything_is_launched():
         proc.ctx.histogram_render(torch.zeros((3, 255), dtype=torch.int32, device="cuda"), [0] * 32, 40)
     torch.cuda.synchronize()
     proc.close()
+
+
+def test_a_resident_seed_caller_gets_a_fresh_exposure_range_every_frame():
+    """a caller that keeps the seed resident (R2F_F_FRAME_RESIDENT: it wrote the frame block itself) used to keep the
+    exposure RANGE of earlier frames too -- only r2f_write_frame_params reset it -- so the union of the frames so far decided frame
+    N's scratch element.  Now every whole-frame render starts its record empty, eager or replayed: a benign frame after a hostile
+    one takes the 12-byte element again, and its bits are those of the same frame rendered by a non-resident caller."""
+    from helpers import oracle_inputs
+    from raw2film_amd import _lib
+    from raw2film_amd.context import HipContext
+    from test_gpu_parity import setup_ctx
+
+    H, W = 700, 1100
+    neg, prt, _ = stocks()
+    p = oracle_inputs(neg, prt, 341.33, seed=SEED)
+    benign = np.clip(synthetic_frame(H, W, seed=9), 0.01, 16.0)
+    hostile = benign.copy()
+    hostile[300:304, 500:504] = 65504.0
+    hostile[50:150, 60:200] = 1e-5
+    c = HipContext(0)
+    try:
+        params = setup_ctx(c, p)
+        c.set_option("stencil_fft_window_rows", 256)
+        c.set_option("stencil_fft_window", 512)
+        buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        want = {}
+        for name, frame in (("benign", benign), ("hostile", hostile)):  # a non-resident caller: r2f_render writes the block itself
+            buf.copy_(torch.from_numpy(frame))
+            for _ in range(3):
+                c.render(buf, params, out_f32=out)
+            want[name] = (out.cpu().numpy(), c.frame_exposure_range()["twelve_byte_element"])
+        assert want["benign"][1] and not want["hostile"][1]
+        resident = _lib.Params.from_buffer_copy(params)
+        resident.flags |= _lib.F_FRAME_RESIDENT
+        c.write_frame_params(params)  # the caller's own seed write, once
+        for mode in ("replay", "eager"):
+            c.set_option("render_graph", 1 if mode == "replay" else 0)
+            for name, frame in (("hostile", hostile), ("benign", benign), ("benign", benign), ("hostile", hostile), ("benign", benign)):
+                buf.copy_(torch.from_numpy(frame))
+                c.render(buf, resident, out_f32=out)
+                rng = c.frame_exposure_range()
+                assert rng["armed"] and rng["twelve_byte_element"] == want[name][1], (mode, name, rng)
+                np.testing.assert_array_equal(out.cpu().numpy(), want[name][0])
+    finally:
+        c.close()
+
+
+def test_a_pending_error_of_another_runtime_user_is_not_reported_as_a_launch_failure():
+    """every launch wrapper used to return hipGetLastError(), i.e. whatever error was pending on the calling thread --
+    one PyTorch or RCCL left there -- as its own status (R2F_EHIP), consuming it on the way.  Launches now go through
+    hipLaunchKernel and report that call's own return value: with an error pending (an invalid hipFree through ctypes), a stage
+    call and a whole-frame render succeed and produce the same bits as without."""
+    import ctypes
+
+    from raw2film_amd import HipProcessor
+
+    hip = None
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        pytest.skip("no libamdhip64 to provoke an error with")
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    H, W = 160, 256
+    neg, kw = _settings(H, W, 36.0 * W / 12288.0)
+    frame = torch.from_numpy(synthetic_frame(H, W, seed=5)).cuda()
+    proc = HipProcessor(device=0)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=_rec709(), **kw)
+    for _ in range(3):
+        proc.ctx.render(frame, params, out_f32=out)
+    want = out.clone()
+    proc.ctx.set_option("render_graph", 0)  # kernel by kernel: ~20 launches, each of which used to read the pending error
+    out.zero_()
+    assert hip.hipFree(ctypes.c_void_p(0x10)) != 0  # an error of "somebody else's", left pending on this thread
+    proc.ctx.render(frame, params, out_f32=out)     # raised R2FError before
+    assert torch.equal(out, want)
+    E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    assert hip.hipFree(ctypes.c_void_p(0x10)) != 0
+    proc.ctx.stage_front(frame, params, 0, dst=E)
+    torch.cuda.synchronize()
+    proc.close()
