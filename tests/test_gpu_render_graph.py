@@ -392,11 +392,15 @@ def test_a_pending_error_of_another_runtime_user_is_not_reported_as_a_launch_fai
     want = out.clone()
     proc.ctx.set_option("render_graph", 0)  # kernel by kernel: ~20 launches, each of which used to read the pending error
     out.zero_()
+    E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
     assert hip.hipFree(ctypes.c_void_p(0x10)) != 0  # an error of "somebody else's", left pending on this thread
     proc.ctx.render(frame, params, out_f32=out)     # raised R2FError before
+    # ... and the error is still THEIRS to read: the library neither reported nor consumed it (torch's next check would raise it)
+    assert hip.hipGetLastError() != 0
+    assert hip.hipGetLastError() == 0
     assert torch.equal(out, want)
-    E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
     assert hip.hipFree(ctypes.c_void_p(0x10)) != 0
     proc.ctx.stage_front(frame, params, 0, dst=E)
+    assert hip.hipGetLastError() != 0
     torch.cuda.synchronize()
     proc.close()
