@@ -521,17 +521,22 @@ def main():
         if rng is not None:
             roof["halation_scratch_element"] = dict(
                 rng, eager_breakdown_took_the_same_element=bool(rng_eager and rng_eager["armed"] == rng["armed"]
-                                                                and rng_eager["twelve_byte_element"] == rng["twelve_byte_element"]),
-                note="what r2f_render's front kernel recorded about the exposure planes of the last timed frame and what the halation's "
-                     "FFT passes made of it: the 12-byte element (doubles rounded to 48 bits) when max_abs <= bound x max(min, floor), "
-                     "else complex128.  stage_ms / fft_pass_ms_per_step come from eager stage calls that make the same choice from "
-                     "the same record (R2F_F_TRACK_RANGE / R2F_F_RANGE_VALID)")
-        packed = bool(rng and rng["twelve_byte_element"])
-        armed = bool(rng and rng["armed"])
+                                                                and rng_eager["pairs"] == rng["pairs"]
+                                                                and rng_eager["packed_pairs"] == rng["packed_pairs"]),
+                note="what r2f_render's front kernel recorded about the exposure planes of the last timed frame (min / max_abs: the FRAME's "
+                     "extremes) and what the halation's FFT passes made of the record: the choice is per WINDOW PAIR -- a pair takes the "
+                     "12-byte element (doubles rounded to 48 bits) when the max |x| of its two windows <= bound x max(their min, floor), "
+                     "else complex128; packed_pairs of pairs (per channel) took it, twelve_byte_element = all of them.  stage_ms / "
+                     "fft_pass_ms_per_step come from eager stage calls that make the same choices from the same record "
+                     "(R2F_F_TRACK_RANGE / R2F_F_RANGE_VALID)")
+        src_rng = rng
         if rng_eager is not None and rng is not None and not roof["halation_scratch_element"]["eager_breakdown_took_the_same_element"]:
-            packed = bool(rng_eager["twelve_byte_element"])  # label the breakdown by what IT ran
-            armed = bool(rng_eager["armed"])
-        el_h = "12-byte element" if packed else "complex128"
+            src_rng = rng_eager  # label the breakdown by what IT ran
+        armed = bool(src_rng and src_rng["armed"])
+        packed_frac = (src_rng["packed_pairs"] / src_rng["pairs"]) if (src_rng and src_rng.get("pairs")) else 0.0
+        packed = packed_frac > 0.0
+        el_h = ("12-byte element" if packed_frac == 1.0 else
+                f"12-byte element on {packed_frac:.1%} of the window pairs, complex128 on the rest" if packed else "complex128")
         names = [f"rows_fwd ({el_h})", f"cols ({el_h})", f"rows_inv ({el_h})", "rows_fwd (complex64)", "cols (complex64)",
                  "rows_inv (complex64)"]
         per_step = [extra[0][0] / 2, cols[1][0] / steps_for_cols, extra[2][0] / 2, extra[3][0] / 2, cols[4][0] / steps_for_cols, extra[5][0] / 2]
@@ -548,9 +553,10 @@ def main():
             nzh = np.nonzero(hal_k[..., 0])
             bw_h = int(nzh[1].max() - nzh[1].min() + 1)
             vx_h = (win_h[1] - bw_h + 1) & ~3
-            byte_scale[0] = 1.0 - 0.25 * 16.0 / (16.0 + 8.0)
-            byte_scale[1] = 0.75
-            byte_scale[2] = 1.0 - 0.25 * (win_h[1] * 16.0) / (win_h[1] * 16.0 + 2.0 * vx_h * 4.0)
+            q = 0.25 * packed_frac  # (the share of the pairs that took the element: their scratch part is a quarter smaller)
+            byte_scale[0] = 1.0 - q * 16.0 / (16.0 + 8.0)
+            byte_scale[1] = 1.0 - q
+            byte_scale[2] = 1.0 - q * (win_h[1] * 16.0) / (win_h[1] * 16.0 + 2.0 * vx_h * 4.0)
         cols = [(ms, n, b * byte_scale[c]) for c, (ms, n, b) in enumerate(cols)]
         extra = [(ms, n, b * byte_scale[c]) for c, (ms, n, b) in enumerate(extra)]
         solo = [(ms, n, b * byte_scale[c]) for c, (ms, n, b) in enumerate(solo)]

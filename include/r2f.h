@@ -131,8 +131,8 @@ R2F_API int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int 
  * Stencils of >= 400 taps run as fp64 overlap-save FFTs (like cv.filter2D's own DFT branch above 11 x 11 taps, which the
  * reference's CPU path takes for both of them); their pass scratch (1 MiB per window pair in flight, 192 by default) and
  * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use.
- * Scratch element of the halation's passes: complex128, or -- chosen on the device, frame by frame, by r2f_render only -- a
- * 12-byte element (each component a double rounded to 48 bits) when the range of the exposure samples the front kernel wrote
+ * Scratch element of the halation's passes: complex128, or -- chosen on the device, frame by frame and WINDOW PAIR by window pair -- a
+ * 12-byte element (each component a double rounded to 48 bits) when the range of the exposure samples the pair's two windows hold
  * allows it: max |x| <= bound x max(min x, first breakpoint of the density curve), the bound derived from the curve's steepest
  * cell and the element's worst error (two roundings at 2^-37 of max / shadow, x 1.5: a searched constant, tests/test_gpu_fft.py) so
  * that the element costs a density at most three fp32 ulps -- the MTF's complex64 scratch is allowed the same -- (option
@@ -167,6 +167,11 @@ R2F_API int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
  * spectrum: r2f_render above), *packed = 1 when they then took the 12-byte scratch element (max <= bound x max(min, floor)).
  * Valid until the next write of the frame block (the next render).  Nothing upstream corresponds to it. */
 R2F_API int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed);
+/* The choice itself, which is made PER WINDOW PAIR since round 6 (a pair's two windows' own range, from a grid of 64 x 256-pixel tiles
+ * the front kernel fills beside the frame-level extremes): of the *pairs window pairs per channel of the last halation call that chose
+ * on the device, *packed_pairs took the 12-byte element (r2f_frame_exposure_range's *packed = all of them).  0 / 0 when the last call
+ * did not choose.  Synchronises the device; introspection for the measurement harness and the tests. */
+R2F_API int r2f_frame_scratch_choice(r2f_ctx* ctx, int* pairs, int* packed_pairs);
 
 /* The per-render uniform write: p->seed -> the context's device-side frame block, asynchronously on `stream`
  * (gpu_processor.py:585-597: the uniform buffer `buffer_params_grain` with a fresh random seed, made ahead of the dispatches;

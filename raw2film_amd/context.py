@@ -128,8 +128,12 @@ class HipContext:
         (bound, floor) and whether its FFT passes took the 12-byte scratch element (synchronises the device)."""
         out, armed, packed = (C.c_float * 4)(), C.c_int(), C.c_int()
         self._check(self._lib.r2f_frame_exposure_range(self._h, out, C.byref(armed), C.byref(packed)))
+        pairs, packed_pairs = C.c_int(), C.c_int()
+        self._check(self._lib.r2f_frame_scratch_choice(self._h, C.byref(pairs), C.byref(packed_pairs)))
+        # the choice is made per window pair: `twelve_byte_element` = every pair of the last halation call took it; the counts beside it
         return {"min": float(out[0]), "max_abs": float(out[1]), "bound": float(out[2]), "floor": float(out[3]),
-                "armed": bool(armed.value), "twelve_byte_element": bool(packed.value)}
+                "armed": bool(armed.value), "twelve_byte_element": bool(packed.value),
+                "pairs": int(pairs.value), "packed_pairs": int(packed_pairs.value)}
 
     def write_frame_params(self, params):
         """The per-render uniform write (r2f_write_frame_params): params.seed -> the context's device-side frame block, in

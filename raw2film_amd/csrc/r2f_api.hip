@@ -145,6 +145,11 @@ struct r2f_ctx {
     // Per-render values the kernels read through a pointer (FrameParams: the grain seed), so that a captured frame can be
     // replayed with a new seed; written in stream order by write_frame_params ahead of a frame's launches.
     DeviceBuf frame_buf;
+    // The exposure-range record's tile grid (r2f_device.h RangeRecord: 64 x 256 tiles of the GLOBAL frame, {min, max |.|} each) and
+    // the per-pair flags fft_decide_kernel derives from it for the halation's FFT passes of the call at hand (one per pair-in-channel)
+    DeviceBuf range_tiles, dyn_flags;
+    int tiles_tyn = 0, tiles_txn = 0;
+    int dyn_flags_ppc = 0;  // pairs per channel of the last call that chose per pair (r2f_frame_scratch_choice)
     // r2f_render's graph cache: one entry per (buffers, shape, parameters without the seed).  An entry is rendered kernel by
     // kernel the first time the context sees its structure (tables, scratch and spectra get built then), captured on
     // `cap_stream` afterwards and replayed on the caller's stream from then on.  Everything is dropped when `generation` moves.
@@ -397,13 +402,41 @@ int ensure_bytes(r2f_ctx* ctx, DeviceBuf& buf, size_t bytes) {
 
 // p->seed -> the context's device-side frame block, in stream order (a one-lane kernel: its by-value argument is copied at
 // launch time, so no host staging buffer has to outlive the call).
+RangeRecord record_of(const r2f_ctx* ctx) {
+    RangeRecord r;
+    r.blk = static_cast<FrameParams*>(ctx->frame_buf.p);
+    r.tiles = static_cast<int2*>(ctx->range_tiles.p);
+    r.tyn = ctx->tiles_tyn, r.txn = ctx->tiles_txn;
+    return r;
+}
+
+// The record's tile grid for an H x W frame (allocated on first use and when the frame grows; a fresh grid says "unknown").
+int ensure_range_tiles(r2f_ctx* ctx, int H_global, int W) {
+    const int tyn = (H_global + kRangeTileRows - 1) / kRangeTileRows, txn = (W + kRangeTileCols - 1) / kRangeTileCols;
+    if (ctx->range_tiles.p && tyn <= ctx->tiles_tyn && txn == ctx->tiles_txn) return R2F_OK;
+    R2F_HIP(ctx, hipDeviceSynchronize());  // (kernels of an earlier frame may still be reading the old grid)
+    const int new_tyn = std::max(tyn, ctx->tiles_txn == txn ? ctx->tiles_tyn : 0);
+    const size_t n = (size_t)new_tyn * txn;
+    std::vector<int2> init(n, make_int2((int)kFrameMinReset, (int)kFrameMaxReset));
+    if (ctx->range_tiles.bytes < n * sizeof(int2)) {
+        ctx->range_tiles.release();
+        R2F_HIP(ctx, hipMalloc(&ctx->range_tiles.p, n * sizeof(int2)));
+        ctx->range_tiles.bytes = n * sizeof(int2);
+    }
+    R2F_HIP(ctx, hipMemcpy(ctx->range_tiles.p, init.data(), n * sizeof(int2), hipMemcpyHostToDevice));
+    ctx->tiles_tyn = new_tyn, ctx->tiles_txn = txn;
+    ++ctx->generation;  // (captured launches hold the grid's address and dimensions)
+    return R2F_OK;
+}
+
 // mode 1: seed + reset of the exposure range (the start of a render); 0: a stage entry's own seed write in the middle of one;
-// 2: the range reset alone (a render whose caller keeps the seed resident); 3: the range made unusable (frame_params_kernel)
+// 2: the range reset alone (a render whose caller keeps the seed resident); 3: the range made unusable (frame_params_kernel).
+// Modes 1 and 2 reset the tile grid too.
 int write_frame_params(r2f_ctx* ctx, const r2f_params* p, hipStream_t s, int mode = 1) {
     FrameParams v{};
     v.seed = p->seed;
     v.e_min = kFrameMinReset, v.e_max = kFrameMaxReset;
-    R2F_HIP(ctx, launch_frame_params(static_cast<FrameParams*>(ctx->frame_buf.p), v, mode, s));
+    R2F_HIP(ctx, launch_frame_params(record_of(ctx), v, mode, s));
     return R2F_OK;
 }
 
@@ -656,9 +689,7 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     // the halation of a whole-frame render whose front kernel recorded the range of the exposure planes: element chosen on the device
     if (a.s32 == 0 && which == R2F_KERNEL_HALATION && epilogue == 1 && dyn && ctx->opt_fft_s96_auto && a.kreal &&
         ny == 256 && ctx->opt_fft_cols_walk && ctx->curve.cells) {
-        a.s32 = 3;
-        a.dyn = static_cast<const FrameParams*>(ctx->frame_buf.p);
-        dyn_rule(ctx, &a.dyn_bound, &a.dyn_floor);
+        a.s32 = 3;  // (the flags are worked out below, once the call's tiling is known)
         ctx->frame_dyn_armed = true;
     }
     const plan::FftBatches fb = plan::fft_batches(fo, ny, nx, bh, bw, W, y0, y1, nch, a.s32 == 1 ? 8 : (a.s32 == 2 ? 12 : 16));  // (3: sized for 16)
@@ -674,6 +705,19 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     const int pairs = fb.pairs, nstreams = fb.nstreams, batch = fb.batch;
     rc = ensure_bytes(ctx, ctx->fft_s1, fb.scratch_bytes);
     if (rc) return rc;
+    if (a.s32 == 3) {
+        // the element of every window pair of this call, from the exposure-range tiles its caller vouches for: one small launch on the
+        // caller's stream ahead of the passes (they fan out to the internal streams behind it)
+        rc = ensure_range_tiles(ctx, H, W);
+        if (rc) return rc;
+        rc = ensure_bytes(ctx, ctx->dyn_flags, (size_t)std::max(fb.ppc, 1) * sizeof(int));
+        if (rc) return rc;
+        float bound, floor_;
+        dyn_rule(ctx, &bound, &floor_);
+        a.dyn_flags = static_cast<const int*>(ctx->dyn_flags.p);
+        ctx->dyn_flags_ppc = fb.ppc;
+        R2F_HIP(ctx, launch_fft_decide(a, record_of(ctx), bound, floor_, static_cast<int*>(ctx->dyn_flags.p), s));
+    }
     hipStream_t lanes[4] = {s, s, s, s};
     if (nstreams > 1) {
         for (int i = 0; i < nstreams; ++i) {
@@ -874,6 +918,8 @@ void r2f_destroy(r2f_ctx* ctx) {
     reap_retired_graphs(ctx, true);  // (the device has been synchronised: entries without a usable event go too)
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     ctx->frame_buf.release();
+    ctx->range_tiles.release();
+    ctx->dyn_flags.release();
     ctx->lut2d_buf.release();
     ctx->lut3d_buf.release();
     ctx->curve_buf.release();
@@ -1215,7 +1261,9 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
         if (f.finish_mask && f.finish_mask != 7 && front_fast_eligible(f)) {
             *finished_mask = f.finish_mask;
             if (want_track) {  // the exposure planes' range for the FFT passes
-                f.track = static_cast<FrameParams*>(ctx->frame_buf.p);
+                rc = ensure_range_tiles(ctx, H_global, W);
+                if (rc) return rc;
+                f.track = record_of(ctx);
                 f.track_mask = 7 & ~f.finish_mask;
                 if (tracked) *tracked = true;
             }
@@ -1226,7 +1274,9 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
     if (want_track && !tracked && a.fast && front_fast_eligible(a)) {
         // a row shard writes every channel's exposure (its neighbours need them); the record covers the channels the halation's FFT
         // passes read, i.e. not the single-tap ones -- the same samples a whole-frame render records
-        a.track = static_cast<FrameParams*>(ctx->frame_buf.p);
+        int rc = ensure_range_tiles(ctx, H_global, W);
+        if (rc) return rc;
+        a.track = record_of(ctx);
         a.track_mask = 7;
         if (ctx->stencil[R2F_KERNEL_HALATION].present) {
             float w;
@@ -1265,8 +1315,9 @@ int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, i
         for (int c = 0; c < 3; ++c)
             if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &w)) mask &= ~(1 << c);
     }
-    R2F_HIP(ctx, launch_exposure_range(to_dev(exposure), y0, y1, y2, y3, W, mask, static_cast<FrameParams*>(ctx->frame_buf.p),
-                                       static_cast<hipStream_t>(stream)));
+    rc = ensure_range_tiles(ctx, std::max(std::max(y1, y3), exposure->gy0 + exposure->rows), W);
+    if (rc) return rc;
+    R2F_HIP(ctx, launch_exposure_range(to_dev(exposure), y0, y1, y2, y3, W, mask, record_of(ctx), static_cast<hipStream_t>(stream)));
     return R2F_OK;
 }
 
@@ -1992,8 +2043,25 @@ int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed)
     memcpy(&out4[1], &v.e_max, 4);
     dyn_rule(ctx, &out4[2], &out4[3]);
     *armed = ctx->frame_dyn_armed ? 1 : 0;
-    // (the kernels' own comparison; a block nobody has written a range into since its reset tells nothing)
-    *packed = (*armed && v.e_min != kFrameMinReset && out4[1] <= out4[2] * std::max(out4[0], out4[3])) ? 1 : 0;
+    // the choice is made per window pair (r2f_frame_scratch_choice has the counts): *packed says whether EVERY pair of the last
+    // halation call took the 12-byte element
+    int pairs = 0, packed_pairs = 0;
+    int rc = r2f_frame_scratch_choice(ctx, &pairs, &packed_pairs);
+    if (rc) return rc;
+    *packed = (*armed && pairs > 0 && packed_pairs == pairs) ? 1 : 0;
+    return R2F_OK;
+}
+
+int r2f_frame_scratch_choice(r2f_ctx* ctx, int* pairs, int* packed_pairs) {
+    if (!ctx || !pairs || !packed_pairs) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    *pairs = *packed_pairs = 0;
+    if (!ctx->frame_dyn_armed || !ctx->dyn_flags.p || ctx->dyn_flags_ppc <= 0) return R2F_OK;
+    R2F_HIP(ctx, hipDeviceSynchronize());
+    std::vector<int> flags((size_t)ctx->dyn_flags_ppc);
+    R2F_HIP(ctx, hipMemcpy(flags.data(), ctx->dyn_flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+    *pairs = ctx->dyn_flags_ppc;
+    for (int f : flags) *packed_pairs += f != 0;
     return R2F_OK;
 }
 

@@ -5,6 +5,8 @@
 // contraction on this path, so no MFMA.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -257,6 +259,48 @@ __device__ __forceinline__ void curve_eval_near_lds(const float4* cells, const D
         const float v = fmaf(c[k].w, x[k] - c[k].x, c[k].z);
         x[k] = !(x[k] > cv.x0) ? f_first : (x[k] >= cv.x1 ? f_last : v);
     }
+}
+
+// ---------------------------------------------------------------------------- the exposure-range record, per tile
+// The frame-level range above decides nothing any more (it is kept for the measurement harness): the halation's FFT passes choose
+// their scratch element PER WINDOW PAIR from the range of the samples that pair's two windows hold -- the error of the 12-byte
+// element scales with the energy of the window a pixel shares, not of the frame (r2f_api.hip, dyn_rule) -- and a window's range
+// comes from a grid of tiles over the GLOBAL frame: tile (gy / 64, x / 256) holds {min, max |.|} of the exposure samples recorded
+// for its pixels (float bit patterns; reset = {+inf, 0}: a tile nobody wrote to says "unknown", and a window that touches one keeps
+// complex128).  The front kernel writes it (a wave covers 256 columns of a row: one tile column), r2f_stage_exposure_range adds
+// rows that came from elsewhere, fft_decide_kernel reads the <= 6 x 4 tiles a window touches.
+constexpr int kRangeTileRows = 64, kRangeTileRowsLog2 = 6, kRangeTileCols = 256, kRangeTileColsLog2 = 8;
+struct RangeRecord {
+    FrameParams* blk;  // the frame-level extremes; nullptr: nothing is recorded
+    int2* tiles;       // tyn x txn tiles {min bits, max bits}; nullptr: none
+    int tyn, txn;
+};
+__device__ __forceinline__ void merge_tile(const RangeRecord& rec, int gy, int tx, float lo, float hi) {
+    if (!rec.tiles) return;
+    const int ty = gy >> kRangeTileRowsLog2;
+    if ((unsigned)ty >= (unsigned)rec.tyn || (unsigned)tx >= (unsigned)rec.txn) return;
+    int2* t = rec.tiles + (long long)ty * rec.txn + tx;
+    const int ilo = __float_as_int(lo), ihi = __float_as_int(hi);
+    if (ilo < __atomic_load_n(&t->x, __ATOMIC_RELAXED)) atomicMin(&t->x, ilo);
+    if (ihi > __atomic_load_n(&t->y, __ATOMIC_RELAXED)) atomicMax(&t->y, ihi);
+}
+// min / max of a value over the 64 lanes of a wave, by DPP (no LDS): the result is valid in every lane of the LAST row (lanes 48-63);
+// callers read lane 63.
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_extreme(float v) {
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); };
+    auto dpp = [](float x, auto ctrl_tag, auto row_mask_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value, RM = decltype(row_mask_tag)::value;
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, RM, 0xF, false));
+    };
+    using std::integral_constant;
+    v = op(v, dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{}));   // quad_perm [1, 0, 3, 2]
+    v = op(v, dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{}));   // quad_perm [2, 3, 0, 1]
+    v = op(v, dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{}));  // row_half_mirror
+    v = op(v, dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{}));  // row_mirror: every lane of a row holds the row's
+    v = op(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{}));  // row_bcast15 into rows 1 and 3
+    v = op(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{}));  // row_bcast31 into rows 2 and 3
+    return v;
 }
 
 // S0: out = M . in, ((m0*r + m1*g) + m2*b)

@@ -21,8 +21,8 @@
 //   * pass 2 of 256-row windows with a real spectrum runs as a resident grid whose workgroups WALK the launch's pairs for their
 //     16 columns, the spectrum in registers from pair to pair (fft_cols_walk_kernel);
 //   * the scratch element is a template parameter of every pass: complex128, complex64 (the MTF: density is bounded), or a
-//     12-byte element of doubles rounded to 48 bits -- for the halation of a whole-frame render chosen ON THE DEVICE per frame
-//     from the exposure range the front kernel recorded (ST = 3 kernels branch on dyn_packed once, wave-uniformly).
+//     12-byte element of doubles rounded to 48 bits -- for the halation chosen ON THE DEVICE per window pair from the exposure
+//     range recorded for the pair's samples (ST = 3 kernels read the pair's flag, wave-uniformly; round 6: per pair, not per frame).
 //
 // A 256-point line is transformed by 16 lanes holding 16 elements each (element n = lane + 16 m): a 16-point DFT in
 // registers, the twiddles W_256^(lane p), a 16 x 16 transpose through LDS, a second 16-point DFT -- natural order in and
@@ -293,18 +293,47 @@ __device__ __forceinline__ void sst(void* base, unsigned idx, const cplx v) {
     } else
         *reinterpret_cast<cplx*>(reinterpret_cast<char*>(base) + (idx << 4)) = v;
 }
-// s32 == 3 (FftConvArgs::dyn): the 12-byte element when the range of the samples this frame's launches read allows it -- max |x|
-// within dyn_bound times the smallest sample that matters (samples below dyn_floor end on the clamped part of the density curve).
-// Wave-uniform (scalar loads of the frame block); a NaN anywhere makes the comparison false: complex128.
-__device__ __forceinline__ bool dyn_packed(const FftConvArgs& a) {
-    const float lo = __uint_as_float(a.dyn->e_min), hi = __uint_as_float(a.dyn->e_max);
-    return hi <= a.dyn_bound * fmaxf(lo, a.dyn_floor);
-}
+// s32 == 3 (FftConvArgs::dyn_flags): the element is chosen PER WINDOW PAIR -- the 12-byte one when the range of the samples the pair's
+// two windows hold allows it: max |x| within `bound` times the smallest sample that matters (samples below `floor` end on the clamped
+// part of the density curve).  fft_decide_kernel (below) works that out once per call from the exposure-range tiles and leaves one flag
+// per pair-in-channel; the passes read theirs with a scalar load (the pair is wave-uniform).  Scratch images of such a launch are
+// 16 bytes per element apart whatever they hold, so that pairs of either kind can sit next to each other.
+__device__ __forceinline__ bool pair_packed(const FftConvArgs& a, int pc) { return a.dyn_flags[pc] != 0; }
 
-// scratch image of pair `pair` (n elements each)
+// scratch image of pair `pair` (n elements each); ST = 3: 16-byte pitch (see above)
 template <int ST>
 __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) {
     return reinterpret_cast<char*>(s1) + pair * n * (ST == 1 ? 8 : (ST == 2 ? 12 : 16));
+}
+
+// One thread per pair-in-channel: {min, max |.|} over the tiles the pair's two windows touch -> flags[pc].  A window reads the
+// global rows [wy, wy + ny) and columns [wx, wx + nx), reflected (101) into the frame -- which lands inside the part of the
+// window that is in the frame -- and, for a row shard, clamped to the rows its source buffer holds (pass 1): the tile range
+// below is that.  A tile nobody recorded (reset values) means "unknown": complex128.
+__global__ __launch_bounds__(256) void fft_decide_kernel(const FftConvArgs a, const RangeRecord rec, const float bound, const float floor_, int* flags) {
+    const int pc = blockIdx.x * 256 + threadIdx.x;
+    if (pc >= a.ppc) return;
+    int lo = (int)kFrameMinReset, hi = 0;
+    bool known = rec.tiles != nullptr;
+    for (int half = 0; half < 2 && known; ++half) {
+        int wy, wx;
+        if (!window_of(a, 2 * pc + half, wy, wx)) continue;
+        const int b0 = a.src.gy0, b1 = a.src.gy0 + a.src.rows - 1;
+        const int r0 = clampi(max(wy, 0), b0, b1), r1 = clampi(min(wy + a.ny - 1, a.H_global - 1), b0, b1);
+        const int c0 = max(wx, 0), c1 = min(wx + a.nx - 1, a.W - 1);
+        for (int ty = r0 >> kRangeTileRowsLog2; ty <= (r1 >> kRangeTileRowsLog2); ++ty)
+            for (int tx = c0 >> kRangeTileColsLog2; tx <= (c1 >> kRangeTileColsLog2); ++tx) {
+                if ((unsigned)ty >= (unsigned)rec.tyn || (unsigned)tx >= (unsigned)rec.txn) {
+                    known = false;
+                    continue;
+                }
+                const int2 t = rec.tiles[(long long)ty * rec.txn + tx];
+                if (t.x == (int)kFrameMinReset && t.y == (int)kFrameMaxReset) known = false;
+                lo = min(lo, t.x), hi = max(hi, t.y);
+            }
+    }
+    const float flo = __int_as_float(lo), fhi = __int_as_float(hi);
+    flags[pc] = (known && fhi <= bound * fmaxf(flo, floor_)) ? 1 : 0;  // (a NaN anywhere makes the comparison false)
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 1
@@ -405,11 +434,11 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(__builtin_isfinite(fa[m]) ? (double)fa[m] : 0.0, __builtin_isfinite(fb[m]) ? (double)fb[m] : 0.0);
     }
-    // ST = 3 (element chosen per frame on the device): the choice is needed at the stores only, so the frame block is read HERE --
+    // ST = 3 (element chosen per window pair on the device): the choice is needed at the stores only, so the pair's flag is read HERE --
     // behind the issue of the window loads, its round trip under the loads and the transform -- instead of at the top of the kernel,
-    // where every workgroup's first global load waited for it (+2.2 us per launch of 1 536 short workgroups, measured with rocprofv3)
+    // where every workgroup's first global load would wait for it
     bool packed = false;
-    if (ST == 3) packed = dyn_packed(a);
+    if (ST == 3) packed = pair_packed(a, pc);
     if (!(R2F_FFT_EXP & 4)) {
         G::template fft<false>(v, a, l, wave_tbuf(fsm), lane);
     }
@@ -419,12 +448,11 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftConvArgs& a, double* 
     const int rs = blockIdx.x * G::ROWS + tid / LPL;
     const unsigned sb = sidx(rs, G::out_col(l, 0), G::NBX);
     if (ST == 3) {
+        char* s1 = simg<3>(a.s1, pair, (long long)a.ny * NX);  // (16-byte pitch between the pairs' images whatever they hold)
         if (packed) {
-            char* s1 = simg<2>(a.s1, pair, (long long)a.ny * NX);
 #pragma unroll
             for (int q = 0; q < 16; ++q) sst<2>(s1, sb + q * 256, v[q]);
         } else {
-            char* s1 = simg<0>(a.s1, pair, (long long)a.ny * NX);
 #pragma unroll
             for (int q = 0; q < 16; ++q) sst<0>(s1, sb + q * 256, v[q]);
         }
@@ -616,7 +644,8 @@ __device__ __forceinline__ void fft_cols_walk_body(const FftConvArgs& a, double*
     double kr[16];
     int ci_have = -1;
     for (int pair = blockIdx.y; pair < a.npairs; pair += G) {
-        const int ci = (a.pair0 + pair) / a.ppc;
+        const int gp = a.pair0 + pair, ci = gp / a.ppc;
+        const bool packed = ST == 3 ? pair_packed(a, gp - ci * a.ppc) : false;  // (wave-uniform: a scalar load and a scalar branch)
         char* s1 = simg<ST>(a.s1, pair, img);
         unsigned sbase = sidx(l, k, NBX);  // element (row l + 16 q, column k) = sbase + q * NBX * 256
         cplx w = w1;
@@ -628,30 +657,47 @@ __device__ __forceinline__ void fft_cols_walk_body(const FftConvArgs& a, double*
             ci_have = ci;
         }
         cplx v[16];
+        if (ST == 3) {  // the transforms in between are shared: only the loads and the stores come in two forms
+            if (packed) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = sld<ST>(s1, sbase + m * (NBX * 256));
+                for (int m = 0; m < 16; ++m) v[m] = sld<2>(s1, sbase + m * (NBX * 256));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) v[m] = sld<0>(s1, sbase + m * (NBX * 256));
+            }
+        } else {
+            constexpr int STL = ST == 3 ? 0 : ST;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = sld<STL>(s1, sbase + m * (NBX * 256));
+        }
         fft256<false>(v, w, tbuf, lane);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = make_double2(v[q].x * kr[q], v[q].y * kr[q]);
         asm volatile("" : "+v"(w.x), "+v"(w.y));
         fft256<true>(v, w, tbuf, lane);
+        if (ST == 3) {
+            if (packed) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<ST>(s1, sbase + q * (NBX * 256), v[q]);
+                for (int q = 0; q < 16; ++q)
+                    if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<2>(s1, sbase + q * (NBX * 256), v[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<0>(s1, sbase + q * (NBX * 256), v[q]);
+            }
+        } else {
+            constexpr int STS = ST == 3 ? 0 : ST;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if ((unsigned)(l + 16 * q - a.oy) < (unsigned)a.vy) sst<STS>(s1, sbase + q * (NBX * 256), v[q]);
+        }
     }
 }
 
 template <int NBX, int ST>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fft_cols_walk_kernel(const FftConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    if (ST == 3) {
-        if (dyn_packed(a))
-            fft_cols_walk_body<NBX, 2>(a, fsm);
-        else
-            fft_cols_walk_body<NBX, 0>(a, fsm);
-    } else {
-        fft_cols_walk_body<NBX, ST>(a, fsm);
-    }
+    fft_cols_walk_body<NBX, ST>(a, fsm);  // (ST = 3: the body reads every pair's own flag)
 }
 
 // ---------------------------------------------------------------------------------------------------- pass 3
@@ -673,9 +719,9 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
     // and 128-byte lines as they do for oy = 0 (an odd first row had cost the MTF's pass 0.10 of 0.44 ms).  ro: output row.
     const int pair = blockIdx.y, r = (a.oy & ~(G::ROWS - 1)) + blockIdx.x * G::ROWS + threadIdx.x / LPL, ro = r - a.oy;
     const bool live = (unsigned)ro < (unsigned)a.vy;  // dead lines still take part in the wave's transposes (their data is never stored)
-    // ST = 3: the frame block is read here, ahead of the copy of the curve cells, so that its round trip is over when the loads need it
+    // ST = 3: the pair's flag is read here, ahead of the copy of the curve cells, so that its round trip is over when the loads need it
     bool packed = false;
-    if (ST == 3) packed = dyn_packed(a);
+    if (ST == 3) packed = pair_packed(a, (a.pair0 + pair) % a.ppc);
     // The epilogue's curve cells: 32 divergent 16-byte gathers per lane.  From global memory they go through the texture path at
     // 0.9 lanes per clock and CU (profiles/r02_gather_rate.txt) -- more of its cycles than all of the pass's coalesced scratch
     // loads and stores; from LDS at 4.3.  The workgroup's channel has (m - 1) cells of 16 bytes: copied behind the transpose
@@ -692,12 +738,11 @@ __device__ __forceinline__ void fft_rows_inv_body(const FftConvArgs& a, double* 
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = make_double2(1.0 + m + l, 0.5 * r);
     } else if (ST == 3) {
+        const char* s1 = simg<3>(a.s1, pair, (long long)a.ny * NX);
         if (packed) {
-            const char* s1 = simg<2>(a.s1, pair, (long long)a.ny * NX);
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = sld<2>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
         } else {
-            const char* s1 = simg<0>(a.s1, pair, (long long)a.ny * NX);
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = sld<0>(s1, sidx(live ? r : a.oy, l + LPL * m, G::NBX));
         }
@@ -868,6 +913,12 @@ static void launch_cols_walk(const FftConvArgs& a, hipStream_t s) {
 }
 
 hipError_t fft_init_attributes() { return hipSuccess; }
+
+hipError_t launch_fft_decide(const FftConvArgs& a, const RangeRecord& rec, float bound, float floor_, int* flags, hipStream_t s) {
+    if (a.ppc <= 0) return hipSuccess;
+    launch_k(fft_decide_kernel, dim3((a.ppc + 255) / 256), dim3(256), 0, s, a, rec, bound, floor_, flags);
+    return take_launch_status();
+}
 
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s) {
     if (cols_walk_applies(a, mode)) {

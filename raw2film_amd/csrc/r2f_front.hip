@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     // range of the exposure samples this lane writes for the halation's FFT passes (UPTO = EXPOSURE with a.track): min and max |.|
     float t_lo = __builtin_inff(), t_hi = 0.f;
-    const bool track = UPTO == R2F_UPTO_EXPOSURE && a.track != nullptr;
+    const bool track = UPTO == R2F_UPTO_EXPOSURE && a.track.blk != nullptr;
     if (x >= a.W && !track) return;
     const int W = a.W;
     const float* in = static_cast<const float*>(a.in);
@@ -171,9 +171,36 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
     // 2 any mask): a wave-uniform test of a.track inside the pixel loop is a scalar branch per pixel, i.e. four basic-block borders in
     // what the scheduler otherwise treats as one block with the LUT gathers of four pixels in flight together (+21 us per 100 MP
     // frame with the test inside, rocprofv3).  Only the EXPOSURE instances can track; the others compile the loop once.
+    // Tracking also fills the record's TILES (r2f_device.h RangeRecord: 64 rows x 256 columns of the global frame; a wave's 64 lanes x
+    // 4 pixels are one tile column): a lane gathers its extremes while the wave stays inside one tile row and the wave merges them
+    // into the tile when it leaves (one DPP reduction and at most two atomics per wave and tile) -- for which a tracking workgroup
+    // row walks a CONTIGUOUS chunk of the row groups (a tile row = 64 / BY consecutive iterations) instead of every gridDim.y-th one.
     auto row_loop = [&](auto trk_tag) {
     constexpr int TRK = decltype(trk_tag)::value;
-    for (int gy = a.y0 + blockIdx.y * BY + threadIdx.y; gy < a.y1 && x < W; gy += gridDim.y * BY) {
+    const int groups = (a.y1 - a.y0 + BY - 1) / BY;
+    const int g_begin = TRK ? (int)((long long)blockIdx.y * groups / gridDim.y) : (int)blockIdx.y;
+    const int g_end = TRK ? (int)((long long)(blockIdx.y + 1) * groups / gridDim.y) : groups;
+    const int g_step = TRK ? 1 : (int)gridDim.y;
+    float p_lo = __builtin_inff(), p_hi = 0.f;  // this lane's extremes inside the tile row p_ty
+    int p_ty = -1;
+    auto flush = [&]() {
+        if (p_ty < 0) return;
+        const float w_lo = wave_extreme<false>(p_lo), w_hi = wave_extreme<true>(p_hi);
+        if (threadIdx.x == 63) merge_tile(a.track, p_ty << kRangeTileRowsLog2, blockIdx.x, w_lo, w_hi);
+        t_lo = fminf(t_lo, p_lo), t_hi = fmaxf(t_hi, p_hi);
+        p_lo = __builtin_inff(), p_hi = 0.f;
+    };
+    for (int grp = g_begin; grp < g_end; grp += g_step) {
+        const int gy = a.y0 + grp * BY + threadIdx.y;
+        if (gy >= a.y1) break;
+        if (TRK) {  // (gy is wave-uniform: a wave is one row)
+            const int ty = gy >> kRangeTileRowsLog2;
+            if (ty != p_ty) {
+                flush();
+                p_ty = ty;
+            }
+        }
+        if (x >= W) continue;
         const long long irow = gy - a.in_gy0;
         float r[4], g[4], b[4];
         if (LAYOUT == R2F_LAYOUT_CHW) {
@@ -206,12 +233,12 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
                 // (fminf / fmaxf drop a NaN: pass 1 of the FFT form takes a non-finite sample as 0 anyway; an infinity stays)
                 if (TRK == 1) {
-                    t_lo = fminf(fminf(t_lo, r[q]), g[q]);
-                    t_hi = fmaxf(fmaxf(t_hi, fabsf(r[q])), fabsf(g[q]));
+                    p_lo = fminf(fminf(p_lo, r[q]), g[q]);
+                    p_hi = fmaxf(fmaxf(p_hi, fabsf(r[q])), fabsf(g[q]));
                 } else if (TRK == 2) {
-                    if (a.track_mask & 1) t_lo = fminf(t_lo, r[q]), t_hi = fmaxf(t_hi, fabsf(r[q]));
-                    if (a.track_mask & 2) t_lo = fminf(t_lo, g[q]), t_hi = fmaxf(t_hi, fabsf(g[q]));
-                    if (a.track_mask & 4) t_lo = fminf(t_lo, b[q]), t_hi = fmaxf(t_hi, fabsf(b[q]));
+                    if (a.track_mask & 1) p_lo = fminf(p_lo, r[q]), p_hi = fmaxf(p_hi, fabsf(r[q]));
+                    if (a.track_mask & 2) p_lo = fminf(p_lo, g[q]), p_hi = fmaxf(p_hi, fabsf(g[q]));
+                    if (a.track_mask & 4) p_lo = fminf(p_lo, b[q]), p_hi = fmaxf(p_hi, fabsf(b[q]));
                 }
                 if (FIN) {  // same arithmetic as single_tap_kernel with the halation epilogue: w * x, log10, curve
                     if (a.finish_mask & 1) r[q] = curve_eval_at((const float4*)cells_lds, a.curve, 0, log10_fast(a.finish_w[0] * r[q], a.log_eps));
@@ -282,6 +309,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             o32[2] = u8_of(b[2]) | (u8_of(r[3]) << 8) | (u8_of(g[3]) << 16) | (u8_of(b[3]) << 24);
         }
     }
+    if (TRK) flush();
     };
     if (!track)
         row_loop(std::integral_constant<int, 0>{});
@@ -295,7 +323,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             t_lo = fminf(t_lo, __shfl_xor(t_lo, m));
             t_hi = fmaxf(t_hi, __shfl_xor(t_hi, m));
         }
-        if (threadIdx.x == 0) merge_range(a.track, t_lo, t_hi);
+        if (threadIdx.x == 0) merge_range(a.track.blk, t_lo, t_hi);
     }
 }
 

@@ -1322,55 +1322,66 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s) {
 
 // mode 0: only the seed (a stage entry's own write in the middle of a frame keeps the exposure range the front kernel recorded);
 // 1: the whole block (seed + range reset: the start of a frame); 2: only the range reset (a caller that keeps the seed resident);
-// 3: the range is made unusable (max = +inf: the FFT passes keep complex128) -- a front kernel that was asked to record the range
-// of what it writes and cannot
-__global__ void frame_params_kernel(FrameParams* dst, const FrameParams v, const int mode) {
-    if (mode == 1)
-        *dst = v;
-    else if (mode == 0)
-        dst->seed = v.seed;
-    else if (mode == 2)
-        dst->e_min = v.e_min, dst->e_max = v.e_max;
-    else
-        dst->e_max = 0x7f800000u;
+// 3: the range is made unusable (max = +inf) -- a front kernel that was asked to record the range of what it writes and cannot (its
+// rows' TILES simply stay unwritten, which the per-window choice reads as "unknown": complex128).
+// Modes 1 and 2 also reset the record's tile grid ({+inf, 0} = unknown), one thread per tile.
+__global__ __launch_bounds__(256) void frame_params_kernel(FrameParams* dst, const FrameParams v, const int mode, int2* tiles, const int n_tiles) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        if (mode == 1)
+            *dst = v;
+        else if (mode == 0)
+            dst->seed = v.seed;
+        else if (mode == 2)
+            dst->e_min = v.e_min, dst->e_max = v.e_max;
+        else
+            dst->e_max = 0x7f800000u;
+    }
+    if ((mode == 1 || mode == 2) && i < n_tiles) tiles[i] = make_int2((int)kFrameMinReset, (int)kFrameMaxReset);
 }
 
-hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int mode, hipStream_t s) {
-    launch_k(frame_params_kernel, dim3(1), dim3(1), 0, s, dst, v, mode);
+hipError_t launch_frame_params(const RangeRecord& rec, const FrameParams& v, int mode, hipStream_t s) {
+    const int n_tiles = (rec.tiles && (mode == 1 || mode == 2)) ? rec.tyn * rec.txn : 0;
+    launch_k(frame_params_kernel, dim3(n_tiles > 0 ? (n_tiles + 255) / 256 : 1), dim3(n_tiles > 0 ? 256 : 1), 0, s, rec.blk, v, mode, rec.tiles,
+             n_tiles);
     return take_launch_status();
 }
 
-// min / max |.| of rows [y0, y1) and [y2, y3) of the planes in `mask`, merged into the frame block like the front kernel's own record
-// (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours above and below, one launch for both bands).
-// NaNs drop out of fminf / fmaxf, like there.
+// min / max |.| of rows [y0, y1) and [y2, y3) of the planes in `mask`, merged into the record like the front kernel's own: the frame
+// block and the tile grid (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours above and below, one
+// launch for both bands).  A wave takes 256 columns of one row -- one tile column, like a wave of the front kernel; grid
+// (ceil(W / 256), ceil(rows / 4)), block (64, 4).  NaNs drop out of fminf / fmaxf, like there.
 __global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src, const int y0, const int y1, const int y2, const int y3,
-                                                              const int W, const int mask, FrameParams* dst) {
+                                                              const int W, const int mask, const RangeRecord rec) {
+    const int n0 = y1 - y0, r = blockIdx.y * 4 + threadIdx.y;
+    if (r >= n0 + (y3 - y2)) return;
+    const int gy = r < n0 ? y0 + r : y2 + (r - n0);
     float lo = __builtin_inff(), hi = 0.f;
-    const long long n0 = (long long)(y1 - y0) * W, n = n0 + (long long)(y3 - y2) * W;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     for (int c = 0; c < 3; ++c) {
         if (!((mask >> c) & 1)) continue;
-        const float* p0 = src.data + c * src.plane_stride + (long long)(y0 - src.gy0) * W;
-        const float* p1 = src.data + c * src.plane_stride + (long long)(y2 - src.gy0) * W - n0;
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-            const float v = i < n0 ? p0[i] : p1[i];
-            lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
-        }
-    }
+        const float* p = src.data + c * src.plane_stride + (long long)(gy - src.gy0) * W;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, m));
-        hi = fmaxf(hi, __shfl_xor(hi, m));
+        for (int k = 0; k < 4; ++k)
+            if (x0 + k < W) {
+                const float v = p[x0 + k];
+                lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
+            }
     }
-    if ((threadIdx.x & 63) == 0) merge_range(dst, lo, hi);
+    lo = wave_extreme<false>(lo), hi = wave_extreme<true>(hi);
+    if (threadIdx.x == 63) {
+        merge_tile(rec, gy, blockIdx.x, lo, hi);
+        merge_range(rec.blk, lo, hi);
+    }
 }
 
-hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, FrameParams* dst, hipStream_t s) {
+hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, const RangeRecord& rec, hipStream_t s) {
     if (y1 < y0) y1 = y0;
     if (y3 < y2) y3 = y2;
-    const long long n = (long long)(y1 - y0 + y3 - y2) * W;
-    if (n <= 0 || W <= 0 || !(mask & 7)) return hipSuccess;
-    const int blocks = (int)std::min<long long>((n + 1023) / 1024, 2048);
-    launch_k(exposure_range_kernel, dim3(blocks), dim3(256), 0, s, src, y0, y1, y2, y3, W, mask, dst);
+    const int rows = (y1 - y0) + (y3 - y2);
+    if (rows <= 0 || W <= 0 || !(mask & 7)) return hipSuccess;
+    launch_k(exposure_range_kernel, dim3((W + kRangeTileCols - 1) / kRangeTileCols, (rows + 3) / 4), dim3(64, 4), 0, s, src, y0, y1, y2, y3, W,
+             mask, rec);
     return take_launch_status();
 }
 

@@ -61,8 +61,8 @@ struct FrontArgs {
     float finish_w[3];
     DevPlanes finish_dst;
     // fast kernel, upto = EXPOSURE: min / max |.| of the exposure samples written to `dst` for the channels in track_mask (the ones
-    // the halation's FFT passes read) are accumulated into this frame block (nullptr: not tracked)
-    FrameParams* track;
+    // the halation's FFT passes read) are accumulated into this record: the frame block and the tile grid (blk = nullptr: not tracked)
+    RangeRecord track;
     int track_mask;
 };
 bool front_fast_eligible(const FrontArgs& a);
@@ -224,11 +224,11 @@ struct FftConvArgs {
     int cols_slots;           // ... on a grid of (up to) this many resident workgroups (2 per CU)
     double2* s1;              // npairs x ny x nx scratch images, transformed in place (layout: sidx in r2f_fft.hip)
     int s32;                  // scratch element: 0 complex128, 1 complex64 (half the bytes; the arithmetic stays fp64), 2 the 12-byte form,
-                              // 3 chosen ON THE DEVICE per frame between 0 and 2 from the input's range (dyn, below)
-    // s32 == 3: the frame block holding the range of the samples this launch reads (written by the front kernel of the same
-    // frame, in stream order), and the rule: the 12-byte element when max|x| <= dyn_bound * max(min x, dyn_floor)
-    const FrameParams* dyn;
-    float dyn_bound, dyn_floor;
+                              // 3 chosen ON THE DEVICE per window pair between 0 and 2 from the range of the pair's samples (dyn_flags)
+    // s32 == 3: one flag per pair-in-channel (index gp % ppc), written by fft_decide_kernel ahead of the call's launches from the
+    // exposure-range tiles: != 0 -> the pair's scratch image holds 12-byte elements (max |x| <= bound * max(min x, floor) over the
+    // pair's two windows), 0 -> complex128.  The pairs' images are 16 bytes per element apart either way.
+    const int* dyn_flags;
     int epilogue;
     DevCurve curve;
     float log_eps;
@@ -240,6 +240,7 @@ hipError_t fft_init_attributes();
 hipError_t launch_fft_rows_fwd(const FftConvArgs& a, hipStream_t s);
 hipError_t launch_fft_cols(const FftConvArgs& a, int mode, hipStream_t s);
 hipError_t launch_fft_rows_inv(const FftConvArgs& a, hipStream_t s);
+hipError_t launch_fft_decide(const FftConvArgs& a, const RangeRecord& rec, float bound, float floor_, int* flags, hipStream_t s);
 
 struct NoiseArgs {
     uint32_t* hash;
@@ -280,11 +281,11 @@ hipError_t launch_tail(const TailArgs& a, hipStream_t s);
 hipError_t launch_warp_affine(const WarpArgs& a, hipStream_t s);
 hipError_t launch_lanczos4_u8(const LanczosArgs& a, hipStream_t s);
 hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
-// *dst <- v on stream s (one lane): the per-render write of the context's FrameParams block ahead of a frame's launches
+// the per-render write of the context's FrameParams block (and the reset of the record's tiles) ahead of a frame's launches
 // mode: 0 seed only, 1 seed + range reset, 2 range reset only, 3 range made unusable (frame_params_kernel)
-hipError_t launch_frame_params(FrameParams* dst, const FrameParams& v, int mode, hipStream_t s);
+hipError_t launch_frame_params(const RangeRecord& rec, const FrameParams& v, int mode, hipStream_t s);
 // the range of rows [y0, y1) and [y2, y3) of the planes in `mask` merged into the frame block (r2f_stage_exposure_range)
-hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, FrameParams* dst, hipStream_t s);
+hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, const RangeRecord& rec, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
 hipError_t launch_histogram_u8(const uint8_t* image, long long n_bytes, uint32_t* counts, hipStream_t s);

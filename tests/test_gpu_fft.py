@@ -324,12 +324,21 @@ def test_the_halation_scratch_element_is_chosen_per_frame_on_the_device():
             c128 = render(frame, stencil_fft_scratch96_auto=0)
             forced = render(frame, stencil_fft_scratch96_auto=0, stencil_fft_scratch96=1)
             auto = render(frame)
-            np.testing.assert_array_equal(auto, forced if want_packed else c128)
+            rng = c.frame_exposure_range()
             ref = st.render(frame, p)
             assert np.max(np.abs(auto - ref) / np.maximum(np.abs(ref), 1e-3)) <= 1e-5
-            if want_packed:
+            if want_packed:  # every window pair qualifies: the forced element's frame, bit for bit
+                np.testing.assert_array_equal(auto, forced)
+                assert rng["pairs"] > 0 and rng["packed_pairs"] == rng["pairs"]
                 assert not np.array_equal(forced, c128)
                 assert np.max(np.abs(forced - c128) / np.maximum(np.abs(c128), 1e-3)) <= 2e-6
+            else:
+                # round 6: the choice is per WINDOW PAIR -- the pairs whose windows hold the specular or the deep shadows keep
+                # complex128, the others take the element: neither of the two uniform frames, and within the element's rounding of
+                # the complex128 one
+                assert 0 < rng["packed_pairs"] < rng["pairs"], rng
+                assert not np.array_equal(auto, forced) and not np.array_equal(auto, c128)
+                assert np.max(np.abs(auto - c128) / np.maximum(np.abs(c128), 1e-3)) <= 2e-6
         # one captured graph, two frames: the decision follows the CONTENT of the input buffer, frame by frame
         c.set_option("stencil_fft_scratch96_auto", 1)
         want = {}
@@ -397,7 +406,21 @@ def test_the_halation_scratch_element_is_chosen_per_frame_on_the_device():
             c.stage_halation(E, Dv, params, y0=0, y1=H, H_global=H, range_valid=True)
             rng = c.frame_exposure_range()
             assert rng["armed"] and rng["twelve_byte_element"] == want_packed, rng
-            assert torch.equal(Dv, want[1 if want_packed else 0])
+            if want_packed:
+                assert torch.equal(Dv, want[1])
+            else:
+                # per window pair: every output is the complex128 call's or the 12-byte call's, bit for bit (a window's valid
+                # outputs are one pair's); the ones around the specular (its window: complex128) and over the deep shadows
+                # are the complex128 call's, and far from both the element was taken
+                assert 0 < rng["packed_pairs"] < rng["pairs"], rng
+                either = (Dv == want[0]) | (Dv == want[1])
+                assert bool(either.all())
+                # (windows yield 172 x 428 outputs each here: the specular at (300, 500) sits in the window whose outputs are rows
+                # 172..343, columns 428..855 -- all of those are the complex128 call's, and the 12-byte call's differ among them)
+                assert torch.equal(Dv[:, 172:344, 428:856], want[0][:, 172:344, 428:856])
+                assert not torch.equal(want[1][:2, 172:344, 428:856], want[0][:2, 172:344, 428:856])
+                assert torch.equal(Dv[:, 60:140, 70:190], want[0][:, 60:140, 70:190])
+                assert bool((Dv[:2] != want[0][:2]).any())  # ... and somewhere it is the other element
             assert torch.equal(Dv[2], want[0][2])  # (the single-tap blue plane does not depend on any of this)
         # a front call that cannot record (the generic kernel: front_fast = 0) says so: the range becomes unusable
         c.set_option("front_fast", 0)

@@ -60,37 +60,38 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, mode):
     the windows are anchored at the shard's first row, so a pixel's 256 x 256 window differs between the two renders and
     with it the fp64 rounding noise (~1e-13): after the one rounding to fp32 a handful of pixels may differ by an ulp.
     fft_dyn (round 6): the shards keep the exposure-range record like r2f_render does (R2F_F_TRACK_RANGE on the front call,
-    R2F_F_RANGE_VALID on the halation) and are compared with the DEFAULT whole-frame render: both choose the 12-byte element on
-    this frame, each from its own rows' range; the element rounds per window, so the two tilings agree to ITS rounding."""
+    R2F_F_RANGE_VALID on the halation) and are compared with the DEFAULT whole-frame render: both choose per window pair, nearly
+    always the 12-byte element on this frame; the element rounds per window, so the two tilings agree to ITS rounding."""
     ctx, params, p, frame, out = full
     fft, dyn = mode != "direct", mode == "fft_dyn"
     ctx.set_option("stencil_fft", int(fft))
+    if fft:  # (the fixture's render is not the context's last one any more: render the default again and ask what it chose)
+        again, _ = ctx.render(frame, params)
+        assert torch.equal(again, out)
+        del again
     if not fft:
         out, _ = ctx.render(frame, params)
     elif not dyn:
-        # like for like: stage calls without the record keep complex128 scratch for the halation, and so does the whole-frame
-        # render of THIS frame -- its range (max / shadow = 1.4e5) is beyond the 12-byte element's guard since round 6, and kernels
-        # that choose on the device and choose complex128 compute what the complex128 kernels compute, bit for bit
+        # like for like: stage calls without the record keep complex128 scratch for the halation; the whole-frame render chooses its
+        # element per WINDOW PAIR from the pair's own range (round 6): the frame's range (max / shadow = 1.4e5) is beyond the
+        # element's guard (6.2e4), its windows' ranges (~2e4) are not -- nearly every pair takes the 12-byte element.  The fixture's
+        # default render must agree with the complex128 one to the element's own rounding (at most three ulps of a density)
         rng = ctx.frame_exposure_range()
+        assert rng["armed"] and rng["pairs"] > 500 and 0.9 * rng["pairs"] <= rng["packed_pairs"] <= rng["pairs"], rng
+        assert rng["max_abs"] > rng["bound"] * max(rng["min"], rng["floor"])  # (the FRAME would not qualify)
         ctx.set_option("stencil_fft_scratch96_auto", 0)
         exact, _ = ctx.render(frame, params)
         ctx.set_option("stencil_fft_scratch96_auto", 1)
-        assert torch.equal(exact, out)
-        del exact
-    else:
-        # a frame the guard accepts: the same one with its deepest shadows and brightest speculars clamped (max / shadow ~ 1e4)
-        frame = frame.clamp(4e-3, 48.0)
-        ctx.set_option("stencil_fft_scratch96_auto", 0)
-        exact, _ = ctx.render(frame, params)
-        exact = exact.clone()
-        ctx.set_option("stencil_fft_scratch96_auto", 1)
-        out, _ = ctx.render(frame, params)
-        rng = ctx.frame_exposure_range()
-        assert rng["armed"] and rng["twelve_byte_element"], rng
         d = (exact - out).abs()
         assert float((d / exact.abs().clamp_min(1e-3)).max()) <= 2e-6
         assert 0 < float((d > 0).float().mean()) <= 5e-3  # (it IS the other element: a few pixels in ten thousand differ)
-        del d, exact
+        out = exact
+        del d
+    else:
+        # the shards keep the record and choose per window pair like the whole frame does; their windows are anchored at the shard's
+        # first row, so a pixel's window -- and with it the element's rounding -- differs between the two renders
+        rng = ctx.frame_exposure_range()
+        assert rng["armed"] and rng["packed_pairs"] > 0, rng
     rh, rm = p.halation_kernel.shape[0] // 2, p.mtf_kernel.shape[0] // 2
     bounds = [0, 1000, 4096, 5121, H_FULL]  # uneven shards, each at least a halo tall
     worst = 0.0
@@ -105,7 +106,7 @@ def test_row_shards_of_the_100mp_frame_match_the_whole_frame(full, mode):
         ctx.stage_halation(E, D, params, src_gy0=e_lo, dst_gy0=d_lo, y0=d_lo, y1=d_hi, H_global=H_FULL, range_valid=dyn)
         if dyn:
             rng = ctx.frame_exposure_range()
-            assert rng["armed"] and rng["twelve_byte_element"], rng
+            assert rng["armed"] and rng["packed_pairs"] >= 0.9 * rng["pairs"] > 0, rng
         D2 = torch.empty((3, b - a, W_FULL), dtype=torch.float32, device="cuda")
         ctx.stage_mtf(D, D2, params, src_gy0=d_lo, dst_gy0=a, y0=a, y1=b, H_global=H_FULL)
         part = torch.empty((b - a, W_FULL, 3), dtype=torch.float32, device="cuda")
