@@ -2039,8 +2039,17 @@ int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed)
     R2F_HIP(ctx, hipDeviceSynchronize());
     FrameParams v{};
     R2F_HIP(ctx, hipMemcpy(&v, ctx->frame_buf.p, sizeof v, hipMemcpyDeviceToHost));
-    memcpy(&out4[0], &v.e_min, 4);
-    memcpy(&out4[1], &v.e_max, 4);
+    // the frame's extremes = the extremes over the record's tiles (the kernels merge into tiles only: nothing decides on the frame's
+    // range any more); a record marked unusable (a front kernel that could not record) reads as max = +inf
+    int lo = (int)kFrameMinReset, hi = (int)kFrameMaxReset;
+    if (ctx->range_tiles.p && ctx->tiles_tyn > 0) {
+        std::vector<int2> tiles((size_t)ctx->tiles_tyn * ctx->tiles_txn);
+        R2F_HIP(ctx, hipMemcpy(tiles.data(), ctx->range_tiles.p, tiles.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        for (const int2& t : tiles) lo = std::min(lo, t.x), hi = std::max(hi, t.y);
+    }
+    if (v.e_max == 0x7f800000u) hi = 0x7f800000;
+    memcpy(&out4[0], &lo, 4);
+    memcpy(&out4[1], &hi, 4);
     dyn_rule(ctx, &out4[2], &out4[3]);
     *armed = ctx->frame_dyn_armed ? 1 : 0;
     // the choice is made per window pair (r2f_frame_scratch_choice has the counts): *packed says whether EVERY pair of the last

@@ -158,8 +158,7 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         __syncthreads();
     }
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    // range of the exposure samples this lane writes for the halation's FFT passes (UPTO = EXPOSURE with a.track): min and max |.|
-    float t_lo = __builtin_inff(), t_hi = 0.f;
+    // (UPTO = EXPOSURE with a.track: the range of the exposure samples written for the halation's FFT passes goes into the record's tiles)
     const bool track = UPTO == R2F_UPTO_EXPOSURE && a.track.blk != nullptr;
     if (x >= a.W && !track) return;
     const int W = a.W;
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         if (p_ty < 0) return;
         const float w_lo = wave_extreme<false>(p_lo), w_hi = wave_extreme<true>(p_hi);
         if (threadIdx.x == 63) merge_tile(a.track, p_ty << kRangeTileRowsLog2, blockIdx.x, w_lo, w_hi);
-        t_lo = fminf(t_lo, p_lo), t_hi = fmaxf(t_hi, p_hi);
         p_lo = __builtin_inff(), p_hi = 0.f;
     };
     for (int grp = g_begin; grp < g_end; grp += g_step) {
@@ -317,14 +315,9 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         row_loop(std::integral_constant<int, 1>{});
     else
         row_loop(std::integral_constant<int, 2>{});
-    if (track) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            t_lo = fminf(t_lo, __shfl_xor(t_lo, m));
-            t_hi = fmaxf(t_hi, __shfl_xor(t_hi, m));
-        }
-        if (threadIdx.x == 0) merge_range(a.track.blk, t_lo, t_hi);
-    }
+    // (no frame-level merge here: thousands of waves looking at ONE address at the end of the kernel serialise in its L2 channel --
+    // 23 us on a 22-us front call of a 1/8 row shard -- and nothing decides on the frame's extremes any more; the measurement
+    // harness reduces the tiles on the host, r2f_frame_exposure_range)
 }
 
 size_t fast_lds_bytes(const FrontArgs& a) {

@@ -1369,10 +1369,7 @@ __global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src
             }
     }
     lo = wave_extreme<false>(lo), hi = wave_extreme<true>(hi);
-    if (threadIdx.x == 63) {
-        merge_tile(rec, gy, blockIdx.x, lo, hi);
-        merge_range(rec.blk, lo, hi);
-    }
+    if (threadIdx.x == 63) merge_tile(rec, gy, blockIdx.x, lo, hi);
 }
 
 hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, const RangeRecord& rec, hipStream_t s) {

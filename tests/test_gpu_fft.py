@@ -482,6 +482,52 @@ def test_the_guard_of_the_twelve_byte_element_stands_on_a_search(ctx):
         assert float(np.max(err - np.abs(D[0][:2]) * 2.0 ** -23)) <= 3.6e-7, (kind, fill, float(err.max()))
 
 
+def test_the_per_window_choice_keeps_the_promise_where_the_frame_level_one_could_not_even_be_made(ctx):
+    """A frame whose left half is bright (1 000 .. 2 000) and whose right half is deep shadow (1e-3 .. 2e-3): max / min = 2e6, no
+    frame-level rule would let the 12-byte element near it.  Per window pair (round 6) the windows that lie inside one half span a
+    factor 2 and take the element; the ones astride the edge keep complex128 -- and the promise holds everywhere: the density
+    (halation + log + curve) is within three fp32 ulps of a density in [1, 2) (+ the ulp two fp32 roundings may differ by) of the
+    complex128 call's.  Forcing the element on every window breaks it on the shadows beside the edge (2.7 x the promise here, on
+    the shallow toe of this curve): that is what the guard is for."""
+    neg, _, _ = stocks()
+    rng = np.random.default_rng(12)
+    H, W = 700, 2200
+    img = np.empty((H, W, 3), dtype=np.float32)
+    img[:, :1000] = rng.uniform(1000.0, 2000.0, (H, 1000, 3))
+    img[:, 1000:] = rng.uniform(1e-3, 2e-3, (H, W - 1000, 3))
+    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)
+    ctx.set_curve1d(neg.get_density_curve(0.0, 1.0))
+    ctx.set_kernel(0, k)
+    ctx.set_option("stencil_fft_window_rows", 256)
+    ctx.set_option("stencil_fft_window", 512)
+    params = ctx.make_params(halation=True)
+    E = planes(img)  # (exposure planes handed in directly; their range goes into the record through the range kernel)
+    D = {}
+    for name, opts in (("c128", dict(stencil_fft_scratch96=0)), ("forced", dict(stencil_fft_scratch96=1))):
+        for o, v in opts.items():
+            ctx.set_option(o, v)
+        d = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_halation(E, d, params, y0=0, y1=H, H_global=H)
+        D[name] = d.cpu().numpy().astype(np.float64)
+    ctx.set_option("stencil_fft_scratch96", 0)
+    ctx.write_frame_params(params)
+    ctx.stage_exposure_range(E, y0=0, y1=H)
+    d = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_halation(E, d, params, y0=0, y1=H, H_global=H, range_valid=True)
+    D["chosen"] = d.cpu().numpy().astype(np.float64)
+    info = ctx.frame_exposure_range()
+    assert info["armed"] and 0 < info["packed_pairs"] < info["pairs"], info
+    assert info["max_abs"] / info["min"] > 1e6
+
+    def worst(name):
+        err = np.abs(D[name][:2] - D["c128"][:2]) - np.abs(D["c128"][:2]) * 2.0 ** -23
+        return float(err.max())
+
+    assert worst("chosen") <= 3.6e-7, worst("chosen")
+    assert worst("forced") > 2 * 3.6e-7, worst("forced")  # (measured 9.8e-7: the toe of the curve is shallow where these shadows sit)
+    assert not np.array_equal(D["chosen"], D["c128"])  # (the element WAS taken where it may be)
+
+
 @pytest.mark.parametrize("window", WINDOWS)
 def test_real_spectrum_of_centrally_symmetric_taps(ctx, window):
     """Round 5.  Both production stencils are centrally symmetric around an anchor at the centre of their tap

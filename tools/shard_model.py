@@ -81,13 +81,14 @@ def run(n, rank, graph, kw):
 
 
 base = None
-for n in (1, 2, 4, 8):
+ONLY = os.environ.get("R2F_SHARD_ONLY")  # "8": just the middle rank of 8 on its two-exchange schedule (for a run under rocprofv3)
+for n in ((int(ONLY),) if ONLY else (1, 2, 4, 8)):
     rank = n // 2 if n > 2 else 0
-    for name, kw in (SCHEDULES if n > 1 else SCHEDULES[:1]):
+    for name, kw in ((SCHEDULES[2:3] if ONLY else SCHEDULES) if n > 1 else SCHEDULES[:1]):
         res = {g: run(n, rank, g, kw) for g in (False, True)}
         rows, sched, split, dl, dh, tuned = res[True][2]
-        if n == 1:
-            base = res[True][0]
+        if n == 1 or base is None:
+            base = res[True][0] * n
         what = f"schedule {sched}" + (f", halation interior [{split[0]}, {split[1]}) of [{dl}, {dh})" if split else "")
         if tuned:
             what += ", measured " + " / ".join(f"{t:.3f}" for t in tuned) + " ms per candidate"
@@ -97,7 +98,7 @@ for which, name in ((0, "halation"), (1, "MTF")):
     print(name, "windows of the last call:", [c["window"] for c in proc.ctx.stencil_stats(which)])
 
 # ... and round 3's measure for comparison: a (rows x W) frame of its own (no halo rows, one halation call)
-for n in (8,):
+for n in (() if ONLY else (8,)):
     rows = H // n
     fh = 36.0 * rows / W
     params1 = proc.prepare(neg, 6, 0.4, (W, rows), seed=20260630, matrix=REC709_TO_XYZ, print_film=prt, frame_width=36, frame_height=fh,
