@@ -41,6 +41,8 @@ struct StencilSet {
     DevStencil dev[3];
     plan::StencilGeom geom[3];  // the host-side geometry dev[] was filled from
     bool mixed_sign[3] = {false, false, false};  // the channel has taps of both signs (set by r2f_set_kernel)
+    int single_tap_mask = 0;  // channels whose stencil is ONE tap at the anchor (set by r2f_set_kernel: a scan of every tap, which
+                              // the per-frame front / range calls of a row shard must not repeat -- 15 us of host time per call)
     DeviceBuf wbuf[3], mbuf[3];
 };
 
@@ -1157,6 +1159,11 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
         }
         s.mixed_sign[c] = pos && neg;
     }
+    s.single_tap_mask = 0;
+    for (int c = 0; c < 3; ++c) {
+        float w;
+        if (plan::single_tap_channel(plan::Taps{s.host.data(), kh, kw, kc}, c, &w)) s.single_tap_mask |= 1 << c;
+    }
     ++ctx->generation;
     s.built_q = 0;
     for (int c = 0; c < 3; ++c) {
@@ -1278,11 +1285,7 @@ static int stage_front_impl(r2f_ctx* ctx, const r2f_params* p, const void* in, i
         if (rc) return rc;
         a.track = record_of(ctx);
         a.track_mask = 7;
-        if (ctx->stencil[R2F_KERNEL_HALATION].present) {
-            float w;
-            for (int c = 0; c < 3; ++c)
-                if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &w)) a.track_mask &= ~(1 << c);
-        }
+        if (ctx->stencil[R2F_KERNEL_HALATION].present) a.track_mask &= ~ctx->stencil[R2F_KERNEL_HALATION].single_tap_mask;
     } else {
         int rc = cannot_track();
         if (rc) return rc;
@@ -1310,11 +1313,7 @@ int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, i
     rc = y3 > y2 ? check_rows(ctx, "exposure range", exposure, y2, y3) : R2F_OK;
     if (rc) return rc;
     int mask = 7;  // the channels the halation's FFT passes read: not the single-tap ones (as the front kernel records them)
-    if (ctx->stencil[R2F_KERNEL_HALATION].present) {
-        float w;
-        for (int c = 0; c < 3; ++c)
-            if (single_tap_channel(ctx->stencil[R2F_KERNEL_HALATION], c, &w)) mask &= ~(1 << c);
-    }
+    if (ctx->stencil[R2F_KERNEL_HALATION].present) mask &= ~ctx->stencil[R2F_KERNEL_HALATION].single_tap_mask;
     rc = ensure_range_tiles(ctx, std::max(std::max(y1, y3), exposure->gy0 + exposure->rows), W);
     if (rc) return rc;
     R2F_HIP(ctx, launch_exposure_range(to_dev(exposure), y0, y1, y2, y3, W, mask, record_of(ctx), static_cast<hipStream_t>(stream)));

@@ -91,16 +91,6 @@ struct FrameParams {
 };
 constexpr uint32_t kFrameMinReset = 0x7f800000u, kFrameMaxReset = 0u;
 
-// One wave's (lo, hi) merged into the block's exposure range.  Thousands of waves end here, and atomics on ONE address serialise in
-// the L2 (a 59-row front call of a row shard spent 0.1 ms of its ~5 us in them: 3 072 waves x 2): a wave looks first and only
-// sends the atomic that can still move the extreme -- after the first few waves almost none can.  The look may be stale; the record
-// only ever moves one way (min down, max up), so a stale value can cost an atomic that was not needed, never lose one that was.
-__device__ __forceinline__ void merge_range(FrameParams* blk, float lo, float hi) {
-    const int ilo = __float_as_int(lo), ihi = __float_as_int(hi);
-    if (ilo < __atomic_load_n(reinterpret_cast<int*>(&blk->e_min), __ATOMIC_RELAXED)) atomicMin(reinterpret_cast<int*>(&blk->e_min), ilo);
-    if (ihi > __atomic_load_n(reinterpret_cast<int*>(&blk->e_max), __ATOMIC_RELAXED)) atomicMax(reinterpret_cast<int*>(&blk->e_max), ihi);
-}
-
 // ---------------------------------------------------------------------------- streaming accesses
 // Non-temporal 16-byte accesses for frame-sized buffers that are written once and read back a stage later (1.2 GB per plane set
 // at 100 MP, far beyond the 256 MB Infinity Cache).  On MI355X a float4 copy runs 6.57 TB/s that way against 6.23 with plain loads
@@ -280,9 +270,15 @@ __device__ __forceinline__ void merge_tile(const RangeRecord& rec, int gy, int t
     const int ty = gy >> kRangeTileRowsLog2;
     if ((unsigned)ty >= (unsigned)rec.tyn || (unsigned)tx >= (unsigned)rec.txn) return;
     int2* t = rec.tiles + (long long)ty * rec.txn + tx;
+    // A wave looks first (a device-scope load: L2) and only sends the atomic that can still move the extreme: a tile is merged into by
+    // 8 .. 64 waves, and for the range kernel over many rows (64 waves per tile) the look saves two thirds of the time.  The look may
+    // be stale; the record only ever moves one way (min down, max up), so a stale value can cost an atomic that was not needed, never
+    // lose one that was.
     const int ilo = __float_as_int(lo), ihi = __float_as_int(hi);
-    if (ilo < __atomic_load_n(&t->x, __ATOMIC_RELAXED)) atomicMin(&t->x, ilo);
-    if (ihi > __atomic_load_n(&t->y, __ATOMIC_RELAXED)) atomicMax(&t->y, ihi);
+    if (ilo < __hip_atomic_load(&t->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        (void)__hip_atomic_fetch_min(&t->x, ilo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ihi > __hip_atomic_load(&t->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        (void)__hip_atomic_fetch_max(&t->y, ihi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // min / max of a value over the 64 lanes of a wave, by DPP (no LDS): the result is valid in every lane of the LAST row (lanes 48-63);
 // callers read lane 63.

@@ -307,7 +307,27 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             o32[2] = u8_of(b[2]) | (u8_of(r[3]) << 8) | (u8_of(g[3]) << 16) | (u8_of(b[3]) << 24);
         }
     }
-    if (TRK) flush();
+    if (TRK) {
+        // The LAST flush of every wave comes at the same moment (the end of the kernel), and in a short call -- the 59-row bands a row
+        // shard makes first -- it is every wave's only one: 59 waves x 2 atomics on one tile's line cost such a call 12 us of its 11.
+        // The workgroup's waves (BY consecutive rows of the same 256 columns: one tile, two at a tile-row border) combine theirs
+        // through LDS first: wave 0 sends one merge per tile row present.
+        __shared__ int wg_ty[BY];
+        __shared__ float wg_lo[BY], wg_hi[BY];
+        const float w_lo = wave_extreme<false>(p_lo), w_hi = wave_extreme<true>(p_hi);
+        if (threadIdx.x == 63) wg_ty[threadIdx.y] = p_ty, wg_lo[threadIdx.y] = w_lo, wg_hi[threadIdx.y] = w_hi;
+        __syncthreads();
+        if (threadIdx.y == 0 && threadIdx.x == 0) {
+            for (int i = 0; i < BY; ++i) {
+                const int ty = wg_ty[i];
+                if (ty < 0) continue;
+                float lo = wg_lo[i], hi = wg_hi[i];
+                for (int j = i + 1; j < BY; ++j)
+                    if (wg_ty[j] == ty) lo = fminf(lo, wg_lo[j]), hi = fmaxf(hi, wg_hi[j]), wg_ty[j] = -1;
+                merge_tile(a.track, ty << kRangeTileRowsLog2, blockIdx.x, lo, hi);
+            }
+        }
+    }
     };
     if (!track)
         row_loop(std::integral_constant<int, 0>{});

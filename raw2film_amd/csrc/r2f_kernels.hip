@@ -1347,29 +1347,47 @@ hipError_t launch_frame_params(const RangeRecord& rec, const FrameParams& v, int
     return take_launch_status();
 }
 
-// min / max |.| of rows [y0, y1) and [y2, y3) of the planes in `mask`, merged into the record like the front kernel's own: the frame
-// block and the tile grid (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours above and below, one
-// launch for both bands).  A wave takes 256 columns of one row -- one tile column, like a wave of the front kernel; grid
-// (ceil(W / 256), ceil(rows / 4)), block (64, 4).  NaNs drop out of fminf / fmaxf, like there.
-__global__ __launch_bounds__(256) void exposure_range_kernel(const DevPlanes src, const int y0, const int y1, const int y2, const int y3,
-                                                              const int W, const int mask, const RangeRecord rec) {
-    const int n0 = y1 - y0, r = blockIdx.y * 4 + threadIdx.y;
-    if (r >= n0 + (y3 - y2)) return;
+// min / max |.| of rows [y0, y1) and [y2, y3) of the planes in `mask`, merged into the record's tiles like the front kernel's own
+// (r2f_stage_exposure_range: the halo rows a row shard received from its neighbours above and below, one launch for both bands).
+// A wave takes 256 columns of one row -- one tile column, like a wave of the front kernel --, a workgroup 16 consecutive rows whose
+// waves combine through LDS before one of them merges into the (one or two) tiles they touch: grid (ceil(W / 256), ceil(rows / 16)),
+// block (64, 16).  NaNs drop out of fminf / fmaxf, like there.
+constexpr int kRangeRowsPerBlock = 16;
+__global__ __launch_bounds__(64 * kRangeRowsPerBlock) void exposure_range_kernel(const DevPlanes src, const int y0, const int y1, const int y2,
+                                                                                  const int y3, const int W, const int mask,
+                                                                                  const RangeRecord rec) {
+    __shared__ int wg_ty[kRangeRowsPerBlock];
+    __shared__ float wg_lo[kRangeRowsPerBlock], wg_hi[kRangeRowsPerBlock];
+    const int n0 = y1 - y0, r = blockIdx.y * kRangeRowsPerBlock + threadIdx.y;
+    const bool live = r < n0 + (y3 - y2);  // (wave-uniform)
     const int gy = r < n0 ? y0 + r : y2 + (r - n0);
     float lo = __builtin_inff(), hi = 0.f;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    for (int c = 0; c < 3; ++c) {
-        if (!((mask >> c) & 1)) continue;
-        const float* p = src.data + c * src.plane_stride + (long long)(gy - src.gy0) * W;
+    if (live) {
+        const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+        for (int c = 0; c < 3; ++c) {
+            if (!((mask >> c) & 1)) continue;
+            const float* p = src.data + c * src.plane_stride + (long long)(gy - src.gy0) * W;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (x0 + k < W) {
-                const float v = p[x0 + k];
-                lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
-            }
+            for (int k = 0; k < 4; ++k)
+                if (x0 + k < W) {
+                    const float v = p[x0 + k];
+                    lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
+                }
+        }
     }
     lo = wave_extreme<false>(lo), hi = wave_extreme<true>(hi);
-    if (threadIdx.x == 63) merge_tile(rec, gy, blockIdx.x, lo, hi);
+    if (threadIdx.x == 63) wg_ty[threadIdx.y] = live ? (gy >> kRangeTileRowsLog2) : -1, wg_lo[threadIdx.y] = lo, wg_hi[threadIdx.y] = hi;
+    __syncthreads();
+    if (threadIdx.y == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < kRangeRowsPerBlock; ++i) {
+            const int ty = wg_ty[i];
+            if (ty < 0) continue;
+            float l2 = wg_lo[i], h2 = wg_hi[i];
+            for (int j = i + 1; j < kRangeRowsPerBlock; ++j)
+                if (wg_ty[j] == ty) l2 = fminf(l2, wg_lo[j]), h2 = fmaxf(h2, wg_hi[j]), wg_ty[j] = -1;
+            merge_tile(rec, ty << kRangeTileRowsLog2, blockIdx.x, l2, h2);
+        }
+    }
 }
 
 hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, const RangeRecord& rec, hipStream_t s) {
@@ -1377,8 +1395,8 @@ hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, i
     if (y3 < y2) y3 = y2;
     const int rows = (y1 - y0) + (y3 - y2);
     if (rows <= 0 || W <= 0 || !(mask & 7)) return hipSuccess;
-    launch_k(exposure_range_kernel, dim3((W + kRangeTileCols - 1) / kRangeTileCols, (rows + 3) / 4), dim3(64, 4), 0, s, src, y0, y1, y2, y3, W,
-             mask, rec);
+    launch_k(exposure_range_kernel, dim3((W + kRangeTileCols - 1) / kRangeTileCols, (rows + kRangeRowsPerBlock - 1) / kRangeRowsPerBlock),
+             dim3(64, kRangeRowsPerBlock), 0, s, src, y0, y1, y2, y3, W, mask, rec);
     return take_launch_status();
 }
 
