@@ -10,7 +10,8 @@ python bench.py --config cfg5_batch --no-cpu-baseline > $O/bench_cfg5_batch.json
 python bench.py --no-graph --no-cpu-baseline --no-pcie > $O/bench_cfg4_nograph.json 2>/dev/null
 python bench.py --output u8 --no-cpu-baseline --no-pcie > $O/bench_cfg4_u8_output.json 2>/dev/null
 python bench.py --frame smooth --no-cpu-baseline --no-pcie > $O/bench_cfg4_smooth.json 2>/dev/null
-python bench.py --clamp 0.004,48 --no-cpu-baseline --no-pcie > $O/bench_cfg4_clamped_12byte.json 2>/dev/null
+python bench.py --clamp 0.004,48 --no-cpu-baseline --no-pcie > $O/bench_cfg4_clamped.json 2>/dev/null
+python bench.py --opt stencil_fft_scratch96_auto=0 --no-cpu-baseline --no-pcie > $O/bench_cfg4_complex128.json 2>/dev/null
 python bench.py --checksum --no-cpu-baseline --no-pcie --no-alone > $O/bench_cfg4_checksum.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --same-device --no-cpu-baseline --no-alone --checksum 2>/dev/null | tail -1 > $O/bench_cfg4_2ranks_one_gpu.json
 python bench.py --gpus 8 --backend gloo --same-device --no-cpu-baseline --no-alone --checksum 2>/dev/null | tail -1 > $O/bench_cfg4_8ranks_one_gpu.json
