@@ -68,15 +68,17 @@ enum {
                                      the kernels read what r2f_write_frame_params last wrote there (in stream order).  For callers
                                      that replay captured launches: the write stays outside the capture, the launches inside */
     R2F_F_TRACK_RANGE = 1u << 8,   /* r2f_stage_front (upto = EXPOSURE) / r2f_stage_front_split: merge min and max |.| of the exposure
-                                     samples this call writes for the halation's FFT channels into the frame block (reset by
-                                     r2f_write_frame_params) -- what r2f_render's front kernel does for a whole frame.  A call whose
-                                     kernel cannot record (the generic pointwise kernel) marks the range unusable instead: the
-                                     halation then keeps complex128, nothing goes wrong silently */
-    R2F_F_RANGE_VALID = 1u << 9    /* r2f_stage_halation: the caller vouches that the frame block's range covers EVERY row the
-                                     `exposure` buffer holds for the FFT channels (own rows by R2F_F_TRACK_RANGE front calls, rows
-                                     received from neighbours by r2f_stage_exposure_range -- windows also read buffer rows beyond the
-                                     stencil's reach, for outputs they discard): the passes may then choose the 12-byte scratch
-                                     element on the device exactly like r2f_render's (below) */
+                                     samples this call writes for the halation's FFT channels into the context's exposure-range record
+                                     -- a grid of 64 x 256-pixel tiles over the GLOBAL frame, reset by r2f_write_frame_params -- which is
+                                     what r2f_render's front kernel does for a whole frame.  A call whose kernel cannot record (the
+                                     generic pointwise kernel) leaves its tiles "unknown": the windows that touch them keep complex128,
+                                     nothing goes wrong silently */
+    R2F_F_RANGE_VALID = 1u << 9    /* r2f_stage_halation: the caller has kept the record for the rows the `exposure` buffer holds for the
+                                     FFT channels (own rows by R2F_F_TRACK_RANGE front calls, rows received from neighbours by
+                                     r2f_stage_exposure_range): the passes may then choose the 12-byte scratch element on the device,
+                                     window pair by window pair, exactly like r2f_render's (below).  A tile nobody recorded reads as
+                                     "unknown" and keeps complex128 for the windows that touch it; what the flag vouches for is that
+                                     recorded tiles describe THIS frame's samples (the record was reset at the start of the frame) */
 };
 
 /* `upto` of r2f_stage_front */
@@ -133,13 +135,14 @@ R2F_API int r2f_set_kernel(r2f_ctx* ctx, int which, const float* host_khwc, int 
  * the kernels' spectra (1 MiB per stencil channel) belong to the context, allocated on first use.
  * Scratch element of the halation's passes: complex128, or -- chosen on the device, frame by frame and WINDOW PAIR by window pair -- a
  * 12-byte element (each component a double rounded to 48 bits) when the range of the exposure samples the pair's two windows hold
- * allows it: max |x| <= bound x max(min x, first breakpoint of the density curve), the bound derived from the curve's steepest
+ * allows it (the range comes from a grid of 64 x 256-pixel tiles the front kernel fills as it writes the exposure planes; a window
+ * takes the extremes of the tiles it touches): max |x| <= bound x max(min x, first breakpoint of the density curve), the bound derived from the curve's steepest
  * cell and the element's worst error (two roundings at 2^-37 of max / shadow, x 1.5: a searched constant, tests/test_gpu_fft.py) so
  * that the element costs a density at most three fp32 ulps -- the MTF's complex64 scratch is allowed the same -- (option
- * stencil_fft_scratch96_auto, default 1; with the stand-in Portra curve frames up to max / shadow = 6.1e4 take it, wider ones
- * keep complex128).  The stage entry points make the same choice when their caller keeps the
- * record complete (R2F_F_TRACK_RANGE, r2f_stage_exposure_range, R2F_F_RANGE_VALID) and use complex128 otherwise; a row shard sees
- * the range of ITS rows, so a whole-frame render and a row-sharded one agree to that element's rounding, not bit for bit.
+ * stencil_fft_scratch96_auto, default 1; with the stand-in Portra curve windows up to max / shadow = 6.2e4 take it, wider ones
+ * keep complex128 -- the headline's noise frame spans 1.4e5 as a whole and ~2e4 per window: 99 % of its window pairs take it).  The stage entry points make the same choice when their caller keeps the
+ * record (R2F_F_TRACK_RANGE, r2f_stage_exposure_range, R2F_F_RANGE_VALID) and use complex128 otherwise; a row shard's windows are
+ * anchored at ITS first row, so a whole-frame render and a row-sharded one agree to that element's rounding, not bit for bit.
  * Non-finite samples: in the direct form a NaN / infinity in a stencil's input comes out as NaN in every output whose tap box
  * (plus up to three zero-weight padding rows / columns) covers it, like the per-tap loop of the reference's convolution.wgsl; the FFT form takes such a sample as 0 instead (a NaN
  * handed to the transforms would come back in every output of its 256 x 512 window) -- the outputs inside the tap box are then
@@ -162,9 +165,10 @@ R2F_API int r2f_render_stats(const r2f_ctx* ctx, uint64_t* out4);
 
 /* Introspection for the measurement harness (synchronises the device): what the front kernel of the last whole-frame render (or
  * the front / range calls of a row shard's last frame: R2F_F_TRACK_RANGE, r2f_stage_exposure_range) recorded about the exposure
- * planes the halation's FFT passes read, and what they made of it.  out4 = {min x, max |x|, bound,
- * floor}; *armed = 1 when that render's halation launches carried the rule (stencil_fft_scratch96_auto, 256-row windows, real
- * spectrum: r2f_render above), *packed = 1 when they then took the 12-byte scratch element (max <= bound x max(min, floor)).
+ * planes the halation's FFT passes read, and what they made of it.  out4 = {min x, max |x| (the extremes over the record's tiles,
+ * reduced on the host: the FRAME's range, which decides nothing by itself), bound, floor}; *armed = 1 when that render's halation
+ * launches carried the rule (stencil_fft_scratch96_auto, 256-row windows, real spectrum: r2f_render above), *packed = 1 when EVERY
+ * window pair then took the 12-byte scratch element (r2f_frame_scratch_choice has the counts).
  * Valid until the next write of the frame block (the next render).  Nothing upstream corresponds to it. */
 R2F_API int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int* packed);
 /* The choice itself, which is made PER WINDOW PAIR since round 6 (a pair's two windows' own range, from a grid of 64 x 256-pixel tiles
@@ -211,12 +215,12 @@ R2F_API int r2f_stage_front_split(r2f_ctx* ctx, const r2f_params* p, const void*
                           const r2f_planes* exposure, const r2f_planes* density, int y0, int y1, int W, int H_global,
                           int* finished_mask, void* stream);
 /* A row shard's half of r2f_render's exposure-range record: min and max |.| of rows [y0, y1) and [y2, y3) of `exposure` (the
- * channels whose halation stencil takes the FFT form) merged into the context's frame block, in stream order -- for the halo rows a
+ * channels whose halation stencil takes the FFT form) merged into the context's record (its tiles), in stream order -- for the halo rows a
  * rank received from its neighbours above and below, in one launch (an empty range is skipped; its own rows are recorded by the
  * front kernel, R2F_F_TRACK_RANGE).  Nothing upstream corresponds to it. */
 R2F_API int r2f_stage_exposure_range(r2f_ctx* ctx, const r2f_planes* exposure, int y0, int y1, int y2, int y3, int W, void* stream);
 /* S2 halation stencil on exposure + S3 log + S4 curve -> density planes.  With R2F_F_RANGE_VALID the FFT passes choose their
- * scratch element on the device from the frame block's range (see r2f_render); without it they keep complex128. */
+ * scratch element on the device, per window pair, from the exposure-range record (see r2f_render); without it they keep complex128. */
 R2F_API int r2f_stage_halation(r2f_ctx* ctx, const r2f_params* p, const r2f_planes* exposure, const r2f_planes* density,
                        int y0, int y1, int W, int H_global, void* stream);
 /* S5 MTF stencil on density -> density planes. */
@@ -369,8 +373,8 @@ R2F_API uint64_t r2f_generation(const r2f_ctx* ctx);
  *                                 out around the window origin, pass 2 multiplies by a REAL spectrum (8 B per element)
  *   stencil_fft_cols_walk      1: pass 2 of 256-row windows with a real spectrum runs as a resident grid walking the launch's
  *                                 pairs per column block (spectrum in registers); 0: one workgroup per (column block, pair)
- *   stencil_fft_scratch96_auto 1: r2f_render lets the halation's passes take the 12-byte scratch element when the frame's
- *                                 exposure range allows (above); stencil_fft_scratch96 (mask per stencil) forces it
+ *   stencil_fft_scratch96_auto 1: the halation's passes take the 12-byte scratch element for the window pairs whose exposure range
+ *                                 allows it (above); stencil_fft_scratch96 (mask per stencil) forces it for all
  *   stencil_fft_mixed_sign     1: channels with taps of both signs take the float64 FFT form whatever their size
  * (older ones: stencil_fft, stencil_fft_window[_rows|_max], stencil_fft_batch, stencil_fft_streams, stencil_fft_scratch32,
  *  stencil_fft_min_taps, stencil_fft_epilogue_lds, render_graph, front_fast, ... -- see r2f_set_option in r2f_api.hip) */

@@ -102,12 +102,12 @@ struct r2f_ctx {
     // absolute; the halation acts on linear exposure, where the same roundings are relative to the brightest pixel of the window.
     int opt_fft_s32 = 1 << R2F_KERNEL_MTF;
     int opt_fft_s96 = 0;  // bit `which`: 12-byte scratch elements (doubles rounded to 48 bits, 2^-37) whatever the frame holds -- A/B
-    // 1: a whole-frame render (r2f_render) lets the halation's FFT passes choose between complex128 and the 12-byte element ON THE
-    // DEVICE, per frame, from the range of the exposure samples its front kernel wrote (FrameParams::e_min / e_max): the 12-byte
+    // 1: the halation's FFT passes choose between complex128 and the 12-byte element ON THE DEVICE, per frame and per WINDOW PAIR,
+    // from the range of the exposure samples the pair's windows hold (the record's tiles, filled by the front kernel): the 12-byte
     // element costs a shadow at most 1.46e-11 x (max |x| / shadow) of itself (two roundings at 2^-37; kDynCoefficient below adds a
     // factor 1.5) -- which the density curve turns into 0.434 x slope x that; the bound keeps it under three fp32 ulps of a density
-    // in [1, 2), what the MTF's complex64 scratch is allowed, and frames with a wider range keep complex128 (the stand-in Portra
-    // curve: max / shadow <= 6.1e4; the headline's noise frame, at 1.4e5, does not qualify since round 6).
+    // in [1, 2), what the MTF's complex64 scratch is allowed, and window pairs with a wider range keep complex128 (the stand-in Portra
+    // curve: max / shadow <= 6.2e4; the headline's noise frame spans 1.4e5 as a whole, ~2e4 per window: 99 % of its pairs qualify).
     int opt_fft_s96_auto = 1;
     float curve_slope_max = 0.f;  // max |d density / d log10 exposure| over the density curve's cells (host copy, r2f_set_curve1d)
     bool frame_dyn_armed = false;  // the last whole-frame render's halation launches carried the rule (r2f_frame_exposure_range)
@@ -575,8 +575,8 @@ plan::FftOptions fft_options(const r2f_ctx* ctx) {
 
 // The channels `chans` of a stencil (all with the same tap box) as fp64 overlap-save FFT correlations (r2f_fft.hip);
 // their window pairs share the launches.
-// dyn: the caller (a whole-frame render) vouches that the context's frame block holds the range of exactly the samples `src` holds:
-// the passes may then choose their scratch element on the device (FftConvArgs::dyn).
+// dyn: the caller vouches that the context's exposure-range record (its tiles) was kept for the samples `src` holds this frame: the
+// passes may then choose their scratch element on the device, per window pair (FftConvArgs::dyn_flags, fft_decide_kernel).
 int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2f_planes* src, const r2f_planes* dst, int y0, int y1,
                     int W, int H, int epilogue, float log_eps, hipStream_t s, bool dyn) {
     StencilSet& set = ctx->stencil[which];

@@ -270,15 +270,13 @@ __device__ __forceinline__ void merge_tile(const RangeRecord& rec, int gy, int t
     const int ty = gy >> kRangeTileRowsLog2;
     if ((unsigned)ty >= (unsigned)rec.tyn || (unsigned)tx >= (unsigned)rec.txn) return;
     int2* t = rec.tiles + (long long)ty * rec.txn + tx;
-    // A wave looks first (a device-scope load: L2) and only sends the atomic that can still move the extreme: a tile is merged into by
-    // 8 .. 64 waves, and for the range kernel over many rows (64 waves per tile) the look saves two thirds of the time.  The look may
-    // be stale; the record only ever moves one way (min down, max up), so a stale value can cost an atomic that was not needed, never
-    // lose one that was.
-    const int ilo = __float_as_int(lo), ihi = __float_as_int(hi);
-    if (ilo < __hip_atomic_load(&t->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        (void)__hip_atomic_fetch_min(&t->x, ilo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ihi > __hip_atomic_load(&t->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        (void)__hip_atomic_fetch_max(&t->y, ihi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Two fire-and-forget atomics (device scope, no return value).  No look first: a look is a LOAD the wave would have to wait for, and
+    // waiting for it means waiting for every memory operation issued before it -- in the front kernel, which merges every fourth
+    // iteration, the stores of the rows just finished: a drain of the memory pipeline per tile row, +50 us per 100 MP frame
+    // (rocprofv3).  Contention is low by construction: a tile is merged into by the 8 / 16 waves of ONE workgroup of the front
+    // kernel (spread over its iterations; their last merges combined through LDS) or by four workgroups of the range kernel.
+    (void)__hip_atomic_fetch_min(&t->x, __float_as_int(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(&t->y, __float_as_int(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // min / max of a value over the 64 lanes of a wave, by DPP (no LDS): the result is valid in every lane of the LAST row (lanes 48-63);
 // callers read lane 63.
