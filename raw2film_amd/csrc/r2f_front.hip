@@ -22,6 +22,7 @@
 // Results are bit-identical to the generic kernel's (tests/test_gpu_parity.py::test_fused_pointwise_fast_path_matches_generic).
 // Workgroups are persistent: 1 024 threads and up to 112 KB of LDS (one per CU) when the curve is needed, 512 threads and the
 // 64 KB LUT alone (two per CU) for upto = EXPOSURE; each copies its tables once and walks the frame.
+#include <algorithm>
 #include <type_traits>
 
 #include "r2f_launch.h"
@@ -157,10 +158,20 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         }
         __syncthreads();
     }
-    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+#ifndef R2F_FRONT_UNITS
+// 1: the fused LUT-only pass (UPTO = OUTPUT: BASELINE config 2) runs on a ONE-dimensional persistent grid: the frame's (row group,
+// tile column) units in row-major order -- neighbouring workgroups read neighbouring pieces of the same image rows --, dealt out
+// in equal contiguous runs to exactly as many workgroups as fit the chip (256 at one per CU).  0 (rounds 2-5), and what the other
+// instances keep: a (columns, rows) grid whose row count is the chip's workgroups divided by the columns, ROUNDED DOWN -- 24 columns
+// x 10 = 240 workgroups on 256 CUs for the 24 MP frame: 6 % of the chip idle.  Interleaved A/B of two builds (tools/ab_libs.py):
+// 0.240 against 0.252 ms on the noise frame, 0.213 against 0.224 on the photograph-like one (-4.8 %).  Tried for the exposure
+// instances too: the recording ones need a wave to stay inside one tile for a while, i.e. column- or band-major units -- +0.03 /
+// +0.08 ms on the 100 MP frame (a workgroup that walks down a column reads 3-KB pieces a row pitch apart) --, the non-recording
+// split kernel measured +0.02 ms in row-major order: both keep the 2-D grid.
+#define R2F_FRONT_UNITS 1
+#endif
     // (UPTO = EXPOSURE with a.track: the range of the exposure samples written for the halation's FFT passes goes into the record's tiles)
     const bool track = UPTO == R2F_UPTO_EXPOSURE && a.track.blk != nullptr;
-    if (x >= a.W && !track) return;
     const int W = a.W;
     const float* in = static_cast<const float*>(a.in);
     const float s3 = a.lut3d_scale * (float)(a.lut3d.n - 1);
@@ -177,25 +188,32 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
     auto row_loop = [&](auto trk_tag) {
     constexpr int TRK = decltype(trk_tag)::value;
     const int groups = (a.y1 - a.y0 + BY - 1) / BY;
-    const int g_begin = TRK ? (int)((long long)blockIdx.y * groups / gridDim.y) : (int)blockIdx.y;
-    const int g_end = TRK ? (int)((long long)(blockIdx.y + 1) * groups / gridDim.y) : groups;
-    const int g_step = TRK ? 1 : (int)gridDim.y;
-    float p_lo = __builtin_inff(), p_hi = 0.f;  // this lane's extremes inside the tile row p_ty
-    int p_ty = -1;
+    constexpr bool UNITS = R2F_FRONT_UNITS && UPTO == R2F_UPTO_OUTPUT;
+    const int units = groups * a.gx;
+    const int g_begin = UNITS ? (int)((long long)blockIdx.x * units / gridDim.x)
+                              : (TRK ? (int)((long long)blockIdx.y * groups / gridDim.y) : (int)blockIdx.y);
+    const int g_end = UNITS ? (int)((long long)(blockIdx.x + 1) * units / gridDim.x)
+                            : (TRK ? (int)((long long)(blockIdx.y + 1) * groups / gridDim.y) : groups);
+    const int g_step = (UNITS || TRK) ? 1 : (int)gridDim.y;
+    float p_lo = __builtin_inff(), p_hi = 0.f;  // this lane's extremes inside the tile (p_ty, p_tx)
+    int p_ty = -1, p_tx = 0;
     auto flush = [&]() {
         if (p_ty < 0) return;
         const float w_lo = wave_extreme<false>(p_lo), w_hi = wave_extreme<true>(p_hi);
-        if (threadIdx.x == 63) merge_tile(a.track, p_ty << kRangeTileRowsLog2, blockIdx.x, w_lo, w_hi);
+        if (threadIdx.x == 63) merge_tile(a.track, p_ty << kRangeTileRowsLog2, p_tx, w_lo, w_hi);
         p_lo = __builtin_inff(), p_hi = 0.f;
     };
-    for (int grp = g_begin; grp < g_end; grp += g_step) {
+    for (int unit = g_begin; unit < g_end; unit += g_step) {
+        const int grp = UNITS ? unit / a.gx : unit;
+        const int col = UNITS ? unit - grp * a.gx : (int)blockIdx.x;
+        const int x = (col * 64 + threadIdx.x) * 4;
         const int gy = a.y0 + grp * BY + threadIdx.y;
-        if (gy >= a.y1) break;
-        if (TRK) {  // (gy is wave-uniform: a wave is one row)
+        if (gy >= a.y1) continue;  // (the last row group of a column may be short)
+        if (TRK) {  // (gy and col are wave-uniform: a wave is one row of one tile column)
             const int ty = gy >> kRangeTileRowsLog2;
-            if (ty != p_ty) {
+            if (ty != p_ty || col != p_tx) {
                 flush();
-                p_ty = ty;
+                p_ty = ty, p_tx = col;
             }
         }
         if (x >= W) continue;
@@ -312,19 +330,19 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
         // shard makes first -- it is every wave's only one: 59 waves x 2 atomics on one tile's line cost such a call 12 us of its 11.
         // The workgroup's waves (BY consecutive rows of the same 256 columns: one tile, two at a tile-row border) combine theirs
         // through LDS first: wave 0 sends one merge per tile row present.
-        __shared__ int wg_ty[BY];
+        __shared__ int wg_ty[BY], wg_tx[BY];
         __shared__ float wg_lo[BY], wg_hi[BY];
         const float w_lo = wave_extreme<false>(p_lo), w_hi = wave_extreme<true>(p_hi);
-        if (threadIdx.x == 63) wg_ty[threadIdx.y] = p_ty, wg_lo[threadIdx.y] = w_lo, wg_hi[threadIdx.y] = w_hi;
+        if (threadIdx.x == 63) wg_ty[threadIdx.y] = p_ty, wg_tx[threadIdx.y] = p_tx, wg_lo[threadIdx.y] = w_lo, wg_hi[threadIdx.y] = w_hi;
         __syncthreads();
         if (threadIdx.y == 0 && threadIdx.x == 0) {
             for (int i = 0; i < BY; ++i) {
-                const int ty = wg_ty[i];
+                const int ty = wg_ty[i], tx = wg_tx[i];
                 if (ty < 0) continue;
                 float lo = wg_lo[i], hi = wg_hi[i];
                 for (int j = i + 1; j < BY; ++j)
-                    if (wg_ty[j] == ty) lo = fminf(lo, wg_lo[j]), hi = fmaxf(hi, wg_hi[j]), wg_ty[j] = -1;
-                merge_tile(a.track, ty << kRangeTileRowsLog2, blockIdx.x, lo, hi);
+                    if (wg_ty[j] == ty && wg_tx[j] == tx) lo = fminf(lo, wg_lo[j]), hi = fmaxf(hi, wg_hi[j]), wg_ty[j] = -1;
+                merge_tile(a.track, ty << kRangeTileRowsLog2, tx, lo, hi);
             }
         }
     }
@@ -366,11 +384,20 @@ static void launch_fast(const FrontArgs& a, hipStream_t s) {
     const int per_cu = lds > 80 * 1024 ? 1 : (BY == 16 ? 2 : (lds > 53 * 1024 ? 2 : 3));
     int gy = per_cu * 256 / gx;
     gy = gy > row_groups ? row_groups : (gy < 1 ? 1 : gy);
-    const dim3 grid(gx, gy), block(64, BY);
+    dim3 grid(gx, gy);
+    const dim3 block(64, BY);
+    FrontArgs b = a;
+    b.gx = gx;
+    if (R2F_FRONT_UNITS && UPTO == R2F_UPTO_OUTPUT) {
+        // the fused LUT-only pass: exactly as many workgroups as fit the chip at once, each with an equal contiguous run of the (row
+        // group, tile column) units (front_fast_kernel, R2F_FRONT_UNITS)
+        const long long units = (long long)gx * row_groups;
+        grid = dim3((unsigned)std::min<long long>((long long)per_cu * 256, units));
+    }
     switch (a.in_layout) {
-        case R2F_LAYOUT_CHW: launch_k((front_fast_kernel<R2F_LAYOUT_CHW, UPTO, BY, FIN>), grid, block, lds, s, a); break;
-        case R2F_LAYOUT_HWC3: launch_k((front_fast_kernel<R2F_LAYOUT_HWC3, UPTO, BY, FIN>), grid, block, lds, s, a); break;
-        default: launch_k((front_fast_kernel<R2F_LAYOUT_HWC4, UPTO, BY, FIN>), grid, block, lds, s, a); break;
+        case R2F_LAYOUT_CHW: launch_k((front_fast_kernel<R2F_LAYOUT_CHW, UPTO, BY, FIN>), grid, block, lds, s, b); break;
+        case R2F_LAYOUT_HWC3: launch_k((front_fast_kernel<R2F_LAYOUT_HWC3, UPTO, BY, FIN>), grid, block, lds, s, b); break;
+        default: launch_k((front_fast_kernel<R2F_LAYOUT_HWC4, UPTO, BY, FIN>), grid, block, lds, s, b); break;
     }
 }
 

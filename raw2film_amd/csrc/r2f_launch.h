@@ -64,6 +64,7 @@ struct FrontArgs {
     // the halation's FFT passes read) are accumulated into this record: the frame block and the tile grid (blk = nullptr: not tracked)
     RangeRecord track;
     int track_mask;
+    int gx;  // fast kernel: tile columns of the frame (ceil(W / 256)), set by its launcher
 };
 bool front_fast_eligible(const FrontArgs& a);
 hipError_t launch_front_fast(const FrontArgs& a, hipStream_t s);
