@@ -257,7 +257,8 @@ class HipContext:
     def stage_front(self, image, params, upto, *, in_gy0=0, dst=None, dst_gy0=0, out_f32=None, out_u8=None,
                     out_gy0=0, y0=None, y1=None, H_global=None, layout=None, track_range=False):
         """track_range (upto = exposure): the kernel merges the range of the exposure samples it writes for the halation's FFT
-        channels into the frame block (R2F_F_TRACK_RANGE), like r2f_render's front kernel does for a whole frame."""
+        channels into the context's exposure-range record, a grid of 64 x 256-pixel tiles (R2F_F_TRACK_RANGE), like r2f_render's
+        front kernel does for a whole frame."""
         self._check_image(image)
         if track_range:
             params = _lib.Params.from_buffer_copy(params)
@@ -305,7 +306,7 @@ class HipContext:
         self._check(fn(self._h, first, C.byref(ps), C.byref(pd), y0, y1, W, H_global, self._stream()))
 
     def stage_exposure_range(self, exposure, *, src_gy0=0, y0, y1, y2=0, y3=0):
-        """Merge min / max |.| of rows [y0, y1) and [y2, y3) of the exposure planes (the halation's FFT channels) into the frame block:
+        """Merge min / max |.| of rows [y0, y1) and [y2, y3) of the exposure planes (the halation's FFT channels) into the exposure-range record's tiles:
         the halo rows a row shard received from above and below, one launch (r2f_stage_exposure_range)."""
         if y1 <= y0 and y3 <= y2:
             return
@@ -314,8 +315,8 @@ class HipContext:
                                                        self._stream()))
 
     def stage_halation(self, exposure, density, params, *, src_gy0=0, dst_gy0=0, y0, y1, H_global, identity_done=0, range_valid=False):
-        """range_valid: the caller vouches that the frame block's range covers every row `exposure` holds (R2F_F_RANGE_VALID): the
-        FFT passes then choose their scratch element on the device like r2f_render's."""
+        """range_valid: the caller has kept the exposure-range record for the rows `exposure` holds this frame (R2F_F_RANGE_VALID): the
+        FFT passes then choose their scratch element on the device, window pair by window pair, like r2f_render's."""
         if identity_done or range_valid:
             params = _lib.Params.from_buffer_copy(params)
         if identity_done:  # stage_front_split already wrote the identity channels' density for these rows

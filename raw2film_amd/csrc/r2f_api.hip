@@ -1858,7 +1858,7 @@ static int render_launches(r2f_ctx* ctx, const r2f_params* p, const void* in, in
     const r2f_planes* cur = &A;
     const r2f_planes* other = &B;
     if (hal) {
-        // (r2f_stage_halation with the vouching bit: the frame block holds the range of exactly these exposure planes)
+        // (r2f_stage_halation with the vouching bit: the record's tiles were filled for exactly these exposure planes)
         rc = run_stencil(ctx, R2F_KERNEL_HALATION, cur, other, 0, H, W, H, 1, p->log_eps, static_cast<hipStream_t>(stream),
                          finished != 0 || (p->flags & R2F_F_IDENTITY_DONE) != 0, tracked);
         if (rc) return rc;

@@ -252,7 +252,8 @@ __device__ __forceinline__ void curve_eval_near_lds(const float4* cells, const D
 }
 
 // ---------------------------------------------------------------------------- the exposure-range record, per tile
-// The frame-level range above decides nothing any more (it is kept for the measurement harness): the halation's FFT passes choose
+// The frame-level range fields above decide nothing any more (the measurement harness derives the frame's extremes from the tiles,
+// r2f_frame_exposure_range; e_max = +inf remains the "a front kernel could not record" mark): the halation's FFT passes choose
 // their scratch element PER WINDOW PAIR from the range of the samples that pair's two windows hold -- the error of the 12-byte
 // element scales with the energy of the window a pixel shares, not of the frame (r2f_api.hip, dyn_rule) -- and a window's range
 // comes from a grid of tiles over the GLOBAL frame: tile (gy / 64, x / 256) holds {min, max |.|} of the exposure samples recorded
@@ -261,7 +262,7 @@ __device__ __forceinline__ void curve_eval_near_lds(const float4* cells, const D
 // rows that came from elsewhere, fft_decide_kernel reads the <= 6 x 4 tiles a window touches.
 constexpr int kRangeTileRows = 64, kRangeTileRowsLog2 = 6, kRangeTileCols = 256, kRangeTileColsLog2 = 8;
 struct RangeRecord {
-    FrameParams* blk;  // the frame-level extremes; nullptr: nothing is recorded
+    FrameParams* blk;  // the context's frame block (its e_max doubles as the "could not record" mark); nullptr: nothing is recorded
     int2* tiles;       // tyn x txn tiles {min bits, max bits}; nullptr: none
     int tyn, txn;
 };

@@ -61,7 +61,7 @@ struct FrontArgs {
     float finish_w[3];
     DevPlanes finish_dst;
     // fast kernel, upto = EXPOSURE: min / max |.| of the exposure samples written to `dst` for the channels in track_mask (the ones
-    // the halation's FFT passes read) are accumulated into this record: the frame block and the tile grid (blk = nullptr: not tracked)
+    // the halation's FFT passes read) are accumulated into this record's tile grid (blk = nullptr: not tracked)
     RangeRecord track;
     int track_mask;
     int gx;  // fast kernel: tile columns of the frame (ceil(W / 256)), set by its launcher
@@ -285,7 +285,7 @@ hipError_t launch_noise(const NoiseArgs& a, hipStream_t s);
 // the per-render write of the context's FrameParams block (and the reset of the record's tiles) ahead of a frame's launches
 // mode: 0 seed only, 1 seed + range reset, 2 range reset only, 3 range made unusable (frame_params_kernel)
 hipError_t launch_frame_params(const RangeRecord& rec, const FrameParams& v, int mode, hipStream_t s);
-// the range of rows [y0, y1) and [y2, y3) of the planes in `mask` merged into the frame block (r2f_stage_exposure_range)
+// the range of rows [y0, y1) and [y2, y3) of the planes in `mask` merged into the record's tiles (r2f_stage_exposure_range)
 hipError_t launch_exposure_range(const DevPlanes& src, int y0, int y1, int y2, int y3, int W, int mask, const RangeRecord& rec, hipStream_t s);
 
 // Caller-side histogram (utils.py:145-165): per-channel counts of an interleaved uint8 image; counts[3][256] is zeroed first.
