@@ -174,6 +174,15 @@ _lib = None
 
 
 def _bind(path: str) -> C.CDLL:
+    # torch FIRST: its wheel ships a HIP runtime of its own (torch/lib/libamdhip64.so), and the dynamic loader keeps whichever
+    # libamdhip64 a process met first.  Loaded before torch, this library would pull in the system's runtime (/opt/rocm/lib) and torch
+    # would then run on that one instead of the one it was built against -- on the GPU box r2f_create then fails with R2F_EHIP
+    # (found with `python __graft_entry__.py --smoke`, i.e. build() -- which binds the library -- and smoke() in ONE process).  The
+    # Python layer needs torch anyway (device buffers, streams); a host that only wants the C ABI binds the .so itself.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # (the plan-only entry points and the symbol tests work without it)
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
