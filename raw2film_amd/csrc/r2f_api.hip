@@ -41,6 +41,8 @@ struct StencilSet {
     DevStencil dev[3];
     plan::StencilGeom geom[3];  // the host-side geometry dev[] was filled from
     bool mixed_sign[3] = {false, false, false};  // the channel has taps of both signs (set by r2f_set_kernel)
+    bool unit_gain[3] = {false, false, false};   // no negative tap and the taps sum to 1 (>= 0.99): an output is no smaller than the
+                                                 // smallest sample under the stencil -- what the 12-byte element's guard presumes
     int single_tap_mask = 0;  // channels whose stencil is ONE tap at the anchor (set by r2f_set_kernel: a scan of every tap, which
                               // the per-frame front / range calls of a row shard must not repeat -- 15 us of host time per call)
     DeviceBuf wbuf[3], mbuf[3];
@@ -688,8 +690,12 @@ int run_stencil_fft(r2f_ctx* ctx, int which, const int* chans, int nch, const r2
     a.s32 = ((ctx->opt_fft_s96 >> which) & 1) ? 2 : (s32_eff ? 1 : 0);
     for (int i = 0; i < nch; ++i)
         if (set.mixed_sign[chans[i]] && ctx->opt_fft_mixed_sign) a.s32 = 0;  // (the 12-byte element neither)
-    // the halation of a whole-frame render whose front kernel recorded the range of the exposure planes: element chosen on the device
-    if (a.s32 == 0 && which == R2F_KERNEL_HALATION && epilogue == 1 && dyn && ctx->opt_fft_s96_auto && a.kreal &&
+    // the halation of a whole-frame render whose front kernel recorded the range of the exposure planes: element chosen on the device.
+    // The guard compares a window's SAMPLES; it speaks for the outputs only under a stencil of unit gain (the reference's halation
+    // kernels are normalised and non-negative, effects.py:200-217): taps that cancel or sum to 0.01 make outputs far below the samples
+    bool unit_gain = true;
+    for (int i = 0; i < nch; ++i) unit_gain = unit_gain && set.unit_gain[chans[i]];
+    if (a.s32 == 0 && which == R2F_KERNEL_HALATION && epilogue == 1 && dyn && ctx->opt_fft_s96_auto && a.kreal && unit_gain &&
         ny == 256 && ctx->opt_fft_cols_walk && ctx->curve.cells) {
         a.s32 = 3;  // (the flags are worked out below, once the call's tiling is known)
         ctx->frame_dyn_armed = true;
@@ -1153,11 +1159,14 @@ int r2f_set_kernel(r2f_ctx* ctx, int which, const float* k, int kh, int kw, int 
     s.host.assign(k, k + (size_t)kh * kw * kc);
     for (int c = 0; c < 3; ++c) {
         bool pos = false, neg = false;
+        double sum = 0.0;
         for (size_t i = 0; i < (size_t)kh * kw; ++i) {
             const float v = k[i * kc + (kc == 1 ? 0 : c)];
             pos = pos || v > 0.f, neg = neg || v < 0.f;
+            sum += (double)v;
         }
         s.mixed_sign[c] = pos && neg;
+        s.unit_gain[c] = !neg && sum >= 0.99;  // (NaN taps: false)
     }
     s.single_tap_mask = 0;
     for (int c = 0; c < 3; ++c) {

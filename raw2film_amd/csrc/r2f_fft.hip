@@ -307,9 +307,24 @@ __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) 
 }
 
 // One thread per pair-in-channel: {min, max |.|} over the tiles the pair's two windows touch -> flags[pc].  A window reads the
-// global rows [wy, wy + ny) and columns [wx, wx + nx), reflected (101) into the frame -- which lands inside the part of the
-// window that is in the frame -- and, for a row shard, clamped to the rows its source buffer holds (pass 1): the tile range
-// below is that.  A tile nobody recorded (reset values) means "unknown": complex128.
+// global rows [wy, wy + ny) and columns [wx, wx + nx), reflected (101) into the frame and, for a row shard, clamped to the rows
+// its source buffer holds (pass 1).  What counts is every sample whose rounding can reach a KEPT output:
+// * along a row the transforms mix all nx columns, so all columns of the window count, also the reflected ones that feed only
+//   discarded outputs.  At the left edge the reflection lands inside the part of the window that is in the frame; at the right
+//   edge it need not -- the last window column may keep 44 frame columns and bring in 468 reflected ones from up to 424 columns
+//   to the LEFT of the window -- so the column range is widened by the reflection's reach (reflected_reach: a superset when a
+//   narrow frame is reflected more than once);
+// * across the rows both roundings are row-local (pass 1 rounds a row's own spectrum; pass 2 rounds an output row's, which the
+//   stencil makes from the rows within its reach): rows that feed only discarded outputs cannot reach a kept one, and the rows
+//   within the reach of a kept output are reflected into the frame rows of the window (a window keeps an output only if it holds the
+//   reach above it).  tests/test_gpu_fft.py holds both edge cases.
+// A tile nobody recorded (reset values) means "unknown": complex128.
+__device__ __forceinline__ void reflected_reach(int w0, int n, int size, int& lo, int& hi) {
+    const int last = size - 1, w1 = w0 + n - 1;
+    lo = max(w0, 0), hi = min(w1, last);
+    if (w0 < 0) hi = max(hi, min(-w0, last));
+    if (w1 > last) lo = min(lo, max(2 * last - w1, 0));
+}
 __global__ __launch_bounds__(256) void fft_decide_kernel(const FftConvArgs a, const RangeRecord rec, const float bound, const float floor_, int* flags) {
     const int pc = blockIdx.x * 256 + threadIdx.x;
     if (pc >= a.ppc) return;
@@ -320,7 +335,8 @@ __global__ __launch_bounds__(256) void fft_decide_kernel(const FftConvArgs a, co
         if (!window_of(a, 2 * pc + half, wy, wx)) continue;
         const int b0 = a.src.gy0, b1 = a.src.gy0 + a.src.rows - 1;
         const int r0 = clampi(max(wy, 0), b0, b1), r1 = clampi(min(wy + a.ny - 1, a.H_global - 1), b0, b1);
-        const int c0 = max(wx, 0), c1 = min(wx + a.nx - 1, a.W - 1);
+        int c0, c1;
+        reflected_reach(wx, a.nx, a.W, c0, c1);
         for (int ty = r0 >> kRangeTileRowsLog2; ty <= (r1 >> kRangeTileRowsLog2); ++ty)
             for (int tx = c0 >> kRangeTileColsLog2; tx <= (c1 >> kRangeTileColsLog2); ++tx) {
                 if ((unsigned)ty >= (unsigned)rec.tyn || (unsigned)tx >= (unsigned)rec.txn) {

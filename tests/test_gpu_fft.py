@@ -528,6 +528,104 @@ def test_the_per_window_choice_keeps_the_promise_where_the_frame_level_one_could
     assert not np.array_equal(D["chosen"], D["c128"])  # (the element WAS taken where it may be)
 
 
+@pytest.mark.parametrize("edge", ["bottom", "right"])
+def test_the_per_window_choice_counts_what_the_reflection_brings_into_an_edge_window(ctx, edge):
+    """A window at the right (bottom) edge of the frame may hold few frame columns (rows) and many reflected ones -- and those come
+    from the LEFT of (from above) the window: 62 frame columns and 450 reflected ones here, reaching 389 columns to the left.  They
+    only feed discarded outputs, but along a row the 12-byte element's rounding scales with the energy of the whole window row, so a
+    bright field out there -- in a range tile the window's own frame columns do not touch -- must keep the window on complex128.
+    (Found reading the decide kernel late in round 6: it looked at the tiles under the window's frame columns only, and with an odd
+    number of window columns -- cfg 4 has 29 -- the edge window of every other row shares its complex image with the FIRST window
+    of the next row, whose tiles do not cover that reach either.)  Across the rows the roundings are row-local: at the bottom edge
+    the same arrangement is harmless, the element may be taken, and is.
+    Frame: deep shadow with one bright (4 000 .. 8 000) range-tile column (right) / bright with the last rows deep shadow from a
+    tile boundary on (bottom)."""
+    neg, _, _ = stocks()
+    rng = np.random.default_rng(13)
+    if edge == "right":
+        # windows yield 172 x 428 outputs; 5 window columns (odd): the fifth keeps columns 1670 .. 1731 of the frame and reads 1281 .. 1731;
+        # it is paired with the first window of the second row (columns 0 .. 469)
+        H, W = 300, 4 * 428 + 20
+        img = rng.uniform(1e-3, 2e-3, (H, W, 3)).astype(np.float32)
+        img[:, 1280:1536] = rng.uniform(4000.0, 8000.0, (H, 256, 3))  # range-tile column 5: reached by the reflection alone
+        regions = [(slice(0, 172), slice(1712, W)), (slice(172, H), slice(0, 428))]  # the outputs of both windows of that pair
+    else:
+        H, W = 2 * 172 + 12, 1100  # the third window row keeps rows 302 .. 355 of the frame and reads 153 .. 355
+        img = rng.uniform(4000.0, 8000.0, (H, W, 3)).astype(np.float32)  # range-tile rows 0 .. 3: reflected into the third window row
+        img[256:] = rng.uniform(1e-3, 2e-3, (H - 256, W, 3))             # tile rows 4 and 5: a factor 2
+        regions = [(slice(344, H), slice(0, 856))]                      # the kept outputs of the first pair of the third window row
+    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)
+    ctx.set_curve1d(neg.get_density_curve(0.0, 1.0))
+    ctx.set_kernel(0, k)
+    ctx.set_option("stencil_fft_window_rows", 256)
+    ctx.set_option("stencil_fft_window", 512)
+    params = ctx.make_params(halation=True)
+    E = planes(img)
+    D = {}
+    for name, forced in (("c128", 0), ("forced", 1)):
+        ctx.set_option("stencil_fft_scratch96", forced)
+        d = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_halation(E, d, params, y0=0, y1=H, H_global=H)
+        D[name] = d.cpu().numpy().astype(np.float64)
+    ctx.set_option("stencil_fft_scratch96", 0)
+    ctx.write_frame_params(params)
+    ctx.stage_exposure_range(E, y0=0, y1=H)
+    d = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+    ctx.stage_halation(E, d, params, y0=0, y1=H, H_global=H, range_valid=True)
+    D["chosen"] = d.cpu().numpy().astype(np.float64)
+    info = ctx.frame_exposure_range()
+    assert info["armed"] and 0 < info["packed_pairs"] < info["pairs"], info
+
+    def worst(name, where=(slice(None), slice(None)), against="c128"):
+        a, b = D[name][(slice(0, 2),) + where], D[against][(slice(0, 2),) + where]
+        return float((np.abs(a - b) - np.abs(b) * 2.0 ** -23).max())  # beyond the ulp two fp32 roundings may differ by
+
+    assert worst("chosen") <= 3.6e-7, worst("chosen")  # the promise, everywhere
+    # (the kernel instances that choose per pair are compiled apart from the ones that do not, and the fp32 log + curve epilogue of
+    # pass 3 need not contract its multiply-adds alike in both: on these shadows -- log10 = -3 at an fp32 ulp of 2.4e-7, densities
+    # of 0.43 at one of 3e-8 -- the same scratch image then gives densities up to 6 ulps = 1.8e-7 apart; "the same call's" below means
+    # within that, four times below what the element costs where it must not be taken)
+    for region in regions:
+        if edge == "right":
+            assert worst("forced", region) > 2 * 3.6e-7, worst("forced", region)  # the element on that pair WOULD break the promise
+            assert worst("chosen", region) <= 1.8e-7, worst("chosen", region)     # ... and it is the complex128 call's
+        else:
+            assert worst("forced", region) <= 3.6e-7, worst("forced", region)     # harmless: the bright rows cannot reach these outputs
+            assert worst("chosen", region, against="forced") <= 1.8e-7            # ... and the element is taken (the count below)
+    assert info["packed_pairs"] == (1 if edge == "right" else 3), info
+
+
+def test_the_per_window_choice_is_for_stencils_of_unit_gain(ctx):
+    """The guard of the 12-byte element compares the SAMPLES of a window pair; it speaks for the outputs because the reference's
+    halation kernels are non-negative and normalised (effects.py:200-217: an output is no smaller than the smallest sample under
+    the stencil).  Taps that sum to 0.01, or that cancel, put the outputs far below the samples: such a stencil in the halation slot
+    keeps complex128 whatever the record says."""
+    neg, _, _ = stocks()
+    rng = np.random.default_rng(14)
+    H, W = 300, 700
+    img = rng.uniform(1.0, 2.0, (H, W, 3)).astype(np.float32)
+    k = ok.compute_halation_kernel(341.33, halation_green_factor=0.3)
+    dim = (k * np.float32(0.01)).astype(np.float32)
+    cancel = k.copy()
+    cancel[3, 5, :2] -= np.float32(0.5)   # still centrally symmetric (real spectrum), taps of both signs
+    cancel[-4, -6, :2] -= np.float32(0.5)
+    ctx.set_curve1d(neg.get_density_curve(0.0, 1.0))
+    ctx.set_option("stencil_fft_window_rows", 256)
+    ctx.set_option("stencil_fft_window", 512)
+    params = ctx.make_params(halation=True)
+    E = planes(img)
+    for taps, want in ((k, True), (dim, False), (cancel, False), (k, True)):
+        ctx.set_kernel(0, taps)
+        ctx.write_frame_params(params)
+        ctx.stage_exposure_range(E, y0=0, y1=H)
+        d = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_halation(E, d, params, y0=0, y1=H, H_global=H, range_valid=True)
+        info = ctx.frame_exposure_range()
+        assert info["armed"] == want, (want, info)
+        if want:
+            assert info["packed_pairs"] == info["pairs"] > 0, info
+
+
 @pytest.mark.parametrize("window", WINDOWS)
 def test_real_spectrum_of_centrally_symmetric_taps(ctx, window):
     """Round 5.  Both production stencils are centrally symmetric around an anchor at the centre of their tap
