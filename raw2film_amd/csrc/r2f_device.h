@@ -281,6 +281,9 @@ __device__ __forceinline__ void merge_tile(const RangeRecord& rec, int gy, int t
 }
 // min / max of a value over the 64 lanes of a wave, by DPP (no LDS): the result is valid in every lane of the LAST row (lanes 48-63);
 // callers read lane 63.
+// a tile's minimum with one more sample: a NaN counts as "below every floor" (fminf alone would drop it; see the front kernel)
+__device__ __forceinline__ float range_min(float lo, float x) { return x != x ? -__builtin_inff() : fminf(lo, x); }
+
 template <bool IS_MAX>
 __device__ __forceinline__ float wave_extreme(float v) {
     auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); };

@@ -247,14 +247,15 @@ __global__ __launch_bounds__(64 * BY) void front_fast_kernel(const FrontArgs a) 
             p = lut2d(lut_lds, a.lut2d.n, p);
             if (UPTO == R2F_UPTO_EXPOSURE) {
                 r[q] = p.xy.x, g[q] = p.xy.y, b[q] = p.z;
-                // (fminf / fmaxf drop a NaN: pass 1 of the FFT form takes a non-finite sample as 0 anyway; an infinity stays)
+                // (fminf / fmaxf drop a NaN, and pass 1 of the FFT form takes a non-finite sample as 0: the outputs around it fall below
+                // the samples that are left, so for the minimum a NaN counts as "below every floor"; an infinity stays in the maximum)
                 if (TRK == 1) {
-                    p_lo = fminf(fminf(p_lo, r[q]), g[q]);
+                    p_lo = __builtin_isunordered(r[q], g[q]) ? -__builtin_inff() : fminf(fminf(p_lo, r[q]), g[q]);
                     p_hi = fmaxf(fmaxf(p_hi, fabsf(r[q])), fabsf(g[q]));
                 } else if (TRK == 2) {
-                    if (a.track_mask & 1) p_lo = fminf(p_lo, r[q]), p_hi = fmaxf(p_hi, fabsf(r[q]));
-                    if (a.track_mask & 2) p_lo = fminf(p_lo, g[q]), p_hi = fmaxf(p_hi, fabsf(g[q]));
-                    if (a.track_mask & 4) p_lo = fminf(p_lo, b[q]), p_hi = fmaxf(p_hi, fabsf(b[q]));
+                    if (a.track_mask & 1) p_lo = range_min(p_lo, r[q]), p_hi = fmaxf(p_hi, fabsf(r[q]));
+                    if (a.track_mask & 2) p_lo = range_min(p_lo, g[q]), p_hi = fmaxf(p_hi, fabsf(g[q]));
+                    if (a.track_mask & 4) p_lo = range_min(p_lo, b[q]), p_hi = fmaxf(p_hi, fabsf(b[q]));
                 }
                 if (FIN) {  // same arithmetic as single_tap_kernel with the halation epilogue: w * x, log10, curve
                     if (a.finish_mask & 1) r[q] = curve_eval_at((const float4*)cells_lds, a.curve, 0, log10_fast(a.finish_w[0] * r[q], a.log_eps));

@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(64 * kRangeRowsPerBlock) void exposure_range_kernel
             for (int k = 0; k < 4; ++k)
                 if (x0 + k < W) {
                     const float v = p[x0 + k];
-                    lo = fminf(lo, v), hi = fmaxf(hi, fabsf(v));
+                    lo = range_min(lo, v), hi = fmaxf(hi, fabsf(v));
                 }
         }
     }

@@ -595,6 +595,51 @@ def test_the_per_window_choice_counts_what_the_reflection_brings_into_an_edge_wi
     assert info["packed_pairs"] == (1 if edge == "right" else 3), info
 
 
+def test_a_nan_sample_keeps_its_windows_on_complex128():
+    """Pass 1 of the FFT form takes a non-finite sample as 0 (the reference's cv.filter2D would spread it over the stencil's reach):
+    the outputs around it fall below the samples that are left, which the guard of the 12-byte element compares.  The range record
+    therefore counts a NaN as "below every floor" -- in the front kernel and in the range kernel alike -- and the window pairs that
+    hold one decide with the floor for their minimum (here: complex128, their maximum being above bound x floor)."""
+    from helpers import SEED, oracle_inputs, stocks as _stocks
+    from raw2film_amd.context import HipContext
+    from raw2film_amd.synthetic import synthetic_frame
+    from test_gpu_parity import setup_ctx
+
+    H, W = 700, 1100
+    neg, prt, _ = _stocks()
+    p = oracle_inputs(neg, prt, 341.33, seed=SEED)
+    frame = np.clip(synthetic_frame(H, W, seed=9), 0.01, 16.0)
+    c = HipContext(0)
+    try:
+        params = setup_ctx(c, p)
+        c.set_option("stencil_fft_window_rows", 256)
+        c.set_option("stencil_fft_window", 512)
+        buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        buf.copy_(torch.from_numpy(frame))
+        for _ in range(3):
+            c.render(buf, params, out_f32=out)
+        clean = c.frame_exposure_range()
+        assert clean["packed_pairs"] == clean["pairs"] > 0 and clean["min"] > 0
+        buf[300:303, 500:503, :] = float("nan")  # (the front kernel's tables turn a NaN pixel into NaN exposure samples)
+        for _ in range(2):
+            c.render(buf, params, out_f32=out)
+        rng = c.frame_exposure_range()
+        assert rng["min"] == -np.inf and 0 < rng["packed_pairs"] < rng["pairs"], rng
+        # the same through the range kernel (a row shard's halo rows)
+        E = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        c.stage_front(buf, params, 0, dst=E)
+        assert bool(torch.isnan(E[:2]).any())
+        c.write_frame_params(params)
+        c.stage_exposure_range(E, y0=0, y1=H)
+        D = torch.empty_like(E)
+        c.stage_halation(E, D, params, y0=0, y1=H, H_global=H, range_valid=True)
+        rng2 = c.frame_exposure_range()
+        assert rng2["min"] == -np.inf and rng2["packed_pairs"] == rng["packed_pairs"], (rng, rng2)
+    finally:
+        c.close()
+
+
 def test_the_per_window_choice_is_for_stencils_of_unit_gain(ctx):
     """The guard of the 12-byte element compares the SAMPLES of a window pair; it speaks for the outputs because the reference's
     halation kernels are non-negative and normalised (effects.py:200-217: an output is no smaller than the smallest sample under
