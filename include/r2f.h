@@ -176,6 +176,11 @@ R2F_API int r2f_frame_exposure_range(r2f_ctx* ctx, float* out4, int* armed, int*
  * on the device, *packed_pairs took the 12-byte element (r2f_frame_exposure_range's *packed = all of them).  0 / 0 when the last call
  * did not choose.  Synchronises the device; introspection for the measurement harness and the tests. */
 R2F_API int r2f_frame_scratch_choice(r2f_ctx* ctx, int* pairs, int* packed_pairs);
+/* The same choice pair by pair: flags[i] = 1 when window pair i (per channel; its windows are 2 i and 2 i + 1 in row-major order over the
+ * call's grid of windows, r2f_plan_fft) took the 12-byte element.  At most `capacity` flags are written; *count = pairs per channel
+ * (0 when the last halation call did not choose).  Synchronises the device.  What tools/scratch_choice_model.py checks against a host
+ * model of the samples each pair's windows hold: a pair may take the element only if ITS samples allow it. */
+R2F_API int r2f_frame_scratch_flags(r2f_ctx* ctx, int32_t* flags, int capacity, int* count);
 
 /* The per-render uniform write: p->seed -> the context's device-side frame block, asynchronously on `stream`
  * (gpu_processor.py:585-597: the uniform buffer `buffer_params_grain` with a fresh random seed, made ahead of the dispatches;

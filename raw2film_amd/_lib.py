@@ -162,6 +162,7 @@ _SIGNATURES = {
     "r2f_write_frame_params": (C.c_int, [C.c_void_p, _P(Params), C.c_void_p]),
     "r2f_frame_exposure_range": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_int), _P(C.c_int)]),
     "r2f_frame_scratch_choice": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
+    "r2f_frame_scratch_flags": (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_int, _P(C.c_int)]),
     "r2f_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "r2f_histogram_render": (
         C.c_int,

@@ -135,6 +135,18 @@ class HipContext:
                 "armed": bool(armed.value), "twelve_byte_element": bool(packed.value),
                 "pairs": int(pairs.value), "packed_pairs": int(packed_pairs.value)}
 
+    def frame_scratch_flags(self):
+        """r2f_frame_scratch_flags: one flag per window pair (per channel) of the last halation call that chose its scratch element on
+        the device -- 1 = the 12-byte element -- as a numpy int32 array (empty when it did not choose).  Synchronises the device."""
+        import numpy as np
+
+        n = C.c_int()
+        self._check(self._lib.r2f_frame_scratch_flags(self._h, None, 0, C.byref(n)))
+        flags = np.zeros(max(int(n.value), 0), dtype=np.int32)
+        if flags.size:
+            self._check(self._lib.r2f_frame_scratch_flags(self._h, flags.ctypes.data_as(C.POINTER(C.c_int32)), int(flags.size), C.byref(n)))
+        return flags
+
     def write_frame_params(self, params):
         """The per-render uniform write (r2f_write_frame_params): params.seed -> the context's device-side frame block, in
         stream order.  Stage calls whose params carry F_FRAME_RESIDENT read it instead of writing their own seed."""

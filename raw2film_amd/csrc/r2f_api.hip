@@ -2082,6 +2082,18 @@ int r2f_frame_scratch_choice(r2f_ctx* ctx, int* pairs, int* packed_pairs) {
     return R2F_OK;
 }
 
+int r2f_frame_scratch_flags(r2f_ctx* ctx, int32_t* out, int capacity, int* count) {
+    if (!ctx || !count || capacity < 0 || (capacity > 0 && !out)) return R2F_EINVAL;
+    R2F_GUARD(ctx);
+    *count = 0;
+    if (!ctx->frame_dyn_armed || !ctx->dyn_flags.p || ctx->dyn_flags_ppc <= 0) return R2F_OK;
+    R2F_HIP(ctx, hipDeviceSynchronize());
+    *count = ctx->dyn_flags_ppc;
+    const int n = std::min(capacity, ctx->dyn_flags_ppc);
+    if (n > 0) R2F_HIP(ctx, hipMemcpy(out, ctx->dyn_flags.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return R2F_OK;
+}
+
 int r2f_write_frame_params(r2f_ctx* ctx, const r2f_params* p, void* stream) {
     if (!ctx || !p) return R2F_EINVAL;
     R2F_GUARD(ctx);

@@ -319,6 +319,9 @@ __device__ __forceinline__ char* simg(double2* s1, long long pair, long long n) 
 //   within the reach of a kept output are reflected into the frame rows of the window (a window keeps an output only if it holds the
 //   reach above it).  tests/test_gpu_fft.py holds both edge cases.
 // A tile nobody recorded (reset values) means "unknown": complex128.
+#ifndef R2F_DECIDE_OWN_COLUMNS_ONLY
+#define R2F_DECIDE_OWN_COLUMNS_ONLY 0
+#endif
 __device__ __forceinline__ void reflected_reach(int w0, int n, int size, int& lo, int& hi) {
     const int last = size - 1, w1 = w0 + n - 1;
     lo = max(w0, 0), hi = min(w1, last);
@@ -337,6 +340,9 @@ __global__ __launch_bounds__(256) void fft_decide_kernel(const FftConvArgs a, co
         const int r0 = clampi(max(wy, 0), b0, b1), r1 = clampi(min(wy + a.ny - 1, a.H_global - 1), b0, b1);
         int c0, c1;
         reflected_reach(wx, a.nx, a.W, c0, c1);
+#if R2F_DECIDE_OWN_COLUMNS_ONLY  // development switch: the decide kernel as it was before the reflected reach counted (the hole
+        c0 = max(wx, 0), c1 = min(wx + a.nx - 1, a.W - 1);  // tools/scratch_choice_model.py finds at once; never in a shipped build)
+#endif
         for (int ty = r0 >> kRangeTileRowsLog2; ty <= (r1 >> kRangeTileRowsLog2); ++ty)
             for (int tx = c0 >> kRangeTileColsLog2; tx <= (c1 >> kRangeTileColsLog2); ++tx) {
                 if ((unsigned)ty >= (unsigned)rec.tyn || (unsigned)tx >= (unsigned)rec.txn) {

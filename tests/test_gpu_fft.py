@@ -596,6 +596,28 @@ def test_the_per_window_choice_counts_what_the_reflection_brings_into_an_edge_wi
     assert info["packed_pairs"] == (1 if edge == "right" else 3), info
 
 
+def test_no_window_pair_takes_the_twelve_byte_element_against_its_own_samples(ctx):
+    """The soundness of the per-window-pair choice without any numerics (tools/scratch_choice_model.py): the flags the device left
+    (r2f_frame_scratch_flags) against a host model that gathers, from the exposure planes themselves, the samples whose rounding can
+    reach an output each pair keeps -- reflected and clamped like pass 1 reads them, both windows of the pair, all their columns.
+    Random frame sizes (edges and pairings fall everywhere), whole frames and row shards with a source buffer of their own, the
+    record filled by the range kernel or by the front kernel, tile-aligned bright regions, NaN samples: a pair may take the element
+    only if ITS samples satisfy the rule.  (The right-edge hole of round 6 passed every parity soak; the tool finds it in 5 of 1 500
+    random calls -- profiles/r06_scratch_choice_model.txt -- so the fixed budget here guards the mechanism, the tool the rare case.)"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import scratch_choice_model as scm
+
+    tot, bad = scm.soak(ctx, torch, budget=60, seed=20261004)
+    print(f"per-pair choice against the host model: {tot[0]} pairs, {tot[1]} took the element, {tot[2]} allowed by their own samples")
+    assert not bad, bad[:5]
+    assert tot[0] > 300 and tot[1] > 30          # the cases do exercise the choice ...
+    assert tot[1] <= tot[2]                       # ... a superset decides, so it never allows more than the exact range would ...
+    assert tot[1] >= 0.5 * tot[2], tot            # ... and the 64 x 256 tiles do not cost most of what it allows
+
+
 def test_a_nan_sample_keeps_its_windows_on_complex128():
     """Pass 1 of the FFT form takes a non-finite sample as 0 (the reference's cv.filter2D would spread it over the stencil's reach):
     the outputs around it fall below the samples that are left, which the guard of the 12-byte element compares.  The range record
