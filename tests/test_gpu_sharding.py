@@ -279,6 +279,120 @@ def test_row_shards_choose_the_halation_scratch_element_like_the_whole_frame(tmp
         assert lo >= rng["min"] and hi <= rng["max_abs"]  # a rank's record is a sub-range of the frame's
 
 
+def test_a_rank_vouches_for_exactly_the_rows_its_halation_reads_this_frame():
+    """The row-sharded renderer's side of the per-window-pair choice, checked without numerics (tools/scratch_choice_model.py): every
+    rank of a 3-rank world, on each of its three schedules, renders a sequence of hostile frames (extremes anywhere, halo rows
+    included; graphs captured and replayed on the way) with the halo exchange looped back from the whole frame's exposure planes --
+    and after every frame the flags its last vouched halation call left are held against a host model of the samples that call's
+    windows hold: own rows as the front calls wrote them, halo rows as they arrived THIS frame, nothing of the rows the buffer keeps
+    from an earlier frame (under two exchanges the planes are wider than what travels).  A pair may take the 12-byte element only
+    if its own samples allow it."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hostile
+    import scratch_choice_model as scm
+    from raw2film_amd import HipProcessor, stencils
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.sharding import HipStageBackend, RowShardedRenderer
+
+    class Loopback(RowShardedRenderer):
+        """Neighbours that answer at once: the exposure halo rows come from the whole frame's planes (full_E); the density halo of
+        the two-exchange schedule does not travel (its rows feed outputs nobody looks at here)."""
+        full_E = None
+
+        def _exchange(self, buf, buf_gy0, above, below, wait=True):
+            p = self.plan
+            if buf is not self.E:
+                return None
+            above = [above] * 3 if isinstance(above, int) else list(above)
+            below = [below] * 3 if isinstance(below, int) else list(below)
+            for c in range(3):
+                if p.rank > 0 and above[c]:
+                    buf[c, p.r0 - above[c] - buf_gy0:p.r0 - buf_gy0].copy_(self.full_E[c, p.r0 - above[c]:p.r0])
+                if p.rank < p.world - 1 and below[c]:
+                    buf[c, p.r1 - buf_gy0:p.r1 + below[c] - buf_gy0].copy_(self.full_E[c, p.r1:p.r1 + below[c]])
+            return None
+
+    neg, prt, _ = stocks()
+    # 420 px/mm: the halation reaches 52 rows; three shards of 310 rows -- the middle rank's upper halo (rows 258 .. 309) lies inside the
+    # range tile its own first rows belong to (rows 256 .. 319): a tile the record knows whether or not the halo rows were added
+    H, W, fw = 930, 1300, 3.1
+    proc = HipProcessor(device=0)
+    proc.ctx.set_option("stencil_fft_window_rows", 256)
+    params = proc.prepare(neg, 6, 0.4, (W, H), seed=SEED, matrix=REC709_TO_XYZ, print_film=prt, frame_width=fw,
+                          frame_height=fw * H / W, halation_green_factor=0.3, exp_kelvin=6000, color_masking=1.0)
+    scale = max(H, W) / fw
+    hal = stencils.halation_stencil(scale, 1.0, halation_green_factor=0.3)
+    mtf = stencils.mtf_stencil(neg, scale, 0.0, 1.0)
+    geo = scm.geometry(hal, (0, 1))
+    rng = np.random.default_rng(20261005)
+    frames = [scm.random_frame(rng, H, W, hostile) for _ in range(4)]
+    frames = [np.nan_to_num(f, nan=1.0) for f in frames]  # (NaN pixels have their own test; here they would blank whole LUT cells)
+    # ... and the two frames this is about: shadows everywhere / shadows with a bright band of 30 rows next to every shard boundary
+    # (in the halo its neighbour sends the middle rank, outside that rank's own rows): rendered alternately, so that what a buffer keeps
+    # from the frame before is always the opposite of what this frame holds
+    dark = (1e-3 * rng.uniform(1.0, 3.0, (H, W, 3))).astype(np.float32)
+    band = dark.copy()
+    for b0, b1 in ((280, 310), (620, 650)):  # (either side of the middle rank's rows [310, 620): in its halo, not in its own rows)
+        band[b0:b1] = (1e3 * rng.uniform(0.5, 1.0, (b1 - b0, W, 3))).astype(np.float32)
+    frames += [dark, band]
+    E_full = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+
+    def run(cls, rank, kw, order):
+        be = HipStageBackend.for_stencils(proc.ctx, params, hal, mtf)
+        calls = []
+        inner = be.halation
+
+        def recording(E, e_gy0, D, d_gy0, y0, y1, Hh, identity_done=0, range_valid=False):
+            calls.append((int(e_gy0), int(E.shape[1]), int(y0), int(y1), bool(range_valid)))
+            return inner(E, e_gy0, D, d_gy0, y0, y1, Hh, identity_done=identity_done, range_valid=range_valid)
+
+        be.halation = recording
+        rr = cls(be, H, W, halation=True, mtf=True, rank=rank, world=3, graph=True, dyn_scratch=True, **kw)
+        out = torch.empty((rr.plan.rows, W, 3), dtype=torch.float32, device="cuda")
+        pairs = packed = allowed = 0
+        bad = []
+        for i in order:  # (the graphs are captured on the first frames and replayed on the others)
+            img = torch.from_numpy(frames[i]).cuda()
+            proc.ctx.stage_front(img, params, 0, dst=E_full)
+            rr.full_E = E_full
+            rr.render(img[rr.plan.r0:rr.plan.r1].contiguous(), out_f32=out, seed=i)
+            info = proc.ctx.frame_exposure_range()
+            flags = proc.ctx.frame_scratch_flags()
+            vouched = [c for c in calls if c[4]]
+            assert info["armed"] and vouched, (rank, kw, info)
+            e_gy0, e_rows, y0, y1, _ = vouched[-1]
+            ny, nx = proc.ctx.stencil_stats(0)[0]["window"]
+            assert ny == 256
+            m = scm.model(E_full.cpu().numpy(), geo, y0, y1, H, W, e_gy0, e_gy0 + e_rows, info["bound"], info["floor"], (0, 1), NY=ny, NX=nx)
+            assert len(m) == len(flags), (rank, kw, len(m), len(flags))
+            bad += [(rank, kw, i, y0, y1, e_gy0, e_rows, pc, m[pc]) for pc in range(len(m)) if flags[pc] and not m[pc][0]]
+            if os.environ.get("R2F_DEBUG_SHARD_MODEL"):
+                print(cls.__name__, rank, kw, "frame", i, "call", (y0, y1), "buffer", (e_gy0, e_gy0 + e_rows), "window", (ny, nx), "flags", flags.tolist(), "model", [(a, f"{lo:.2g}", f"{hi:.2g}") for a, lo, hi in m])
+            pairs, packed, allowed = pairs + len(m), packed + int(flags.sum()), allowed + sum(a for a, _, _ in m)
+        return pairs, packed, allowed, bad
+
+    tot = np.zeros(3, dtype=np.int64)
+    for rank in range(3):
+        for kw in (dict(exchanges=1, split_halation=False), dict(exchanges=1, split_halation=True), dict(exchanges=2)):
+            n, k, a, bad = run(Loopback, rank, kw, (0, 5, 4, 5, 1, 4, 5, 2, 4, 3))
+            assert not bad, bad[:3]
+            tot += (n, k, a)
+    print(f"row shards against the host model: {tot[0]} pairs, {tot[1]} took the element, {tot[2]} allowed by their own samples")
+    assert tot[0] > 400 and 0 < tot[1] <= tot[2] < tot[0]
+
+    # the control: a middle rank that does NOT add its halo rows to the record still has their tiles "known" through the own rows
+    # that share them -- and takes the element on windows whose halo rows hold the bright band: the model must object
+    class NoHaloRange(Loopback):
+        def _halo_range(self):
+            pass
+
+    _, _, _, bad = run(NoHaloRange, 1, dict(exchanges=2), (4, 5, 4, 5))
+    assert bad, "the host model did not notice halo rows missing from the record"
+    proc.close()
+
+
 def test_four_rank_hip_row_shards_bit_identical_to_single_gpu(tmp_path):
     """Four ranks (gloo, all on cuda:0): ranks 1 and 2 have a neighbour on BOTH sides, which a 2-rank world never exercises --
     two sends and two receives in one batch, halos above and below.  Direct stencils: bit-identical to the whole frame."""

@@ -50,9 +50,9 @@ def geometry(kernel, fft_channels):
     return bh, bw, k.shape[0] // 2 - b0, k.shape[1] // 2 - b2
 
 
-def model(E, geo, y0, y1, H, W, buf0, buf1, bound, floor_, fft_channels):
+def model(E, geo, y0, y1, H, W, buf0, buf1, bound, floor_, fft_channels, NY=NY, NX=NX):
     """Per pair: (allowed by its own samples, lo, hi).  E: (3, H, W) float32 host copy of the WHOLE frame's exposure planes; the call
-    covers rows [y0, y1) from a source buffer that holds rows [buf0, buf1)."""
+    covers rows [y0, y1) from a source buffer that holds rows [buf0, buf1).  NY x NX: the call's window shape."""
     bh, bw, ay, ax = geo
     vy, vx = NY - bh + 1, (NX - bw + 1) & ~3
     gx = (W + vx - 1) // vx
