@@ -11,7 +11,7 @@ the tiles are: a pair that took the element satisfies the rule on ITS OWN sample
     both windows of the pair (they share one complex image), the FFT channels of the stencil.
 Random frames (tests/hostile.py families, tile-aligned bright regions, NaN sprinkles), random frame sizes (so that edges and window
 pairings fall everywhere), whole-frame calls and row-shard calls with a source buffer of their own, the record filled by the range
-kernel or by the front kernel.  It also reports how many pairs the exact per-pair range WOULD allow (what the tiles' granularity
+kernel or by the front kernel, and whole frames through r2f_render itself (eager and from its captured graph).  It also reports how many pairs the exact per-pair range WOULD allow (what the tiles' granularity
 costs).  Numerics play no part: this is the soundness of the decision, which no parity soak sees (the right-edge hole of round 6 -- a
 window that reflects in columns its tiles did not cover -- passed 2 700 fuzz cases; this tool finds it in 5 of 1 500 random calls:
 profiles/r06_scratch_choice_model.txt).
@@ -126,7 +126,28 @@ def run_case(ctx, torch, rng, params, kernel, hostile, front=None, log=None):
     if y1 + below > H:
         buf0 = min(buf0, max(2 * (H - 1) - (y1 - 1 + below), 0))
     use_front = front is not None and bool(rng.integers(0, 3) == 0)
+    use_render = front is not None and not shard and not use_front and bool(rng.integers(0, 3) == 0)
     ctx.write_frame_params(params)
+    if use_render:
+        # the whole-frame entry itself: r2f_render (front kernel recording, halation choosing, MTF, tail) -- launched kernel by kernel
+        # on its first call, from a captured graph on the third; the exposure planes for the model come from an untracked front call
+        src = torch.from_numpy(img).cuda()
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        for _ in range(int(rng.integers(1, 4))):
+            ctx.render(src, front, out_f32=out)
+        info = ctx.frame_exposure_range()
+        flags = ctx.frame_scratch_flags()
+        Efull = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+        ctx.stage_front(src, front, 0, dst=Efull)
+        if not info["armed"]:
+            return 0, 0, 0, []
+        m = model(Efull.cpu().numpy(), geo, 0, H, H, W, 0, H, info["bound"], info["floor"], fft_channels)
+        assert len(m) == len(flags), (len(m), len(flags), H, W)
+        bad = [(pc, m[pc]) for pc in range(len(m)) if flags[pc] and not m[pc][0]]
+        if log:
+            log(f"H {H:4d} W {W:4d} r2f_render: pairs {len(m)} packed {int(flags.sum())} allowed by their own samples {sum(a for a, _, _ in m)}"
+                f"{'  VIOLATIONS ' + str(bad) if bad else ''}")
+        return len(m), int(flags.sum()), sum(a for a, _, _ in m), [(H, W, 0, H, 0, H, pc, v) for pc, v in bad]
     if use_front:
         # the exposure planes are made by the front kernel from `img` as a linear frame, which records what it writes; rows of the
         # buffer it does not write (none here: it writes the whole buffer) would stay unknown
@@ -198,7 +219,7 @@ if __name__ == "__main__":
     ctx = HipContext(0, lib_path=args.lib)
     tot, bad = soak(ctx, torch, args.budget, args.seed, log=print if args.verbose else None)
     print(f"# tools/scratch_choice_model.py --budget {args.budget} --seed {args.seed}{' --lib ' + args.lib if args.lib else ''}: {tot[0]} window pairs in {args.budget} random calls "
-          f"(whole frames and row shards, range kernel and front kernel)")
+          f"(whole frames and row shards; record by the range kernel, the front kernel, r2f_render)")
     print(f"#   took the 12-byte element: {tot[1]}   allowed by their own samples (exact per-pair range): {tot[2]}   "
           f"-> the 64 x 256 tiles cost {tot[2] - tot[1]} pairs ({100.0 * (tot[2] - tot[1]) / max(tot[2], 1):.1f} % of the allowed ones)")
     print(f"#   pairs that took the element AGAINST their own samples: {len(bad)}")
