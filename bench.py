@@ -751,13 +751,25 @@ def main():
             e2e.append((time.perf_counter() - t0) * 1e3)
         copies["process_end_to_end_pinned_result_ms"] = min(e2e)
         copies["process_end_to_end_pinned_result_all_ms"] = [round(x, 3) for x in e2e]
+        # ... which streams the frame through the pipeline in row bands while it arrives (HipProcessor._process_streamed: PCIe is full
+        # duplex and the stage entry points are row-range calls); the same call with upload, render and download one after the other:
+        bands, proc.stream_bands = proc.stream_bands, 0
+        e2e = []
+        for i in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + 30 + i, lens_correction=False, **settings)
+            e2e.append((time.perf_counter() - t0) * 1e3)
+        copies["process_end_to_end_pinned_result_one_after_the_other_ms"] = min(e2e)
+        copies["process_stream_bands"] = bands
         # where that call's time goes: one more call with a device synchronisation behind every stage
         # (HipProcessor.profile_stages -- a measuring mode: its total is a little above the un-profiled call's)
         proc.profile_stages = True
         proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + 20, lens_correction=False, **settings)
         proc.profile_stages = False
+        proc.stream_bands = bands
         copies["process_stage_ms"] = {k: round(float(v), 3) for k, v in proc.last_stage_ms.items()}
-        copies["process_stage_note"] = ("HipProcessor.process(host ndarray, cache=False, result_buffers=2) with a synchronisation behind each stage: "
+        copies["process_stage_note"] = ("the one-after-the-other path of HipProcessor.process(host ndarray, cache=False, result_buffers=2) with a synchronisation behind each stage: "
                                         "host_phase = extract_image_data_cpu (views and index arithmetic; cache=False skips the 32-row checksum "
                                         "that cost ~4 ms in round 5), upload_and_device_prepath = the fp32 frame over PCIe + the clamp of "
                                         "gpu_processor.py:275 on the device, prepare_and_render = table checks + r2f_render, download = uint8 "
@@ -772,7 +784,9 @@ def main():
                           "the launch stream, best of 5.  process_end_to_end: wall clock of HipProcessor.process(host ndarray, cache=False) -> "
                           "uint8 ndarray, best of 3 (first call listed too: it builds tables and pinned staging buffers): upload 21 + render 5 + a download "
                           "into a FRESH pageable array (33 ms for 0.3 GB -- upstream's ownership semantics); process_end_to_end_pinned_result: the "
-                          "same with result_buffers = 2 (a view of a pinned buffer comes back)")
+                          "same with result_buffers = 2 (a view of a pinned buffer comes back), which also lets the frame stream through the "
+                          "pipeline in process_stream_bands row bands while it arrives -- upload of band k + 2, render of band k + 1, download "
+                          "of band k at the same time; ..._one_after_the_other: the same call with stream_bands = 0")
         result["host_device_copies"] = copies
         del host_f32, host_np
 

@@ -63,6 +63,10 @@ class HipProcessor:
         self.lenses = lenses
         self.payload_alpha = bool(payload_alpha)
         self.result_buffers = int(result_buffers)  # 0: process() returns a fresh array; n: views of n pinned buffers in turn (_download)
+        # process(host array, cache=False) with pinned result buffers streams a large frame through the pipeline in row bands while it
+        # is still arriving (_process_streamed): at most this many, of at least 512 rows each (100 MP: 16 bands of 512 rows = 23.3 ms
+        # against 24.7 with 8, 27.2 with 4, 24.9 with 24 -- tools/stream_bands_probe.py); 0: upload, render, download one after the other
+        self.stream_bands = 16
         self.ctx = HipContext(device, lib_path=lib_path)
         self.device = self.ctx.device  # NB: a torch device, not a wgpu device (gui.py:1652 uses bitmap mode)
         # comparison dicts, same role as cpu_processor.py:41-45 / gpu_processor.py
@@ -150,6 +154,7 @@ class HipProcessor:
         k = stencils.halation_stencil(scale, halation_size, halation_red_factor, halation_green_factor,
                                       halation_blue_factor, halation_intensity, bw=bw)
         self.ctx.set_kernel(_lib.KERNEL_HALATION, k)
+        self._halation_reach = stencils.vertical_reach(k)  # (rows above, rows below): what a row band needs of its neighbours
         self.uploads += 1
         self.halation_param_dict = new
 
@@ -159,7 +164,9 @@ class HipProcessor:
                "sharpening_sigma": sharpening_sigma}
         if new == self.mtf_param_dict:
             return
-        self.ctx.set_kernel(_lib.KERNEL_MTF, stencils.mtf_stencil(negative_film, scale, sharpening_strength, sharpening_sigma))
+        k = stencils.mtf_stencil(negative_film, scale, sharpening_strength, sharpening_sigma)
+        self.ctx.set_kernel(_lib.KERNEL_MTF, k)
+        self._mtf_reach = stencils.vertical_reach(k)
         self.uploads += 1
         self.mtf_param_dict = new
 
@@ -358,6 +365,25 @@ class HipProcessor:
 
             self._torch.cuda.synchronize(self.device)
             t_start = time.perf_counter()
+        elif (not cache and self.stream_bands > 1 and self.result_buffers > 0 and dst_texture is None and isinstance(src, np.ndarray)
+              and src.dtype != np.uint16 and not rotation and not chroma_nr and canvas_mode == "No" and not highlight_burn):
+            # a large host frame that is uploaded for this one render: streamed through the pipeline in row bands while it arrives
+            res = self._process_streamed(
+                src, negative_film, grain_size, grain_sigma,
+                load=dict(cam=cam, lens=lens, lens_correction=lens_correction, frame_width=frame_width, frame_height=frame_height,
+                          rotation=rotation, zoom=zoom, rotate_times=rotate_times, flip=flip, resolution=resolution, half_size=half_size,
+                          cache=cache, chroma_nr=chroma_nr, max_scale=max_scale, canvas_mode=canvas_mode, canvas_scale=canvas_scale,
+                          canvas_ratio=canvas_ratio, exposure=exposure, metadata=metadata),
+                print_film=print_film, exp_comp=exp_comp, red_light=red_light, green_light=green_light, blue_light=blue_light,
+                projector_kelvin=projector_kelvin, shadow_comp=shadow_comp, sat_adjust=sat_adjust, gamma_func=gamma_func,
+                exp_kelvin=exp_kelvin, tint=tint, inversion_gamma=inversion_gamma, idealized_curve=idealized_curve, inversion=inversion,
+                push_pull=push_pull, white_balance=white_balance, white_clip=white_clip, icc_transform=icc_transform,
+                frame_width=frame_width, frame_height=frame_height, halation_intensity=halation_intensity, halation=halation,
+                halation_size=halation_size, halation_green_factor=halation_green_factor, sharpness=sharpness,
+                sharpening_strength=sharpening_strength, sharpening_sigma=sharpening_sigma, grain=grain, highlight_burn=highlight_burn,
+                burn_scale=burn_scale, color_masking=color_masking, seed=seed)
+            if res is not None:
+                return res
         # GpuProcessor.load_image_texture (gpu_processor.py:655-719): the pre-processed frame stays on the device while the
         # load parameters do not change -- a re-render with other film settings neither prepares nor uploads it again
         self.load_image_texture(
@@ -523,6 +549,139 @@ class HipProcessor:
         out_u8 = self._render_prepared(image, layout, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture,
                                        histogram_texture, final_scaling, **settings)
         return None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
+
+    def _process_streamed(self, src, negative_film, grain_size, grain_sigma, *, load, **settings):
+        """process() of a large host frame that is uploaded for this one render (cache=False), with pinned result buffers: the
+        frame goes through the pipeline in `stream_bands` row bands WHILE IT ARRIVES -- band k is clamped and taken through S0 + S1
+        as soon as it is on the device, the halation of band k - 1 follows (its stencil reads the first rows of band k), then the
+        MTF and the tail of band k - 2, whose uint8 rows start their way back while later bands are still coming up: the stage
+        entry points are row-range calls (the ones a row shard makes: grain hashed at global coordinates, reflection at the frame
+        edges only, the exposure-range record kept like r2f_render keeps it), PCIe is full duplex, and what remains of the render
+        and the download behind the upload is the last two bands' share.  At 100 MP: upload 21.1 ms, render 4.7, download 5.3
+        one after the other = 32.5 ms; streamed 23.3 (bench.py host_device_copies, tools/stream_bands_probe.py).
+        The FFT stencils' windows are anchored at a call's first row, so a band's outputs agree with the whole-frame render's to the
+        FFT form's rounding (an fp32 ulp on a handful of samples, like a row shard's); pointwise configurations agree bit for bit.
+        Returns None when the frame does not qualify (the caller then takes the one-after-the-other path): a device pre-path
+        (uint16, rotation, chroma NR, scaling), a canvas, a highlight burn (a function of the whole grained frame), a small frame."""
+        payload = self.extract_image_data_cpu(
+            src, load["cam"], load["lens"], load["lens_correction"], load["frame_width"], load["frame_height"], load["rotation"],
+            load["zoom"], load["rotate_times"], load["flip"], load["resolution"], load["half_size"], load["cache"], load["chroma_nr"],
+            load["max_scale"], load["canvas_mode"], load["canvas_scale"], load["canvas_ratio"], exposure=load["exposure"],
+            metadata=load["metadata"], _internal=True)
+        host = self._payload_tensor(payload)
+        if (payload.get("warp") or payload.get("resize_to") or payload.get("upscale_to") or payload.get("chroma_nr")
+                or payload.get("u16_factor") is not None or not payload.get("clip_on_device") or payload.get("canvas_resolution")
+                or host.is_cuda or host.dim() != 3 or int(host.shape[2]) != 3 or host.numel() < (1 << 24)):
+            return None
+        H, W = int(host.shape[0]), int(host.shape[1])
+        fr = payload.get("final_resolution")
+        if fr is not None and (int(fr[0]), int(fr[1])) != (H, W):
+            return None
+        torch, ctx = self._torch, self.ctx
+        params = self.prepare(negative_film, grain_size, grain_sigma, (W, H), **settings)
+        flags = int(params.flags)
+        hal, mtf, grain = bool(flags & _lib.F_HALATION), bool(flags & _lib.F_MTF), bool(flags & _lib.F_GRAIN)
+        if flags & _lib.F_BURN:
+            return None
+        ha = self._halation_reach if hal else (0, 0)
+        ma = self._mtf_reach if mtf else (0, 0)
+        n = min(int(self.stream_bands), max(H // 512, 2))
+        while n > 1 and H // n < max(2 * max(ha + ma) + 2, 64):  # a band holds its neighbours' halo (and is worth a launch)
+            n -= 1
+        if n < 2 or W % 4:
+            return None
+        bounds = [H * i // n for i in range(n + 1)]
+        bufs = getattr(self, "_stream_bufs", None)
+        if bufs is None or bufs["shape"] != (H, W) or bufs["mtf"] != mtf:
+            def planes():
+                return torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+
+            bufs = self._stream_bufs = {"shape": (H, W), "mtf": mtf, "image": torch.empty((H, W, 3), dtype=torch.float32, device=self.device),
+                                        "E": planes(), "D": planes(), "D2": planes() if mtf else None,
+                                        "u8": torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)}
+        image, E, D, D2, out_u8 = bufs["image"], bufs["E"], bufs["D"], bufs["D2"], bufs["u8"]
+        ring = getattr(self, "_result_ring", None)
+        nres = self.result_buffers
+        if ring is None or ring[0].shape != out_u8.shape or len(ring) != nres:
+            ring = self._result_ring = [torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(nres)]
+            self._result_turn = 0
+        result = ring[self._result_turn % nres]
+        self._result_turn += 1
+        if getattr(self, "_up_stream", None) is None:
+            self._up_stream = torch.cuda.Stream(device=self.device)
+            self._down_stream = torch.cuda.Stream(device=self.device)
+        up, down, compute = self._up_stream, self._down_stream, torch.cuda.current_stream(self.device)
+        p = _lib.Params.from_buffer_copy(params)
+        p.flags |= _lib.F_FRAME_RESIDENT  # the seed is written once, below; the stage calls read it from the frame block
+        ctx.write_frame_params(p)          # (and the exposure-range record starts empty)
+        up.wait_stream(compute)            # (the buffers may still be read by the previous frame's launches)
+        down.wait_stream(compute)
+        pointwise = not (hal or mtf or grain)
+        state = {"front": 0, "dens": 0, "mtf": 0, "tail": 0, "ident": 0}
+        cur = D2 if mtf else D
+
+        def band(b):
+            return bounds[b], bounds[b + 1]
+
+        def send_back(b):
+            y0, y1 = band(b)
+            done = compute.record_event()
+            with torch.cuda.stream(down):
+                down.wait_event(done)
+                result[y0:y1].copy_(out_u8[y0:y1], non_blocking=True)
+
+        def advance():
+            # every stage runs a band as soon as the rows it reads exist: a stencil stage reads into the band after its own
+            while True:
+                moved = False
+                if hal and state["dens"] < n and state["front"] > min(state["dens"] + 1, n - 1):
+                    y0, y1 = band(state["dens"])
+                    lo, hi = max(y0 - ha[0], 0), min(y1 + ha[1], H)
+                    ctx.stage_halation(E[:, lo:hi], D, p, src_gy0=lo, dst_gy0=0, y0=y0, y1=y1, H_global=H,
+                                       identity_done=state["ident"], range_valid=True)
+                    state["dens"] += 1
+                    moved = True
+                if not hal:
+                    state["dens"] = state["front"]
+                if mtf and state["mtf"] < n and state["dens"] > min(state["mtf"] + 1, n - 1):
+                    y0, y1 = band(state["mtf"])
+                    lo, hi = max(y0 - ma[0], 0), min(y1 + ma[1], H)
+                    ctx.stage_mtf(D[:, lo:hi], D2, p, src_gy0=lo, dst_gy0=0, y0=y0, y1=y1, H_global=H)
+                    state["mtf"] += 1
+                    moved = True
+                ready = state["mtf"] if mtf else state["dens"]
+                if not pointwise and state["tail"] < ready:
+                    y0, y1 = band(state["tail"])
+                    ctx.stage_tail(cur, p, src_gy0=0, out_u8=out_u8, out_gy0=0, y0=y0, y1=y1, H_global=H)
+                    send_back(state["tail"])
+                    state["tail"] += 1
+                    moved = True
+                if not moved:
+                    return
+
+        for k in range(n):
+            a0, a1 = band(k)
+            with torch.cuda.stream(up):
+                image[a0:a1].copy_(host[a0:a1], non_blocking=True)
+                arrived = up.record_event()
+            compute.wait_event(arrived)
+            rows = image[a0:a1]
+            rows.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, band by band
+            if pointwise:  # LUTs only: one fused pass per band, straight to uint8
+                ctx.stage_front(rows, p, 2, in_gy0=a0, out_u8=out_u8, out_gy0=0, y0=a0, y1=a1, H_global=H)
+                send_back(k)
+            elif hal:
+                state["ident"] = ctx.stage_front_split(rows, p, E, D, in_gy0=a0, y0=a0, y1=a1, H_global=H, track_range=True)
+            else:
+                ctx.stage_front(rows, p, 1, in_gy0=a0, dst=D, dst_gy0=0, y0=a0, y1=a1, H_global=H)
+            state["front"] = k + 1
+            advance()
+        down.synchronize()
+        self._texture = (image, None, {k: v for k, v in payload.items() if k != "image_array"})
+        self.image_param_dict = None
+        self._texture_src = None
+        self.last_output = out_u8
+        return result.numpy()
 
     def _download(self, out_u8):
         """The uint8 result as a NumPy array.  Default: a fresh array per call, like upstream.  With result_buffers = n > 0 the

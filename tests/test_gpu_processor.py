@@ -513,6 +513,72 @@ def test_a_large_host_frame_is_clamped_on_its_way_up_in_chunks():
     proc.close()
 
 
+def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
+    """Round 6: process(host array, cache=False) with pinned result buffers takes a frame of >= 16.7 M samples through the pipeline
+    in row bands (four of 600 rows here) while it arrives (HipProcessor._process_streamed): band k is clamped and fronted as soon as it is on the
+    device, the halation of band k - 1 and the MTF / tail / download of band k - 2 follow.  Same frame as the one-after-the-other
+    path: bit for bit where nothing but pointwise stages run (LUTs only; with grain: the hash is taken at global coordinates), to
+    the FFT form's rounding with the stencil stages (their windows are anchored at each call's first row, like a row shard's) --
+    out-of-range samples in the first, a middle and the last band, an odd row count, the same buffer edited and handed in again,
+    and the frames that do not qualify (a canvas, a burn, a rotation) taking the other path."""
+    from raw2film_amd import HipProcessor, filmstock
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    rng = np.random.default_rng(9)
+    H, W = 2403, 2400
+    img = (0.18 * 2.0 ** rng.normal(0.0, 1.5, (H, W, 1)) * rng.uniform(0.6, 1.4, (H, W, 3))).astype(np.float32)
+    img[0, 0] = (1e6, -2.0, 70000.0)
+    img[H // 2 + 7, 33] = (-1e-3, 0.5, -5.0)
+    img[H - 1, W - 1] = (80000.0, 65504.0, -0.0)
+    plain = HipProcessor(device=0, result_buffers=2)
+    plain.stream_bands = 0
+    banded = HipProcessor(device=0, result_buffers=2)
+    base = dict(print_film=prt, lens_correction=False, seed=2, frame_width=36, frame_height=36)
+    calls = []
+    inner = banded._process_streamed
+
+    def counted(*a, **k):
+        res = inner(*a, **k)
+        calls.append(res is not None)
+        return res
+
+    banded._process_streamed = counted
+    for name, kw, exact in (("luts", dict(grain=0, halation=False, sharpness=False), True),
+                            ("grain", dict(grain=2, halation=False, sharpness=False), True),
+                            ("full", dict(grain=2), False),
+                            ("halation", dict(grain=0, sharpness=False), False),
+                            ("mtf", dict(grain=0, halation=False), False)):
+        want = plain.process(img, neg, 6, 0.4, cache=False, **base, **kw).copy()
+        del calls[:]
+        got = banded.process(img, neg, 6, 0.4, cache=False, **base, **kw).copy()
+        assert calls == [True], (name, calls)
+        if exact:
+            np.testing.assert_array_equal(got, want, err_msg=name)
+        else:
+            d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size, (name, int(d.max()), int(np.count_nonzero(d)))
+    # the same buffer, other content: nothing of the previous frame is left in a band
+    img[100:200] *= 0.5
+    want2 = plain.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
+    got2 = banded.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
+    d = np.abs(got2.astype(np.int16) - want2.astype(np.int16))
+    assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size and not np.array_equal(got2, got)
+    # the histogram source is the streamed frame's device copy
+    np.testing.assert_array_equal(banded.last_output.cpu().numpy(), got2)
+    # frames that do not qualify take the other path and give its result
+    for kw in (dict(canvas_mode="Proportional", canvas_scale=1.1), dict(highlight_burn=0.5), dict(rotation=3.0), dict(cache=True)):
+        del calls[:]
+        args = dict(cache=False, grain=0, halation=False, sharpness=False)
+        args.update(kw)
+        got3 = banded.process(img, neg, 6, 0.4, **base, **args)
+        want3 = plain.process(img, neg, 6, 0.4, **base, **args)
+        np.testing.assert_array_equal(got3, want3, err_msg=str(kw))
+        assert not any(calls), (kw, calls)
+    plain.close()
+    banded.close()
+
+
 def test_pinned_result_buffers_return_views_in_turn():
     from raw2film_amd import HipProcessor, filmstock
 
