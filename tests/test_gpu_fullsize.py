@@ -375,6 +375,40 @@ def test_cfg4_100mp_uint8_windows_match_the_oracle(full):
     _check_windows(out, u8, frame, p, H_FULL, W_FULL, [(0, 0), (4000, 6000), (H_FULL - 96, W_FULL - 96)], 96, halo)
 
 
+def test_the_100mp_host_frame_streamed_in_row_bands_is_the_whole_frame_render():
+    """HipProcessor.process(host array, cache=False) with pinned result buffers at BASELINE's full size: the frame streams through the
+    pipeline in 16 bands of 512 rows while it arrives (3 halation window rows of 172 per band, anchored at the band's first row) --
+    against the same call with upload, render and download one after the other (r2f_render, whose windows the tests above hold
+    against the oracle): uint8, at most one step apart on at most 1e-4 of the samples; and the two pinned buffers come back in turn."""
+    from raw2film_amd import HipProcessor, filmstock
+    from raw2film_amd.hip_processor import REC709_TO_XYZ
+    from raw2film_amd.synthetic import synthetic_frame_device
+
+    stocks_ = filmstock.builtin_stocks()
+    neg, prt = stocks_["Kodak Portra 400"], stocks_["Kodak 2383"]
+    host = torch.empty((H_FULL, W_FULL, 3), dtype=torch.float32, pin_memory=True)
+    host.copy_(synthetic_frame_device(H_FULL, W_FULL, seed=23))
+    img = host.numpy()
+    kw = dict(print_film=prt, lens_correction=False, frame_width=36, frame_height=24, exp_kelvin=6000, color_masking=1.0,
+              halation_green_factor=0.3, matrix=REC709_TO_XYZ, seed=SEED, cache=False)
+    proc = HipProcessor(device=0, result_buffers=2)
+    try:
+        assert proc.stream_bands == 16
+        got = proc.process(img, neg, 6, 0.4, **kw)
+        proc.stream_bands = 0
+        want = proc.process(img, neg, 6, 0.4, **kw)
+        assert got.shape == want.shape == (H_FULL, W_FULL, 3) and got.dtype == np.uint8 and got.ctypes.data != want.ctypes.data
+        bad = 0
+        for r0 in range(0, H_FULL, 1024):  # (int16 differences of 0.3 G samples, a slab at a time)
+            d = np.abs(got[r0:r0 + 1024].astype(np.int16) - want[r0:r0 + 1024].astype(np.int16))
+            assert int(d.max()) <= 1
+            bad += int(np.count_nonzero(d))
+        assert bad <= 1e-4 * got.size, bad
+        assert got.std() > 10  # (a picture, not a constant)
+    finally:
+        proc.close()
+
+
 def test_a_frame_with_more_than_2_31_elements_per_buffer():
     """Maximum sizes: 32768 x 21888 x 3 = 2.15e9 floats (8.6 GB) per interleaved buffer -- element indices beyond int32, byte offsets
     beyond 2^33 -- through r2f_render with the headline's stencils; windows at the far end of the buffers against the oracle."""
