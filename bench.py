@@ -726,7 +726,7 @@ def main():
         dev_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=frame.device)
         host_u8 = torch.empty((H, W, 3), dtype=torch.uint8, pin_memory=True)
         copies["d2h_u8_ms"] = best_ms(lambda: host_u8.copy_(dev_u8, non_blocking=True))
-        del dev_f32, dev_u16, dev_u8, host_u16, host_u8
+        del dev_f32, dev_u16, dev_u8, host_u8
         # the drop-in call on a host array, as the GUI's export makes it: upload (pageable NumPy memory), render, uint8 download
         host_np = host_f32.numpy()
         e2e = []
@@ -762,6 +762,19 @@ def main():
             e2e.append((time.perf_counter() - t0) * 1e3)
         copies["process_end_to_end_pinned_result_one_after_the_other_ms"] = min(e2e)
         copies["process_stream_bands"] = bands
+        # ... and the hand-off RAW decoding really makes: LibRaw's uint16 frame (half the upload), converted on the device
+        # (raw_conversion.py:50-52 = r2f_decode_u16) band by band as it arrives; exposure given in stops (no host pass over the frame)
+        host_u16_np = host_u16.numpy().view(np.uint16)
+        for name, b in (("process_u16_end_to_end_pinned_result_ms", bands), ("process_u16_end_to_end_pinned_result_one_after_the_other_ms", 0)):
+            proc.stream_bands = b
+            e2e = []
+            for i in range(6):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = proc.process(host_u16_np, neg, 6, 0.4, cache=False, exposure=0.0, seed=GRAIN_SEED + 40 + i, lens_correction=False, **settings)
+                e2e.append((time.perf_counter() - t0) * 1e3)
+            copies[name] = min(e2e[2:])
+        proc.stream_bands = 0
         # where that call's time goes: one more call with a device synchronisation behind every stage
         # (HipProcessor.profile_stages -- a measuring mode: its total is a little above the un-profiled call's)
         proc.profile_stages = True
@@ -786,9 +799,10 @@ def main():
                           "into a FRESH pageable array (33 ms for 0.3 GB -- upstream's ownership semantics); process_end_to_end_pinned_result: the "
                           "same with result_buffers = 2 (a view of a pinned buffer comes back), which also lets the frame stream through the "
                           "pipeline in process_stream_bands row bands while it arrives -- upload of band k + 2, render of band k + 1, download "
-                          "of band k at the same time; ..._one_after_the_other: the same call with stream_bands = 0")
+                          "of band k at the same time; ..._one_after_the_other: the same call with stream_bands = 0; process_u16_...: the same two calls "
+                          "on LibRaw's uint16 frame (half the upload, exposure in stops, converted on the device)")
         result["host_device_copies"] = copies
-        del host_f32, host_np
+        del host_f32, host_np, host_u16, host_u16_np
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -500,15 +500,22 @@ class HipContext:
                                                  out.data_ptr(), int(out_h), int(out_w), self._stream()))
         return out
 
-    def decode_u16(self, image_u16, factor: float, divisor: float = 65535.0):
+    def decode_u16(self, image_u16, factor: float, divisor: float = 65535.0, out=None):
         """raw_to_linear's last two lines (raw_conversion.py:50-52) on the device: float32(u) / divisor * float32(factor) for a
-        uint16 (H, W, 3 | 4) CUDA tensor (LibRaw's 16-bit output; int16 tensors are read as the same bits) -> float32 (H, W, 3)."""
+        uint16 (H, W, 3 | 4) CUDA tensor (LibRaw's 16-bit output; int16 tensors are read as the same bits) -> float32 (H, W, 3).
+        out: a contiguous float32 (H, W, 3) CUDA tensor to write into (e.g. a band of rows of a larger frame)."""
         torch = self._torch
         if not (image_u16.is_cuda and image_u16.dtype in (torch.uint16, torch.int16) and image_u16.is_contiguous()
                 and image_u16.dim() == 3 and image_u16.shape[2] in (3, 4)):
             raise ValueError("decode_u16 needs a contiguous uint16 (H, W, 3 or 4) CUDA tensor")
         self._same_device(image_u16, "image")
-        out = torch.empty((int(image_u16.shape[0]), int(image_u16.shape[1]), 3), dtype=torch.float32, device=self.device)
+        shape = (int(image_u16.shape[0]), int(image_u16.shape[1]), 3)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == shape):
+            raise ValueError(f"decode_u16: out must be a contiguous float32 CUDA tensor of shape {shape}")
+        else:
+            self._same_device(out, "out")
         self._check(self._lib.r2f_decode_u16(self._h, image_u16.data_ptr(), int(image_u16.shape[0]), int(image_u16.shape[1]),
                                              int(image_u16.shape[2]), float(np.float32(divisor)), float(np.float32(factor)),
                                              out.data_ptr(), self._stream()))

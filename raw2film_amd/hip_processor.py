@@ -366,7 +366,7 @@ class HipProcessor:
             self._torch.cuda.synchronize(self.device)
             t_start = time.perf_counter()
         elif (not cache and self.stream_bands > 1 and self.result_buffers > 0 and dst_texture is None and isinstance(src, np.ndarray)
-              and src.dtype != np.uint16 and not rotation and not chroma_nr and canvas_mode == "No" and not highlight_burn):
+              and not rotation and not chroma_nr and canvas_mode == "No" and not highlight_burn):
             # a large host frame that is uploaded for this one render: streamed through the pipeline in row bands while it arrives
             res = self._process_streamed(
                 src, negative_film, grain_size, grain_sigma,
@@ -561,23 +561,27 @@ class HipProcessor:
         one after the other = 32.5 ms; streamed 23.3 (bench.py host_device_copies, tools/stream_bands_probe.py).
         The FFT stencils' windows are anchored at a call's first row, so a band's outputs agree with the whole-frame render's to the
         FFT form's rounding (an fp32 ulp on a handful of samples, like a row shard's); pointwise configurations agree bit for bit.
+        A uint16 frame (LibRaw's 16-bit output: half the upload) is converted band by band on the device as it arrives.
         Returns None when the frame does not qualify (the caller then takes the one-after-the-other path): a device pre-path
-        (uint16, rotation, chroma NR, scaling), a canvas, a highlight burn (a function of the whole grained frame), a small frame."""
+        (rotation, chroma NR, scaling), a canvas, a highlight burn (a function of the whole grained frame), a small frame."""
         payload = self.extract_image_data_cpu(
             src, load["cam"], load["lens"], load["lens_correction"], load["frame_width"], load["frame_height"], load["rotation"],
             load["zoom"], load["rotate_times"], load["flip"], load["resolution"], load["half_size"], load["cache"], load["chroma_nr"],
             load["max_scale"], load["canvas_mode"], load["canvas_scale"], load["canvas_ratio"], exposure=load["exposure"],
             metadata=load["metadata"], _internal=True)
         host = self._payload_tensor(payload)
+        torch = self._torch
+        is_u16 = host.dtype == torch.int16  # LibRaw's 16-bit output: converted band by band on the device (raw_conversion.py:50-52)
         if (payload.get("warp") or payload.get("resize_to") or payload.get("upscale_to") or payload.get("chroma_nr")
-                or payload.get("u16_factor") is not None or not payload.get("clip_on_device") or payload.get("canvas_resolution")
-                or host.is_cuda or host.dim() != 3 or int(host.shape[2]) != 3 or host.numel() < (1 << 24)):
+                or payload.get("canvas_resolution") or host.is_cuda or host.dim() != 3 or int(host.shape[2]) != 3
+                or host.numel() < (1 << 24)
+                or (payload.get("u16_factor") is None if is_u16 else (payload.get("u16_factor") is not None or not payload.get("clip_on_device")))):
             return None
         H, W = int(host.shape[0]), int(host.shape[1])
         fr = payload.get("final_resolution")
         if fr is not None and (int(fr[0]), int(fr[1])) != (H, W):
             return None
-        torch, ctx = self._torch, self.ctx
+        ctx = self.ctx
         params = self.prepare(negative_film, grain_size, grain_sigma, (W, H), **settings)
         flags = int(params.flags)
         hal, mtf, grain = bool(flags & _lib.F_HALATION), bool(flags & _lib.F_MTF), bool(flags & _lib.F_GRAIN)
@@ -600,6 +604,9 @@ class HipProcessor:
                                         "E": planes(), "D": planes(), "D2": planes() if mtf else None,
                                         "u8": torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)}
         image, E, D, D2, out_u8 = bufs["image"], bufs["E"], bufs["D"], bufs["D2"], bufs["u8"]
+        if is_u16 and bufs.get("u16") is None:
+            bufs["u16"] = torch.empty((H, W, 3), dtype=torch.int16, device=self.device)
+        raw16 = bufs.get("u16") if is_u16 else None
         ring = getattr(self, "_result_ring", None)
         nres = self.result_buffers
         if ring is None or ring[0].shape != out_u8.shape or len(ring) != nres:
@@ -662,11 +669,14 @@ class HipProcessor:
         for k in range(n):
             a0, a1 = band(k)
             with torch.cuda.stream(up):
-                image[a0:a1].copy_(host[a0:a1], non_blocking=True)
+                (raw16 if is_u16 else image)[a0:a1].copy_(host[a0:a1], non_blocking=True)
                 arrived = up.record_event()
             compute.wait_event(arrived)
             rows = image[a0:a1]
-            rows.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, band by band
+            if is_u16:
+                ctx.decode_u16(raw16[a0:a1], payload["u16_factor"], out=rows)
+            else:
+                rows.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, band by band
             if pointwise:  # LUTs only: one fused pass per band, straight to uint8
                 ctx.stage_front(rows, p, 2, in_gy0=a0, out_u8=out_u8, out_gy0=0, y0=a0, y1=a1, H_global=H)
                 send_back(k)

@@ -564,7 +564,17 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
     got2 = banded.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
     d = np.abs(got2.astype(np.int16) - want2.astype(np.int16))
     assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size and not np.array_equal(got2, got)
+    # LibRaw's 16-bit output streams too: converted band by band on the device (raw_conversion.py:50-52) as it arrives
+    raw = rng.integers(0, 65536, (H, W, 3), dtype=np.uint16)
+    for kw, exact in ((dict(grain=0, halation=False, sharpness=False), True), (dict(grain=2), False)):
+        want16 = plain.process(raw, neg, 6, 0.4, cache=False, exposure=0.5, **base, **kw).copy()
+        del calls[:]
+        got16 = banded.process(raw, neg, 6, 0.4, cache=False, exposure=0.5, **base, **kw).copy()
+        assert calls == [True], calls
+        d = np.abs(got16.astype(np.int16) - want16.astype(np.int16))
+        assert (d.max() == 0) if exact else (d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size), (kw, int(d.max()), int(np.count_nonzero(d)))
     # the histogram source is the streamed frame's device copy
+    got2 = banded.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
     np.testing.assert_array_equal(banded.last_output.cpu().numpy(), got2)
     # frames that do not qualify take the other path and give its result
     for kw in (dict(canvas_mode="Proportional", canvas_scale=1.1), dict(highlight_burn=0.5), dict(rotation=3.0), dict(cache=True)):
