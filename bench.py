@@ -729,15 +729,27 @@ def main():
         del dev_f32, dev_u16, dev_u8, host_u8
         # the drop-in call on a host array, as the GUI's export makes it: upload (pageable NumPy memory), render, uint8 download
         host_np = host_f32.numpy()
-        e2e = []
-        for i in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            res = proc.process(host_np, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + i, lens_correction=False, **settings)
-            e2e.append((time.perf_counter() - t0) * 1e3)
-        assert res.dtype == np.uint8 and res.shape == (H, W, 3)
+
+        def timed_calls(src, n, seed0, **kw):
+            ts = []
+            for i in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = proc.process(src, neg, 6, 0.4, cache=False, seed=GRAIN_SEED + seed0 + i, lens_correction=False, **settings, **kw)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            assert r.dtype == np.uint8 and r.shape == (H, W, 3)
+            return ts
+
+        e2e = timed_calls(host_np, 6, 0)
         copies["process_end_to_end_ms"] = min(e2e)
         copies["process_end_to_end_first_ms"] = e2e[0]
+        copies["process_end_to_end_all_ms"] = [round(x, 3) for x in e2e]
+        bands0, proc.stream_bands = proc.stream_bands, 0
+        copies["process_end_to_end_one_after_the_other_ms"] = min(timed_calls(host_np, 3, 50))
+        proc.stream_bands = bands0
+        pageable = np.array(host_np)  # the same frame in ordinary (pageable) host memory, like an array the GUI's decoder hands over
+        copies["process_end_to_end_pageable_source_ms"] = min(timed_calls(pageable, 3, 60))
+        del pageable
         # the same call with the result handed back as a view of a pinned buffer (HipProcessor(result_buffers=2): interactive use)
         # instead of a fresh pageable array like upstream's: the download then runs at the link's rate
         proc.result_buffers = 2
@@ -795,8 +807,12 @@ def main():
                           "(the reference's write_texture, gpu_processor.py:279-305); h2d_u16: pinned uint16 frame -> device + r2f_decode_u16 "
                           "(raw_conversion.py:50-52 on the device); d2h_u8: the uint8 result -> pinned host (read_texture, :1311-1357); events on "
                           "the launch stream, best of 5.  process_end_to_end: wall clock of HipProcessor.process(host ndarray, cache=False) -> "
-                          "uint8 ndarray, best of 3 (first call listed too: it builds tables and pinned staging buffers): upload 21 + render 5 + a download "
-                          "into a FRESH pageable array (33 ms for 0.3 GB -- upstream's ownership semantics); process_end_to_end_pinned_result: the "
+                          "uint8 ndarray of the caller's own, with NO option set (first call listed too: it builds tables and pinned buffers): the frame "
+                          "streams through the pipeline in row bands while it arrives, into one of up to three pinned buffers the processor lends "
+                          "out and gets back when the caller drops the array (a caller that keeps more gets freshly allocated arrays, filled by "
+                          "helper threads band by band: 38 ms); ..._one_after_the_other: stream_bands = 0 (upload 21 + render 5 + a pageable "
+                          "download of 33 ms into a fresh array: upstream's sequence); ..._pageable_source: the "
+                          "source array in ordinary host memory instead of pinned memory; process_end_to_end_pinned_result: the "
                           "same with result_buffers = 2 (a view of a pinned buffer comes back), which also lets the frame stream through the "
                           "pipeline in process_stream_bands row bands while it arrives -- upload of band k + 2, render of band k + 1, download "
                           "of band k at the same time; ..._one_after_the_other: the same call with stream_bands = 0; process_u16_...: the same two calls "

@@ -84,6 +84,11 @@ class HipProcessor:
         self.last_output = None  # device uint8 (H, W, 3) of the last process()/process_preloaded(): histogram source
 
     def close(self):
+        pool = getattr(self, "_copy_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self._copy_pool = None
+        self._stream_bufs = None
         self._texture = None  # the frame kept on the device for re-renders
         self._texture_src = None
         self.image_param_dict = None
@@ -365,7 +370,7 @@ class HipProcessor:
 
             self._torch.cuda.synchronize(self.device)
             t_start = time.perf_counter()
-        elif (not cache and self.stream_bands > 1 and self.result_buffers > 0 and dst_texture is None and isinstance(src, np.ndarray)
+        elif (not cache and self.stream_bands > 1 and dst_texture is None and isinstance(src, np.ndarray) and src.size >= (1 << 24)
               and not rotation and not chroma_nr and canvas_mode == "No" and not highlight_burn):
             # a large host frame that is uploaded for this one render: streamed through the pipeline in row bands while it arrives
             res = self._process_streamed(
@@ -459,11 +464,14 @@ class HipProcessor:
             import time
 
             t0 = time.perf_counter()
-        cpu_payload = self.extract_image_data_cpu(
-            src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
-            half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
-            _internal=True,
-        )
+        cpu_payload = getattr(self, "_stash_payload", None)  # (made a moment ago by _process_streamed for a frame that did not qualify)
+        self._stash_payload = None
+        if cpu_payload is None:
+            cpu_payload = self.extract_image_data_cpu(
+                src, cam, lens, lens_correction, frame_width, frame_height, rotation, zoom, rotate_times, flip, resolution,
+                half_size, cache, chroma_nr, max_scale, canvas_mode, canvas_scale, canvas_ratio, exposure=exposure, metadata=metadata,
+                _internal=True,
+            )
         if prof:
             t1 = time.perf_counter()
         self.prepare_gpu_textures(cpu_payload)
@@ -551,7 +559,7 @@ class HipProcessor:
         return None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
 
     def _process_streamed(self, src, negative_film, grain_size, grain_sigma, *, load, **settings):
-        """process() of a large host frame that is uploaded for this one render (cache=False), with pinned result buffers: the
+        """process() of a large host frame that is uploaded for this one render (cache=False): the
         frame goes through the pipeline in `stream_bands` row bands WHILE IT ARRIVES -- band k is clamped and taken through S0 + S1
         as soon as it is on the device, the halation of band k - 1 follows (its stencil reads the first rows of band k), then the
         MTF and the tail of band k - 2, whose uint8 rows start their way back while later bands are still coming up: the stage
@@ -569,6 +577,7 @@ class HipProcessor:
             load["zoom"], load["rotate_times"], load["flip"], load["resolution"], load["half_size"], load["cache"], load["chroma_nr"],
             load["max_scale"], load["canvas_mode"], load["canvas_scale"], load["canvas_ratio"], exposure=load["exposure"],
             metadata=load["metadata"], _internal=True)
+        self._stash_payload = payload  # (should the frame not qualify, load_image_texture takes the payload from here)
         host = self._payload_tensor(payload)
         torch = self._torch
         is_u16 = host.dtype == torch.int16  # LibRaw's 16-bit output: converted band by band on the device (raw_conversion.py:50-52)
@@ -594,6 +603,7 @@ class HipProcessor:
             n -= 1
         if n < 2 or W % 4:
             return None
+        self._stash_payload = None
         bounds = [H * i // n for i in range(n + 1)]
         bufs = getattr(self, "_stream_bufs", None)
         if bufs is None or bufs["shape"] != (H, W) or bufs["mtf"] != mtf:
@@ -607,13 +617,47 @@ class HipProcessor:
         if is_u16 and bufs.get("u16") is None:
             bufs["u16"] = torch.empty((H, W, 3), dtype=torch.int16, device=self.device)
         raw16 = bufs.get("u16") if is_u16 else None
-        ring = getattr(self, "_result_ring", None)
         nres = self.result_buffers
-        if ring is None or ring[0].shape != out_u8.shape or len(ring) != nres:
-            ring = self._result_ring = [torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(nres)]
-            self._result_turn = 0
-        result = ring[self._result_turn % nres]
-        self._result_turn += 1
+        fresh, copies = None, []
+        if nres > 0:  # the caller takes views of pinned buffers in turn (_download)
+            ring = getattr(self, "_result_ring", None)
+            if ring is None or ring[0].shape != out_u8.shape or len(ring) != nres:
+                ring = self._result_ring = [torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(nres)]
+                self._result_turn = 0
+            result = ring[self._result_turn % nres]
+            self._result_turn += 1
+        elif (leased := self._lease_result(tuple(out_u8.shape))) is not None:
+            # upstream's ownership semantics -- an array of the caller's own per call -- without a fresh allocation: the array is a
+            # view of one of up to three pinned buffers this object lends out, and the buffer comes back when the caller's last
+            # reference to the array (or to any view of it) is gone.  A caller that drops a result before asking for the next but
+            # one -- an export loop, a preview widget -- never meets a fresh page
+            result = leased
+        else:
+            # ... and for a caller that holds on to more results than that: a FRESH array.  Its pages are touched for the first time by whoever writes them
+            # (~30 ms for 0.3 GB) -- here by four helper threads that fault them in while the first bands are still on their way up,
+            # then copy each band out of a pinned staging buffer as soon as it is back, instead of by one pageable download behind
+            # the render
+            stage = bufs.get("stage")
+            if stage is None:
+                stage = bufs["stage"] = torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True)
+            result = stage
+            fresh = np.empty((H, W, 3), dtype=np.uint8)
+            if getattr(self, "_copy_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="r2f-result")
+            stage_np = stage.numpy()
+            flat = fresh.reshape(-1)
+
+            def touch(i0, i1):
+                flat[i0:i1:4096] = 0  # one byte per page (NumPy releases the GIL for the strided fill)
+
+            q = -(-flat.size // 4)
+            copies += [self._copy_pool.submit(touch, i, min(i + q, flat.size)) for i in range(0, flat.size, q)]
+
+            def copy_out(back, y0, y1):
+                back.synchronize()  # (releases the GIL)
+                np.copyto(fresh[y0:y1], stage_np[y0:y1])
         if getattr(self, "_up_stream", None) is None:
             self._up_stream = torch.cuda.Stream(device=self.device)
             self._down_stream = torch.cuda.Stream(device=self.device)
@@ -636,6 +680,8 @@ class HipProcessor:
             with torch.cuda.stream(down):
                 down.wait_event(done)
                 result[y0:y1].copy_(out_u8[y0:y1], non_blocking=True)
+                if fresh is not None:
+                    copies.append(self._copy_pool.submit(copy_out, down.record_event(), y0, y1))
 
         def advance():
             # every stage runs a band as soon as the rows it reads exist: a stencil stage reads into the band after its own
@@ -687,11 +733,35 @@ class HipProcessor:
             state["front"] = k + 1
             advance()
         down.synchronize()
+        for c in copies:
+            c.result()
         self._texture = (image, None, {k: v for k, v in payload.items() if k != "image_array"})
         self.image_param_dict = None
         self._texture_src = None
         self.last_output = out_u8
-        return result.numpy()
+        if fresh is not None:
+            return fresh
+        arr = result.numpy()
+        if nres <= 0:  # a lent buffer: back into the pool when the caller lets go of the array
+            import weakref
+
+            weakref.finalize(arr, self._lease_pool.append, result)
+        return arr
+
+    def _lease_result(self, shape):
+        """A pinned uint8 buffer of `shape` to lend to the caller of process() as its result (see _process_streamed), or None when
+        three are out already."""
+        pool = self.__dict__.setdefault("_lease_pool", [])
+        for i, t in enumerate(pool):
+            if tuple(t.shape) == shape:
+                return pool.pop(i)
+        del pool[:]  # (buffers of another frame size: let them go)
+        if self.__dict__.get("_lease_shape") != shape:
+            self._lease_shape, self._lease_count = shape, 0
+        if self._lease_count >= 3:
+            return None
+        self._lease_count += 1
+        return self._torch.empty(shape, dtype=self._torch.uint8, pin_memory=True)
 
     def _download(self, out_u8):
         """The uint8 result as a NumPy array.  Default: a fresh array per call, like upstream.  With result_buffers = n > 0 the

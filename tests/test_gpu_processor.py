@@ -564,6 +564,30 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
     got2 = banded.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
     d = np.abs(got2.astype(np.int16) - want2.astype(np.int16))
     assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size and not np.array_equal(got2, got)
+    # without pinned result buffers the caller gets a FRESH array per call (upstream's ownership): the same frame, other memory
+    fresh = HipProcessor(device=0)
+    assert fresh.result_buffers == 0 and fresh.stream_bands == 16
+    f1 = fresh.process(img, neg, 6, 0.4, cache=False, **base, grain=2)
+    f2 = fresh.process(img, neg, 6, 0.4, cache=False, **base, grain=2)
+    np.testing.assert_array_equal(f1, got2)
+    np.testing.assert_array_equal(f2, got2)
+    assert f1.ctypes.data != f2.ctypes.data and f1.flags.writeable and f2.flags.writeable
+    # (the arrays are views of pinned buffers the processor lends out -- up to three; a buffer comes back when the caller's last
+    # reference to its array is gone, views included, and a caller that keeps more than three results gets freshly allocated arrays)
+    view = f1[10:20]
+    addr1 = f1.ctypes.data
+    del f1
+    f3 = fresh.process(img, neg, 6, 0.4, cache=False, **base, grain=2)
+    assert f3.ctypes.data not in (addr1, f2.ctypes.data)  # f1's buffer is still held through `view`
+    np.testing.assert_array_equal(view, got2[10:20])
+    del view
+    f4 = fresh.process(img, neg, 6, 0.4, cache=False, **base, grain=2)
+    assert f4.ctypes.data == addr1  # ... and now it has come back
+    f5 = fresh.process(img, neg, 6, 0.4, cache=False, **base, grain=2)  # f2, f3, f4 are out: a freshly allocated array
+    assert f5.flags.owndata and f5.ctypes.data not in (f2.ctypes.data, f3.ctypes.data, f4.ctypes.data)
+    for f in (f2, f3, f4, f5):
+        np.testing.assert_array_equal(f, got2)
+    fresh.close()
     # LibRaw's 16-bit output streams too: converted band by band on the device (raw_conversion.py:50-52) as it arrives
     raw = rng.integers(0, 65536, (H, W, 3), dtype=np.uint16)
     for kw, exact in ((dict(grain=0, halation=False, sharpness=False), True), (dict(grain=2), False)):
