@@ -712,26 +712,35 @@ class HipProcessor:
                 if not moved:
                     return
 
-        for k in range(n):
-            a0, a1 = band(k)
-            with torch.cuda.stream(up):
-                (raw16 if is_u16 else image)[a0:a1].copy_(host[a0:a1], non_blocking=True)
-                arrived = up.record_event()
-            compute.wait_event(arrived)
-            rows = image[a0:a1]
-            if is_u16:
-                ctx.decode_u16(raw16[a0:a1], payload["u16_factor"], out=rows)
-            else:
-                rows.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, band by band
-            if pointwise:  # LUTs only: one fused pass per band, straight to uint8
-                ctx.stage_front(rows, p, 2, in_gy0=a0, out_u8=out_u8, out_gy0=0, y0=a0, y1=a1, H_global=H)
-                send_back(k)
-            elif hal:
-                state["ident"] = ctx.stage_front_split(rows, p, E, D, in_gy0=a0, y0=a0, y1=a1, H_global=H, track_range=True)
-            else:
-                ctx.stage_front(rows, p, 1, in_gy0=a0, dst=D, dst_gy0=0, y0=a0, y1=a1, H_global=H)
-            state["front"] = k + 1
-            advance()
+        try:
+            for k in range(n):
+                a0, a1 = band(k)
+                with torch.cuda.stream(up):
+                    (raw16 if is_u16 else image)[a0:a1].copy_(host[a0:a1], non_blocking=True)
+                    arrived = up.record_event()
+                compute.wait_event(arrived)
+                rows = image[a0:a1]
+                if is_u16:
+                    ctx.decode_u16(raw16[a0:a1], payload["u16_factor"], out=rows)
+                else:
+                    rows.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, band by band
+                if pointwise:  # LUTs only: one fused pass per band, straight to uint8
+                    ctx.stage_front(rows, p, 2, in_gy0=a0, out_u8=out_u8, out_gy0=0, y0=a0, y1=a1, H_global=H)
+                    send_back(k)
+                elif hal:
+                    state["ident"] = ctx.stage_front_split(rows, p, E, D, in_gy0=a0, y0=a0, y1=a1, H_global=H, track_range=True)
+                else:
+                    ctx.stage_front(rows, p, 1, in_gy0=a0, dst=D, dst_gy0=0, y0=a0, y1=a1, H_global=H)
+                state["front"] = k + 1
+                advance()
+        except BaseException:
+            # a stage call refused (or the caller interrupted): let the queued work drain, hand a lent buffer back, pass it on
+            torch.cuda.synchronize(self.device)
+            for c in copies:
+                c.cancel()
+            if nres <= 0 and fresh is None:
+                self._lease_pool.append(result)
+            raise
         down.synchronize()
         for c in copies:
             c.result()
