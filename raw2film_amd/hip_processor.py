@@ -559,8 +559,8 @@ class HipProcessor:
         return None if out_u8 is None else self._download(out_u8)  # DEVICE -> HOST, the reference's read_texture/map_sync
 
     def _process_streamed(self, src, negative_film, grain_size, grain_sigma, *, load, **settings):
-        """process() of a large host frame that is uploaded for this one render (cache=False): the
-        frame goes through the pipeline in `stream_bands` row bands WHILE IT ARRIVES -- band k is clamped and taken through S0 + S1
+        """process() of a large host frame that is uploaded for this one render (cache=False: the GUI's export calls,
+        gui.py:2374,2458,2479): the frame goes through the pipeline in `stream_bands` row bands WHILE IT ARRIVES -- band k is clamped and taken through S0 + S1
         as soon as it is on the device, the halation of band k - 1 follows (its stencil reads the first rows of band k), then the
         MTF and the tail of band k - 2, whose uint8 rows start their way back while later bands are still coming up: the stage
         entry points are row-range calls (the ones a row shard makes: grain hashed at global coordinates, reflection at the frame
