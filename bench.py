@@ -810,8 +810,8 @@ def main():
                           "uint8 ndarray of the caller's own, with NO option set (first call listed too: it builds tables and pinned buffers): the frame "
                           "streams through the pipeline in row bands while it arrives, into one of up to three pinned buffers the processor lends "
                           "out and gets back when the caller drops the array (a caller that keeps more gets freshly allocated arrays, filled by "
-                          "helper threads band by band: 38 ms); ..._one_after_the_other: stream_bands = 0 (upload 21 + render 5 + a pageable "
-                          "download of 33 ms into a fresh array: upstream's sequence); ..._pageable_source: the "
+                          "helper threads band by band: 38 ms); ..._one_after_the_other: stream_bands = 0 (upload 21 + render 5 + download 5; until "
+                          "round 5 the download was a pageable one into a fresh array, 33 ms: upstream's sequence); ..._pageable_source: the "
                           "source array in ordinary host memory instead of pinned memory; process_end_to_end_pinned_result: the "
                           "same with result_buffers = 2 (a view of a pinned buffer comes back), which also lets the frame stream through the "
                           "pipeline in process_stream_bands row bands while it arrives -- upload of band k + 2, render of band k + 1, download "

@@ -499,10 +499,12 @@ def test_a_large_host_frame_is_clamped_on_its_way_up_in_chunks():
     img[H // 2 + 7, 33] = (-1e-3, 0.5, -5.0)
     img[H - 1, W - 1] = (80000.0, 65504.0, -0.0)
     proc = HipProcessor(device=0)
+    proc.stream_bands = 0  # (the path a frame takes that does not stream through the pipeline: cache=True, a canvas, a burn ...)
     kw = dict(print_film=prt, lens_correction=False, seed=2, grain=0, halation=False, sharpness=False)
     want = proc.process(np.clip(img, 0, 65504), neg, 6, 0.4, cache=False, **kw)
     got = proc.process(img, neg, 6, 0.4, cache=False, **kw)
     np.testing.assert_array_equal(got, want)
+    assert got.ctypes.data != want.ctypes.data  # (arrays of the caller's own: views of two of the pinned buffers the processor lends)
     pinned = torch.from_numpy(img).pin_memory().numpy()
     np.testing.assert_array_equal(proc.process(pinned, neg, 6, 0.4, cache=False, **kw), want)
     img[100:200] *= 0.5  # the same buffer, other content
