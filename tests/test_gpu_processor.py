@@ -615,6 +615,49 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
     banded.close()
 
 
+def test_a_lent_result_is_never_written_while_anybody_holds_it():
+    """process() without result_buffers hands back the caller's own array -- since round 6 a view of one of up to three pinned
+    buffers the processor lends out and takes back when the array and every view of it are gone (hip_processor._lease_result).
+    A random walk over what a caller may do with results -- keep them, keep a slice only, drop them, keep more than three --
+    while frames keep coming: whatever is still held, array or slice, keeps the content it came with."""
+    import gc
+
+    from raw2film_amd import HipProcessor, filmstock
+
+    stocks = filmstock.builtin_stocks()
+    neg, prt = stocks["Kodak Portra 400"], stocks["Kodak 2383"]
+    rng = np.random.default_rng(21)
+    H, W = 1000, 1500  # 4.5 M samples: above the size from which downloads are lent
+    base = rng.uniform(0.0, 1.0, (H, W, 3)).astype(np.float32)
+    proc = HipProcessor(device=0)
+    kw = dict(print_film=prt, lens_correction=False, seed=2, grain=0, halation=False, sharpness=False)
+    held = []  # (what the caller kept, a private copy of what it must still hold)
+    leases = []
+    inner = proc._lease_result
+    proc._lease_result = lambda shape: (leases.append(inner(shape)), leases[-1])[1]
+    for i in range(60):
+        out = proc.process(base * np.float32(0.2 + 0.8 * rng.random()), neg, 6, 0.4, cache=False, **kw)
+        what = int(rng.integers(0, 4))
+        if what == 0:
+            held.append((out, out.copy()))
+        elif what == 1:
+            a = int(rng.integers(0, H - 50))
+            held.append((out[a:a + 50, ::7], out[a:a + 50, ::7].copy()))
+        del out
+        while held and rng.integers(0, 3) == 0:
+            held.pop(int(rng.integers(0, len(held))))
+        gc.collect()
+        for kept, want in held:
+            np.testing.assert_array_equal(kept, want)
+    lent, fresh = sum(t is not None for t in leases), sum(t is None for t in leases)
+    assert len(leases) == 60 and lent > 20 and fresh > 0, (lent, fresh)  # lent buffers and, with more than three held, fresh arrays
+    assert len({t.data_ptr() for t in leases if t is not None}) <= 3
+    del leases
+    proc.close()
+    for kept, want in held:  # (a closed processor does not take its buffers from under the caller)
+        np.testing.assert_array_equal(kept, want)
+
+
 def test_pinned_result_buffers_return_views_in_turn():
     from raw2film_amd import HipProcessor, filmstock
 
