@@ -602,6 +602,18 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
     # the histogram source is the streamed frame's device copy
     got2 = banded.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
     np.testing.assert_array_equal(banded.last_output.cpu().numpy(), got2)
+    # host-side geometry (index arithmetic ahead of the upload: aspect crop, zoom, quarter turns, flip) streams like any other frame
+    streamed = 0
+    for kw in (dict(zoom=1.25), dict(rotate_times=1, frame_width=36, frame_height=36), dict(flip=True), dict(frame_width=36, frame_height=24),
+               dict(rotate_times=2, zoom=1.1)):
+        args = dict(base, cache=False, grain=2, halation=False, sharpness=False)
+        args.update(kw)
+        del calls[:]
+        got4 = banded.process(img, neg, 6, 0.4, **args)
+        want4 = plain.process(img, neg, 6, 0.4, **args)
+        np.testing.assert_array_equal(got4, want4, err_msg=str(kw))
+        streamed += calls == [True]
+    assert streamed >= 2, streamed  # (a crop below 16.7 M samples or with a width that is no multiple of 4 takes the other path)
     # frames that do not qualify take the other path and give its result
     for kw in (dict(canvas_mode="Proportional", canvas_scale=1.1), dict(highlight_burn=0.5), dict(rotation=3.0), dict(cache=True)):
         del calls[:]
