@@ -586,25 +586,32 @@ class HipProcessor:
                 or payload.get("canvas_resolution") or host.is_cuda or host.dim() != 3 or int(host.shape[2]) != 3
                 or host.numel() < (1 << 24)
                 or (payload.get("u16_factor") is None if is_u16 else (payload.get("u16_factor") is not None or not payload.get("clip_on_device")))):
+            self.stream_rejected = ("a device pre-path, a canvas, or a frame below 16.7 M samples: " + ", ".join(
+                f"{k} = {payload.get(k)!r}" for k in ("warp", "resize_to", "upscale_to", "chroma_nr", "canvas_resolution", "u16_factor",
+                                                      "clip_on_device")) + f", frame {tuple(host.shape)} {host.dtype}")
             return None
         H, W = int(host.shape[0]), int(host.shape[1])
         fr = payload.get("final_resolution")
         if fr is not None and (int(fr[0]), int(fr[1])) != (H, W):
+            self.stream_rejected = f"the finished frame is scaled to {fr}"
             return None
         ctx = self.ctx
         params = self.prepare(negative_film, grain_size, grain_sigma, (W, H), **settings)
         flags = int(params.flags)
         hal, mtf, grain = bool(flags & _lib.F_HALATION), bool(flags & _lib.F_MTF), bool(flags & _lib.F_GRAIN)
         if flags & _lib.F_BURN:
+            self.stream_rejected = "highlight burn (a function of the whole grained frame)"
             return None
         ha = self._halation_reach if hal else (0, 0)
         ma = self._mtf_reach if mtf else (0, 0)
         n = min(int(self.stream_bands), max(H // 512, 2))
         while n > 1 and H // n < max(2 * max(ha + ma) + 2, 64):  # a band holds its neighbours' halo (and is worth a launch)
             n -= 1
-        if n < 2 or W % 4:
+        if n < 2:
+            self.stream_rejected = f"{n} band(s) of {H} rows above the stencils' reach {ha} + {ma}"
             return None
         self._stash_payload = None
+        self.stream_rejected = None
         bounds = [H * i // n for i in range(n + 1)]
         # the last bands are the ones nothing hides (their stencil stages, tail and download run behind the last byte of the upload):
         # the final `stream_taper` of them are halved while they stay above the stencils' reach (100 MP: 23.26 -> 22.73 ms with 2)

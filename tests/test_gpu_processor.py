@@ -613,7 +613,7 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
         want4 = plain.process(img, neg, 6, 0.4, **args)
         np.testing.assert_array_equal(got4, want4, err_msg=str(kw))
         streamed += calls == [True]
-    assert streamed >= 2, streamed  # (a crop below 16.7 M samples or with a width that is no multiple of 4 takes the other path)
+    assert streamed >= 2, streamed  # (a crop below 16.7 M samples takes the other path)
     # frames that do not qualify take the other path and give its result
     for kw in (dict(canvas_mode="Proportional", canvas_scale=1.1), dict(highlight_burn=0.5), dict(rotation=3.0), dict(cache=True)):
         del calls[:]
