@@ -6,6 +6,10 @@
 //   mode 3: random texels of a table held in LDS (ds_read_b128)
 //   mode 4: random 8-byte gathers (global)
 //   mode 5: mode 0 with nontemporal loads (global_load_dwordx4 ... nt)
+//   mode 6: random 4-byte gathers (global_load_dword): is the rate per LANE-ADDRESS or per byte?
+//   mode 7: a texel as three 4-byte gathers from three planes of `texels` floats (what a planar LUT would cost: counted as ONE
+//           gather per three loads, to compare with mode 0 directly)
+//   mode 8: LDS 4-byte gathers (ds_read_b32)
 // Round 4: the tetrahedral 3-D LUT's access pattern itself, texel-major against a CELL-MAJOR copy:
 //   cell_kernel<false>: a pixel = 4 corners of one cell of an n^3 texel table (c000, c100, c110, c111: 4 different 128-byte lines)
 //   cell_kernel<true>:  a pixel = 4 of the 8 corners of one cell of a cell-major copy (8 x 16 B = ONE 128-byte line per cell;
@@ -28,7 +32,7 @@ template <int MODE>
 __global__ __launch_bounds__(512) void gather_kernel(const float4* __restrict__ table, unsigned texels, int iters, float* out) {
     extern __shared__ float4 lds[];
     const int tid = threadIdx.x;
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 8) {
         for (unsigned i = tid; i < texels; i += blockDim.x) lds[i] = table[i];
         __syncthreads();
     }
@@ -46,6 +50,13 @@ __global__ __launch_bounds__(512) void gather_kernel(const float4* __restrict__ 
             else if (MODE == 4) {
                 const float2 t = reinterpret_cast<const float2*>(table)[idx * 2];
                 v[k] = make_float4(t.x, t.y, 0.f, 0.f);
+            } else if (MODE == 6) {
+                v[k] = make_float4(reinterpret_cast<const float*>(table)[idx], 0.f, 0.f, 0.f);
+            } else if (MODE == 7) {
+                const float* p = reinterpret_cast<const float*>(table);
+                v[k] = make_float4(p[idx], p[texels + idx], p[2 * texels + idx], 0.f);
+            } else if (MODE == 8) {
+                v[k] = make_float4(reinterpret_cast<const float*>(lds)[idx], 0.f, 0.f, 0.f);
             } else if (MODE == 5) {
                 typedef float f4v __attribute__((ext_vector_type(4)));
                 const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(table) + idx);
@@ -108,7 +119,7 @@ void run_cells(const char* name, const float4* table, int n, unsigned hot, float
 template <int MODE>
 void run(const char* name, const float4* table, unsigned texels, float* out) {
     const int iters = 512, blocks = 256 * 4, threads = 512;
-    const size_t lds = MODE == 3 ? texels * sizeof(float4) : 0;
+    const size_t lds = (MODE == 3 || MODE == 8) ? texels * sizeof(float4) : 0;
     hipFuncSetAttribute(reinterpret_cast<const void*>(gather_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -140,6 +151,9 @@ int main() {
         run<2>("global 16 B, one texel per wave (broadcast)", d, texels, out);
         run<4>("global 8 B, random per lane", d, texels, out);
         run<5>("global 16 B, random, nontemporal (nt)", d, texels, out);
+        run<6>("global 4 B, random per lane", d, texels, out);
+        run<7>("global 3 x 4 B from three planes = one texel", d, texels, out);
+        if (texels * 16 <= 128 * 1024) run<8>("LDS 4 B (ds_read_b32), random per lane", d, texels, out);
         if (texels * 16 <= 128 * 1024) run<3>("LDS 16 B (ds_read_b128), random texel per lane", d, texels, out);
         hipFree(d);
     }
