@@ -727,12 +727,41 @@ class HipProcessor:
                 if not moved:
                     return
 
+        landing = raw16 if is_u16 else image
+
+        def send_up(k):
+            a0, a1 = band(k)
+            with torch.cuda.stream(up):
+                landing[a0:a1].copy_(host[a0:a1], non_blocking=True)
+                return up.record_event()
+
+        # A copy out of ordinary (pageable) host memory -- any NumPy array that was not made from pinned memory -- returns only when
+        # its bytes have left the host: issued from this thread, every band's copy would hold back the launches of the band before
+        # it (measured: 35.5 ms against 32.7 one after the other).  So such a source is sent up by a helper thread of its own, band
+        # by band, and this thread launches a band when its arrival event comes through the queue.
+        arrivals, uploader = None, None
+        if not host.is_pinned():
+            import queue
+            import threading
+
+            arrivals = queue.Queue()
+
+            def upload_all():
+                try:
+                    with torch.cuda.device(self.device):
+                        for k in range(n):
+                            arrivals.put(send_up(k))
+                except BaseException as e:  # noqa: BLE001 -- handed to the thread that waits for the bands
+                    arrivals.put(e)
+
+            uploader = threading.Thread(target=upload_all, name="r2f-upload", daemon=True)
+            uploader.start()
         try:
             for k in range(n):
                 a0, a1 = band(k)
-                with torch.cuda.stream(up):
-                    (raw16 if is_u16 else image)[a0:a1].copy_(host[a0:a1], non_blocking=True)
-                    arrived = up.record_event()
+                arrived = send_up(k) if arrivals is None else arrivals.get()
+                if isinstance(arrived, BaseException):
+                    raise arrived
                 compute.wait_event(arrived)
                 rows = image[a0:a1]
                 if is_u16:
@@ -750,12 +779,16 @@ class HipProcessor:
                 advance()
         except BaseException:
             # a stage call refused (or the caller interrupted): let the queued work drain, hand a lent buffer back, pass it on
+            if uploader is not None:
+                uploader.join()
             torch.cuda.synchronize(self.device)
             for c in copies:
                 c.cancel()
             if nres <= 0 and fresh is None:
                 self._lease_pool.append(result)
             raise
+        if uploader is not None:
+            uploader.join()
         down.synchronize()
         for c in copies:
             c.result()
