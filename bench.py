@@ -670,6 +670,8 @@ def main():
         # ... and as LibRaw's 16-bit output with the conversion of raw_conversion.py:50-52 on the device (r2f_decode_u16)
         host16 = (frame.clamp(0, 1) * 65535).to(torch.int32).to(torch.int16).cpu().pin_memory()  # the 16 bits of a uint16 frame
         payload16 = dict(payload, image_array=host16, u16_factor=1.0)
+        # ... and the frame as an ordinary (pageable) NumPy array, which is what a decoder hands over
+        payload3p = dict(payload, image_array=host3.numpy().copy())
         kw = dict(settings, seed=GRAIN_SEED, matrix=REC709_TO_XYZ)
         legs = {}
         for name, pay, execute, collect in (
@@ -678,7 +680,8 @@ def main():
                 ("serial", payload, lambda t, pl: int(proc.process_preloaded(pl, neg, 6, 0.4, **kw)[0, 0, 0]), None),
                 ("overlapped", payload, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0])),
                 ("overlapped_rgb", payload3, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0])),
-                ("overlapped_u16", payload16, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0]))):
+                ("overlapped_u16", payload16, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0])),
+                ("overlapped_rgb_pageable", payload3p, lambda t, pl: proc.submit_preloaded(pl, neg, 6, 0.4, **kw), lambda t, h: int(h.result()[0, 0, 0]))):
             BatchSharder(0, 1).run([0, 1], lambda t: pay, execute, collect=collect)  # warm-up (pinned pools, streams)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -688,11 +691,14 @@ def main():
         result["pcie_inclusive"] = {
             "value": legs["overlapped"], "unit": "MP/s", "frames": n_e2e, "serial": legs["serial"],
             "without_alpha_plane": legs["overlapped_rgb"], "uint16_payload": legs["overlapped_u16"],
+            "without_alpha_plane_pageable_source": legs["overlapped_rgb_pageable"],
             "note": "BatchSharder.run over the two-phase API: pinned fp32 HWC4 frame -> device, render, uint8 result -> pinned host "
                     "memory. value: one frame in flight while the next is submitted (upload, render and download on three streams); "
                     "serial: process_preloaded frame after frame.  Upload-bound (384 MB per 24 MP frame); without_alpha_plane: the same "
                     "with the (H, W, 3) payload of HipProcessor(payload_alpha=False), 288 MB per frame; uint16_payload: the decoded frame handed over as LibRaw's 16-bit output "
-                    "(144 MB per frame), converted by r2f_decode_u16 on the device.  Not part of `value`"}
+                    "(144 MB per frame), converted by r2f_decode_u16 on the device; without_alpha_plane_pageable_source: the (H, W, 3) payload as an "
+                    "ordinary NumPy array instead of pinned memory (its copy blocks the submitting thread, so nothing of the host's "
+                    "work overlaps it; until round 6 submit_preloaded pinned such a frame first: 373 MP/s).  Not part of `value`"}
 
     if not batch and world == 1 and not args.no_pcie:
         # host <-> device copies reported separately, never in `value`.  What the reference pays at the same boundary:

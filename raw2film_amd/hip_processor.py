@@ -871,8 +871,10 @@ class HipProcessor:
             self._up_stream = torch.cuda.Stream(device=self.device)
             self._down_stream = torch.cuda.Stream(device=self.device)
         image = self._payload_tensor(cpu_payload)
-        if not image.is_cuda and not image.is_pinned():
-            image = image.pin_memory()  # (a pageable source would make the "asynchronous" copy a synchronous one)
+        # (A pageable source -- an ordinary NumPy array -- makes the "asynchronous" copy below a synchronous one: this thread waits
+        # for the frame's bytes to leave the host.  That is fine: the frame before is already queued on the device and its render
+        # and download run meanwhile.  Pinning the array first, which this method did until round 6, is a fresh pinned allocation
+        # and a single-threaded host copy per frame: 64 instead of 6.3 ms per 24 MP frame, tools/batch_pageable_probe.py.)
         compute = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self._up_stream):
             dev = image.to(self.device, non_blocking=True)
