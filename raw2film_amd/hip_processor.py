@@ -35,13 +35,20 @@ REC709_TO_XYZ = np.array(  # data.py:128-135
 class PendingFrame:
     """A frame submitted with HipProcessor.submit_preloaded: `.result()` waits for its download and returns the uint8 array."""
 
-    def __init__(self, host, done):
-        self._host, self._done = host, done
+    def __init__(self, host, done, array=None):
+        self._host, self._done, self._array = host, done, array
+
+    @classmethod
+    def finished(cls, array):
+        """A frame that is back already (a payload that streamed through the pipeline: submit_preloaded)."""
+        return cls(None, None, array)
 
     def ready(self) -> bool:
-        return self._done.query()
+        return self._array is not None or self._done.query()
 
     def result(self) -> np.ndarray:
+        if self._array is not None:
+            return self._array
         self._done.synchronize()
         return self._host.numpy()
 
@@ -553,6 +560,10 @@ class HipProcessor:
         final_scaling: "gpu" -- like GpuProcessor, the canvas keeps its size and only a `max_scale` render is scaled back up;
         "cpu" -- like CpuProcessor.process (cpu_processor.py:411-412), the finished frame, canvas included, is scaled to the
         requested resolution (INTER_AREA down, LANCZOS4 up).  dst_texture / histogram_texture: see process()."""
+        if dst_texture is None and histogram_texture is None and self.stream_bands > 1:
+            res = self._stream_payload(cpu_payload, negative_film, grain_size, grain_sigma, final_scaling, **settings)
+            if res is not None:  # a large frame without a device pre-path: through the pipeline in row bands while it arrives
+                return res
         self.prepare_gpu_textures(cpu_payload)
         image, layout, _ = self._texture
         out_u8 = self._render_prepared(image, layout, cpu_payload, negative_film, grain_size, grain_sigma, dst_texture,
@@ -572,26 +583,35 @@ class HipProcessor:
         FFT form's rounding (an fp32 ulp on a handful of samples, like a row shard's); pointwise configurations agree bit for bit.
         A uint16 frame (LibRaw's 16-bit output: half the upload) is converted band by band on the device as it arrives.
         Returns None when the frame does not qualify (the caller then takes the one-after-the-other path): a device pre-path
-        (rotation, chroma NR, scaling), a canvas, a highlight burn (a function of the whole grained frame), a small frame."""
+        (rotation, chroma NR, scaling), a canvas, a highlight burn (a function of the whole grained frame), a small frame.
+        The two-phase API's device phase (process_preloaded, submit_preloaded: batch export) streams its payload the same way."""
         payload = self.extract_image_data_cpu(
             src, load["cam"], load["lens"], load["lens_correction"], load["frame_width"], load["frame_height"], load["rotation"],
             load["zoom"], load["rotate_times"], load["flip"], load["resolution"], load["half_size"], load["cache"], load["chroma_nr"],
             load["max_scale"], load["canvas_mode"], load["canvas_scale"], load["canvas_ratio"], exposure=load["exposure"],
             metadata=load["metadata"], _internal=True)
-        self._stash_payload = payload  # (should the frame not qualify, load_image_texture takes the payload from here)
+        res = self._stream_payload(payload, negative_film, grain_size, grain_sigma, "cpu", **settings)
+        # (should the frame not qualify, load_image_texture takes the payload from here)
+        self._stash_payload = payload if res is None else None
+        return res
+
+    def _stream_payload(self, payload, negative_film, grain_size, grain_sigma, final_scaling="cpu", **settings):
+        """A phase-1 payload (extract_image_data_cpu) through the pipeline in row bands while it arrives: see _process_streamed.
+        Returns the uint8 frame, or None (with `stream_rejected` saying why) when the payload does not qualify."""
         host = self._payload_tensor(payload)
         torch = self._torch
         is_u16 = host.dtype == torch.int16  # LibRaw's 16-bit output: converted band by band on the device (raw_conversion.py:50-52)
         if (payload.get("warp") or payload.get("resize_to") or payload.get("upscale_to") or payload.get("chroma_nr")
-                or payload.get("canvas_resolution") or host.is_cuda or host.dim() != 3 or int(host.shape[2]) != 3
-                or host.numel() < (1 << 24)
-                or (payload.get("u16_factor") is None if is_u16 else (payload.get("u16_factor") is not None or not payload.get("clip_on_device")))):
+                or payload.get("canvas_resolution") or settings.get("canvas_mode", "No") != "No" or host.is_cuda or host.dim() != 3
+                or int(host.shape[2]) not in (3, 4) or host.numel() < (1 << 24)
+                or (host.dtype not in (torch.float32, torch.int16))
+                or (payload.get("u16_factor") is None if is_u16 else payload.get("u16_factor") is not None)):
             self.stream_rejected = ("a device pre-path, a canvas, or a frame below 16.7 M samples: " + ", ".join(
                 f"{k} = {payload.get(k)!r}" for k in ("warp", "resize_to", "upscale_to", "chroma_nr", "canvas_resolution", "u16_factor",
                                                       "clip_on_device")) + f", frame {tuple(host.shape)} {host.dtype}")
             return None
         H, W = int(host.shape[0]), int(host.shape[1])
-        fr = payload.get("final_resolution")
+        fr = payload.get("final_resolution") if final_scaling == "cpu" else None  # (cpu_processor.py:411-412: the final scaling)
         if fr is not None and (int(fr[0]), int(fr[1])) != (H, W):
             self.stream_rejected = f"the finished frame is scaled to {fr}"
             return None
@@ -610,7 +630,6 @@ class HipProcessor:
         if n < 2:
             self.stream_rejected = f"{n} band(s) of {H} rows above the stencils' reach {ha} + {ma}"
             return None
-        self._stash_payload = None
         self.stream_rejected = None
         bounds = [H * i // n for i in range(n + 1)]
         # the last bands are the ones nothing hides (their stencil stages, tail and download run behind the last byte of the upload):
@@ -621,16 +640,18 @@ class HipProcessor:
         bounds = sorted(set(bounds + cut))
         n = len(bounds) - 1
         bufs = getattr(self, "_stream_bufs", None)
-        if bufs is None or bufs["shape"] != (H, W) or bufs["mtf"] != mtf:
+        chans = 3 if is_u16 else int(host.shape[2])  # (a payload with upstream's constant alpha plane, gpu_processor.py:765: 4)
+        if bufs is None or bufs["shape"] != (H, W, chans) or bufs["mtf"] != mtf:
             def planes():
                 return torch.empty((3, H, W), dtype=torch.float32, device=self.device)
 
-            bufs = self._stream_bufs = {"shape": (H, W), "mtf": mtf, "image": torch.empty((H, W, 3), dtype=torch.float32, device=self.device),
+            bufs = self._stream_bufs = {"shape": (H, W, chans), "mtf": mtf,
+                                        "image": torch.empty((H, W, chans), dtype=torch.float32, device=self.device),
                                         "E": planes(), "D": planes(), "D2": planes() if mtf else None,
                                         "u8": torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)}
         image, E, D, D2, out_u8 = bufs["image"], bufs["E"], bufs["D"], bufs["D2"], bufs["u8"]
-        if is_u16 and bufs.get("u16") is None:
-            bufs["u16"] = torch.empty((H, W, 3), dtype=torch.int16, device=self.device)
+        if is_u16 and (bufs.get("u16") is None or tuple(bufs["u16"].shape) != tuple(host.shape)):
+            bufs["u16"] = torch.empty(tuple(host.shape), dtype=torch.int16, device=self.device)
         raw16 = bufs.get("u16") if is_u16 else None
         nres = self.result_buffers
         fresh, copies = None, []
@@ -766,7 +787,7 @@ class HipProcessor:
                 rows = image[a0:a1]
                 if is_u16:
                     ctx.decode_u16(raw16[a0:a1], payload["u16_factor"], out=rows)
-                else:
+                elif payload.get("clip_on_device"):
                     rows.clamp_(0.0, 65504.0)  # np.clip(image, 0, 65504) of gpu_processor.py:275, band by band
                 if pointwise:  # LUTs only: one fused pass per band, straight to uint8
                     ctx.stage_front(rows, p, 2, in_gy0=a0, out_u8=out_u8, out_gy0=0, y0=a0, y1=a1, H_global=H)
@@ -867,6 +888,15 @@ class HipProcessor:
         directions with the render (raw2film_amd.sharding.BatchSharder.run(..., collect=...) does exactly that) -- what the
         reference's queue.write_texture / read_texture pair serialises."""
         torch = self._torch
+        src = cpu_payload.get("image_array")
+        if self.stream_bands > 1 and not (isinstance(src, torch.Tensor) and (src.is_cuda or src.is_pinned())):
+            # a large frame in ordinary (pageable) host memory: its copy blocks this thread, so nothing of the next frame's host work
+            # would overlap it -- it overlaps its own upload, render and download band by band instead (_process_streamed; 24 MP:
+            # 7.0 against 7.5 ms, uint16 4.7 against 5.0) and is back when this call returns.  A pinned payload keeps the
+            # frame-in-flight scheme below (2.9 against 3.5 ms for uint16: tools/batch_pageable_probe.py)
+            res = self._stream_payload(cpu_payload, negative_film, grain_size, grain_sigma, final_scaling, **settings)
+            if res is not None:
+                return PendingFrame.finished(res)
         if getattr(self, "_up_stream", None) is None:
             self._up_stream = torch.cuda.Stream(device=self.device)
             self._down_stream = torch.cuda.Stream(device=self.device)

@@ -599,6 +599,21 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
         assert calls == [True], calls
         d = np.abs(got16.astype(np.int16) - want16.astype(np.int16))
         assert (d.max() == 0) if exact else (d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size), (kw, int(d.max()), int(np.count_nonzero(d)))
+    # the two-phase API's device phase streams its payload the same way: upstream's payload with the constant alpha plane (clamped on
+    # the host in phase 1), the uint16 payload, serial and "submitted"
+    pre = {k: v for k, v in base.items() if k not in ("lens_correction", "frame_width", "frame_height")}
+    for src_, ex in ((img, {}), (raw, dict(exposure=0.5))):
+        pay = banded.extract_image_data_cpu(src_, lens_correction=False, frame_width=36, frame_height=36, **ex)
+        assert pay["image_array"].shape[2] == (4 if src_ is img else 3)
+        want5 = plain.process_preloaded(pay, neg, 6, 0.4, frame_width=36, frame_height=36, grain=2, **pre).copy()
+        banded.stream_rejected = "not asked"
+        got5 = banded.process_preloaded(pay, neg, 6, 0.4, frame_width=36, frame_height=36, grain=2, **pre).copy()
+        assert banded.stream_rejected is None
+        got6 = banded.submit_preloaded(pay, neg, 6, 0.4, frame_width=36, frame_height=36, grain=2, **pre)
+        assert got6.ready()  # (a pageable payload streams and is back at once; a pinned one stays in flight)
+        np.testing.assert_array_equal(got6.result(), got5)
+        d = np.abs(got5.astype(np.int16) - want5.astype(np.int16))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size, (int(d.max()), int(np.count_nonzero(d)))
     # the histogram source is the streamed frame's device copy
     got2 = banded.process(img, neg, 6, 0.4, cache=False, **base, grain=2).copy()
     np.testing.assert_array_equal(banded.last_output.cpu().numpy(), got2)
