@@ -806,6 +806,22 @@ def main():
                                         "gpu_processor.py:275 on the device, prepare_and_render = table checks + r2f_render, download = uint8 "
                                         "result into a pinned buffer; load_and_upload = the first two together")
         proc.result_buffers = 0
+        # ... and what a slider step costs: a preview re-render through the same call -- the frame already on the device (cache=True),
+        # one film setting changed, a 1500 x 1000 preview back on the host
+        pv = dict(settings, resolution=(1000, 1500), lens_correction=False)
+        proc.process(host_np, neg, 6, 0.4, seed=GRAIN_SEED, **pv)
+        proc.process(host_np, neg, 6, 0.4, seed=GRAIN_SEED, exp_comp=0.01, **pv)
+        ts = []
+        for i in range(12):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            proc.process(host_np, neg, 6, 0.4, seed=GRAIN_SEED, exp_comp=0.02 + 0.01 * i, **pv)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        copies["preview_rerender_ms"] = sorted(ts)[len(ts) // 2]
+        copies["preview_rerender_note"] = ("HipProcessor.process(host ndarray, resolution=(1000, 1500)) with the frame already on the device and "
+                                           "one film setting changed per call, median of 12: table rebuild + a 1.5 MP render + its download + the "
+                                           "source array's fingerprint (a 192 KB sample since round 6: 0.14 ms; all of 32 rows before: 2.4 ms of a "
+                                           "2.76 ms call at 100 MP)")
         gb = H * W * 3 / 1e9
         copies["GB_per_s"] = {"h2d_f32": 4 * gb / (copies["h2d_f32_ms"] * 1e-3), "h2d_u16": 2 * gb / (copies["h2d_u16_ms"] * 1e-3),
                               "d2h_u8": gb / (copies["d2h_u8_ms"] * 1e-3)}
