@@ -820,9 +820,8 @@ class HipProcessor:
         down.synchronize()
         for c in copies:
             c.result()
-        self._texture = (image, None, {k: v for k, v in payload.items() if k != "image_array"})
-        self.image_param_dict = None
-        self._texture_src = None
+        # (the frame kept on the device for re-renders -- a preview's, typically -- is left alone: an export in between does not cost
+        # the preview its cached frame, which the one-after-the-other path has to overwrite because it works in it)
         self.last_output = out_u8
         if fresh is not None:
             return fresh

@@ -629,6 +629,20 @@ def test_a_large_host_frame_streams_through_the_pipeline_in_row_bands():
         np.testing.assert_array_equal(got4, want4, err_msg=str(kw))
         streamed += calls == [True]
     assert streamed >= 2, streamed  # (a crop below 16.7 M samples takes the other path)
+    # an export in between leaves the frame a preview keeps on the device alone: the preview's next re-render uploads nothing
+    loads = []
+    inner_load = banded.prepare_gpu_textures
+    banded.prepare_gpu_textures = lambda p: (loads.append(1), inner_load(p))[1]
+    pv = dict(base, resolution=(600, 600), grain=0, halation=False, sharpness=False)
+    p1 = banded.process(img, neg, 6, 0.4, **pv)
+    assert loads == [1]
+    del calls[:]
+    banded.process(img, neg, 6, 0.4, cache=False, **base, grain=0, halation=False, sharpness=False)  # the export: streamed
+    assert calls == [True] and loads == [1]
+    p2 = banded.process(img, neg, 6, 0.4, **pv)
+    np.testing.assert_array_equal(p1, p2)
+    assert loads == [1], "the preview's frame had to be uploaded again"
+    banded.prepare_gpu_textures = inner_load
     # frames that do not qualify take the other path and give its result
     for kw in (dict(canvas_mode="Proportional", canvas_scale=1.1), dict(highlight_burn=0.5), dict(rotation=3.0), dict(cache=True)):
         del calls[:]
